@@ -1,0 +1,320 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under exaconstit_amd/ may include, link or call this.
+//
+// CPU restatement of the callers of the hot path, enough to run the reference's regression cases end-to-end
+// and compare with its golden curves (test/data/*_stress.txt):
+//   NonlinearMechOperator::Mult / Setup / GetGradient / GetUpdateBCsAction   reference src/mechanics_operator.cpp:288-483
+//   MechOperatorJacobiSmoother                                              reference src/mechanics_operator_ext.cpp:11-55
+//   L<->E + essential-dof masking                                           reference src/mechanics_operator_ext.cpp:125-202
+//   ExaNewtonSolver::Mult, ExaNewtonLSSolver::Mult                          reference src/mechanics_solver.cpp:39-143,155-281
+//   SystemDriver::Solve / SolveInit / UpdateVelocity / UpdateModel          reference src/system_driver.cpp:221-558
+//   main time-step loop, state initialisation, boundary attributes          reference src/mechanics_driver.cpp:837-907,1058-1231
+//   ExaModel::UpdateEndCoords / UpdateStress / UpdateStateVars              reference src/mechanics_model.cpp:435-481
+//   ECMechXtalModel::init_state_vars                                        reference src/mechanics_ecmech.hpp:264-300
+// MFEM's CGSolver (not in /root/reference) is restated from its published algorithm.
+#pragma once
+#include <vector>
+#include <cmath>
+#include <cstdio>
+#include <chrono>
+#include "fem_port.hpp"
+
+namespace drv {
+
+enum Assembly { ASM_PA = 0, ASM_EA = 1 };
+enum NLSolver { NL_NR = 0, NL_NRLS = 1 };
+enum Precond { PC_IDENTITY = 0, PC_JACOBI = 1 };   // IDENTITY reproduces the reference's stale dinv
+
+struct BCSet {            // one entry per step at which the essential BCs change (BCManager)
+   int step;              // 1-based
+   std::vector<int> ids, comps;
+   std::vector<double> vals;   // 3 per id
+};
+
+struct Config {
+   int nx, ny, nz, p; double sx, sy, sz;
+   int xtal, kin; std::vector<double> props; double temp_k;
+   std::vector<int> elem_grain;        // 0-based grain of each element (x fastest)
+   std::vector<double> quats;          // (4, ngrains)
+   std::vector<double> dts;            // one per step
+   std::vector<BCSet> bcs;
+   int assembly = ASM_PA, nl_solver = NL_NR, precond = PC_IDENTITY;
+   double newton_rel = 5e-5, newton_abs = 5e-10; int newton_iter = 25;
+   double krylov_rel = 1e-7, krylov_abs = 1e-27; int krylov_iter = 1000;
+   bool additional_avgs = false;
+   bool second_order_terms = false;
+   bool use_input_temperature = false;
+   int verbose = 0;
+};
+
+struct Result {
+   std::vector<double> avg_stress;     // 6 per step
+   std::vector<double> avg_def_grad;   // 9 per step
+   std::vector<double> avg_pl_work;    // 1 per step
+   std::vector<double> avg_dp_tensor;  // 6 per step
+   std::vector<int> newton_iters, krylov_iters, model_calls;
+   long qpt_updates = 0; double t_model = 0, t_krylov = 0, t_total = 0;
+   int failed = 0;
+};
+
+struct Sim {
+   Config cfg; fem::RefElem re; fem::Mesh mesh; ecm::Model mdl;
+   int nstatev, E, Q, n, NN, ND; size_t P;
+   std::vector<double> x_ref, x_beg, x_cur, v_sol;
+   std::vector<double> stress0, stress1, state0, state1, matgrad, J;
+   std::vector<char> ess; std::vector<double> ess_val;
+   std::vector<double> dmat, C4, D4, emat, diag, dinv;
+   double dt = 0;
+   Result* res = nullptr;
+   fem::ModelOpts mo;
+   long krylov_total = 0; int model_calls = 0;
+};
+
+inline double dot(const std::vector<double>& a, const std::vector<double>& b) { double s = 0; for (size_t i = 0; i < a.size(); i++) s += a[i] * b[i]; return s; }
+inline double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+inline void sim_init(Sim& s, const Config& cfg) {
+   s.cfg = cfg;
+   fem::ref_elem_init(s.re, cfg.p);
+   fem::mesh_init(s.mesh, s.re, cfg.nx, cfg.ny, cfg.nz, cfg.sx, cfg.sy, cfg.sz);
+   ecm::model_init(s.mdl, cfg.xtal, cfg.kin, cfg.props.data(), (int)cfg.props.size());
+   s.nstatev = ecm::NUM_HIST + 2; s.E = s.mesh.E; s.Q = s.re.Q; s.n = s.re.n; s.NN = s.mesh.NN; s.ND = 3 * s.NN; s.P = (size_t)s.E * s.Q;
+   s.x_ref = s.mesh.X; s.x_beg = s.mesh.X; s.x_cur = s.mesh.X; s.v_sol.assign(s.ND, 0.0);
+   s.stress0.assign(6 * s.P, 0.0); s.stress1.assign(6 * s.P, 0.0);
+   s.state0.assign(s.nstatev * s.P, 0.0); s.state1.assign(s.nstatev * s.P, 0.0);
+   s.matgrad.assign(36 * s.P, 0.0); s.J.assign(9 * s.P, 0.0);
+   s.ess.assign(s.ND, 0); s.ess_val.assign(s.ND, 0.0);
+   s.diag.assign(s.ND, 1.0); s.dinv.assign(s.ND, 1.0);
+   s.mo.po.second_order_terms = cfg.second_order_terms; s.mo.po.use_input_temperature = cfg.use_input_temperature;
+   // initial state: library history defaults, grain quaternion spliced at offset 9, rel. volume 1, e_int 0
+   double h0[ecm::NUM_HIST]; ecm::hist_init(s.mdl, h0);
+   for (int e = 0; e < s.E; e++) for (int q = 0; q < s.Q; q++) {
+      double* sv = &s.state0[s.nstatev * (q + (size_t)s.Q * e)];
+      for (int i = 0; i < ecm::NUM_HIST; i++) sv[i] = h0[i];
+      const double* qg = &cfg.quats[4 * cfg.elem_grain[e]];
+      for (int i = 0; i < 4; i++) sv[ecm::iHistLbQ + i] = qg[i];
+      sv[ecm::NUM_HIST] = 1.0; sv[ecm::NUM_HIST + 1] = 0.0;
+   }
+}
+
+// boundary attribute of a node set: 1 z-min, 2 x-min, 3 y-min, 4 z-max, 5 x-max, 6 y-max  (mechanics_driver.cpp:1207-1227)
+inline bool node_on_face(const fem::Mesh& m, int g, int id) {
+   const int i = g % m.nnx, j = (g / m.nnx) % m.nny, k = g / (m.nnx * m.nny);
+   switch (id) { case 1: return k == 0; case 2: return i == 0; case 3: return j == 0; case 4: return k == m.nnz - 1; case 5: return i == m.nnx - 1; default: return j == m.nny - 1; }
+}
+
+// component codes: BCData.cpp:25-116
+inline void comp_mask(int code, bool c[3]) {
+   c[0] = c[1] = c[2] = false;
+   switch (code) { case 1: c[0] = true; break; case 2: c[1] = true; break; case 3: c[2] = true; break; case 4: c[0] = c[1] = true; break;
+                   case 5: c[1] = c[2] = true; break; case 6: c[0] = c[2] = true; break; case 7: c[0] = c[1] = c[2] = true; break; default: break; }
+}
+
+inline void update_ess_bdr(Sim& s, const BCSet& bc) {
+   std::fill(s.ess.begin(), s.ess.end(), 0); std::fill(s.ess_val.begin(), s.ess_val.end(), 0.0);
+   for (size_t b = 0; b < bc.ids.size(); b++) {
+      bool c[3]; comp_mask(bc.comps[b], c);
+      for (int g = 0; g < s.NN; g++) if (node_on_face(s.mesh, g, bc.ids[b])) for (int k = 0; k < 3; k++) if (c[k]) {
+         s.ess[g + s.NN * k] = 1; s.ess_val[g + s.NN * k] = bc.vals[3 * b + k];
+      }
+   }
+}
+
+inline void update_velocity(Sim& s, std::vector<double>& v) { for (int i = 0; i < s.ND; i++) if (s.ess[i]) v[i] = s.ess_val[i]; }
+
+// NonlinearMechOperator::Setup<upd_crds>
+inline void op_setup(Sim& s, const std::vector<double>& v, bool upd_crds) {
+   if (upd_crds) for (int i = 0; i < s.ND; i++) s.x_cur[i] = s.x_beg[i] + v[i] * s.dt;   // UpdateEndCoords
+   std::vector<double> xe((size_t)3 * s.n * s.E), ve((size_t)3 * s.n * s.E);
+   fem::restrict_LtoE(s.mesh, s.x_cur.data(), xe.data());
+   fem::jacobians(s.re, s.E, xe.data(), s.J.data());
+   fem::restrict_LtoE(s.mesh, v.data(), ve.data());
+   double t0 = now();
+   int nf = fem::model_setup(s.mdl, s.Q, s.E, s.n, s.nstatev, s.dt, s.cfg.temp_k, s.J.data(), s.re.G.data(), ve.data(),
+                             s.stress0.data(), s.state0.data(), s.stress1.data(), s.state1.data(), s.matgrad.data(), nullptr, s.mo);
+   if (s.res) { s.res->t_model += now() - t0; s.res->qpt_updates += (long)s.P; s.res->failed += nf; }
+   s.model_calls++;
+}
+
+inline void residual_action(Sim& s, std::vector<double>& y) {   // Hform->Setup(); Hform->Mult
+   s.dmat.resize(9 * s.P);
+   fem::assemble_pa(s.Q, s.E, s.re.W.data(), s.J.data(), s.stress1.data(), s.dmat.data());
+   std::vector<double> ye((size_t)3 * s.n * s.E, 0.0);
+   fem::add_mult_pa(s.Q, s.E, s.n, s.re.G.data(), s.dmat.data(), ye.data());
+   std::fill(y.begin(), y.end(), 0.0);
+   fem::restrict_EtoL_add(s.mesh, ye.data(), y.data());
+   for (int i = 0; i < s.ND; i++) if (s.ess[i]) y[i] = 0.0;
+}
+
+inline void op_mult(Sim& s, const std::vector<double>& v, std::vector<double>& y) { op_setup(s, v, true); residual_action(s, y); }
+
+inline void grad_setup(Sim& s) {   // Hform->GetGradient + AssembleDiagonal
+   std::vector<double> de((size_t)3 * s.n * s.E, 0.0);
+   if (s.cfg.assembly == ASM_PA) {
+      s.C4.resize(81 * s.P); s.D4.resize(81 * s.P);
+      fem::transform_matgrad_4d(s.P, s.matgrad.data(), s.C4.data());
+      fem::assemble_grad_pa(s.Q, s.E, s.dt, s.re.W.data(), s.J.data(), s.C4.data(), s.D4.data());
+      fem::assemble_grad_diag_pa(s.Q, s.E, s.n, s.dt, s.re.W.data(), s.re.G.data(), s.J.data(), s.matgrad.data(), de.data());
+   } else {
+      s.emat.resize((size_t)9 * s.n * s.n * s.E);
+      fem::assemble_ea(s.Q, s.E, s.n, s.dt, s.re.W.data(), s.re.G.data(), s.J.data(), s.matgrad.data(), s.emat.data());
+      fem::ea_diag(s.E, s.n, s.emat.data(), de.data());
+   }
+   std::fill(s.diag.begin(), s.diag.end(), 0.0);
+   fem::restrict_EtoL_add(s.mesh, de.data(), s.diag.data());
+   for (int i = 0; i < s.ND; i++) if (s.ess[i]) s.diag[i] = 1.0;
+   if (s.cfg.precond == PC_JACOBI) for (int i = 0; i < s.ND; i++) s.dinv[i] = s.ess[i] ? 1.0 : 1.0 / s.diag[i];
+   else std::fill(s.dinv.begin(), s.dinv.end(), 1.0);
+}
+
+inline void grad_mult(Sim& s, const std::vector<double>& x, std::vector<double>& y, bool constrained = true) {
+   std::vector<double> xc(x);
+   if (constrained) for (int i = 0; i < s.ND; i++) if (s.ess[i]) xc[i] = 0.0;
+   std::vector<double> xe((size_t)3 * s.n * s.E), ye((size_t)3 * s.n * s.E, 0.0);
+   fem::restrict_LtoE(s.mesh, xc.data(), xe.data());
+   if (s.cfg.assembly == ASM_PA) fem::add_mult_grad_pa(s.Q, s.E, s.n, s.re.G.data(), s.D4.data(), xe.data(), ye.data());
+   else fem::ea_mult(s.E, s.n, s.emat.data(), xe.data(), ye.data());
+   std::fill(y.begin(), y.end(), 0.0);
+   fem::restrict_EtoL_add(s.mesh, ye.data(), y.data());
+   if (constrained) for (int i = 0; i < s.ND; i++) if (s.ess[i]) y[i] = 0.0;
+}
+
+// MFEM CGSolver::Mult with iterative_mode=false
+inline int cg_solve(Sim& s, const std::vector<double>& b, std::vector<double>& x) {
+   const int N = s.ND;
+   std::vector<double> r(b), z(N), d(N);
+   std::fill(x.begin(), x.end(), 0.0);
+   for (int i = 0; i < N; i++) z[i] = s.dinv[i] * r[i];
+   d = z;
+   double nom = dot(d, r);
+   if (nom < 0) return -1;
+   const double r0 = std::fmax(nom * s.cfg.krylov_rel * s.cfg.krylov_rel, s.cfg.krylov_abs * s.cfg.krylov_abs);
+   if (nom <= r0) return 0;
+   grad_mult(s, d, z);
+   double den = dot(z, d);
+   if (den <= 0) return -1;
+   int i = 1;
+   while (true) {
+      const double alpha = nom / den;
+      for (int k = 0; k < N; k++) { x[k] += alpha * d[k]; r[k] -= alpha * z[k]; }
+      for (int k = 0; k < N; k++) z[k] = s.dinv[k] * r[k];
+      const double betanom = dot(r, z);
+      if (betanom <= r0) break;
+      if (++i > s.cfg.krylov_iter) break;
+      const double beta = betanom / nom;
+      for (int k = 0; k < N; k++) d[k] = z[k] + beta * d[k];
+      grad_mult(s, d, z);
+      den = dot(d, z);
+      if (den <= 0) break;
+      nom = betanom;
+   }
+   return i;
+}
+
+// ExaNewtonSolver::Mult / ExaNewtonLSSolver::Mult (b = empty)
+inline bool newton_solve(Sim& s, std::vector<double>& x, int& iters) {
+   const int N = s.ND;
+   std::vector<double> r(N), c(N), xt(N);
+   op_mult(s, x, r);
+   double norm = std::sqrt(dot(r, r)), norm0 = norm, norm_prev;
+   const double norm_max = std::fmax(s.cfg.newton_rel * norm, s.cfg.newton_abs);
+   double scale = 1.0; bool converged = false; int it;
+   for (it = 0; true; it++) {
+      if (s.cfg.verbose) std::printf("  Newton iteration %2d : ||r|| = %.6e%s\n", it, norm, "");
+      if (norm <= norm_max) { converged = true; break; }
+      if (it >= s.cfg.newton_iter) { converged = false; break; }
+      grad_setup(s);
+      double t0 = now();
+      int kit = cg_solve(s, r, c);
+      if (s.res) s.res->t_krylov += now() - t0;
+      s.krylov_total += (kit > 0 ? kit : 0);
+      if (s.cfg.nl_solver == NL_NRLS) {
+         // quadratic line search on q(scale) through ||r|| at scale 0, 1/2, 1       mechanics_solver.cpp:223-257
+         const double q1 = norm;
+         for (int i = 0; i < N; i++) xt[i] = x[i] - c[i];
+         op_mult(s, xt, r); const double q3 = std::sqrt(dot(r, r));
+         for (int i = 0; i < N; i++) xt[i] = x[i] - 0.5 * c[i];
+         op_mult(s, xt, r); const double q2 = std::sqrt(dot(r, r));
+         const double eps = (3.0 * q1 - 4.0 * q2 + q3) / (4.0 * (q1 - 2.0 * q2 + q3));
+         if ((q1 - 2.0 * q2 + q3) > 0 && eps > 0 && eps < 1) scale = eps;
+         else if (q3 < q1) scale = 1.0;
+         else scale = 0.05;
+      }
+      if (scale == 0.0) { converged = false; break; }
+      for (int i = 0; i < N; i++) x[i] -= scale * c[i];
+      op_mult(s, x, r);
+      norm_prev = norm; norm = std::sqrt(dot(r, r));
+      if (s.cfg.nl_solver == NL_NR) scale = (norm / norm_prev > 0.5) ? 0.5 : 1.0;
+   }
+   (void)norm0;
+   iters = it;
+   return converged;
+}
+
+// SystemDriver::SolveInit : corrector for a change of essential BCs
+inline void solve_init(Sim& s, const std::vector<double>& xprev, std::vector<double>& x) {
+   const int N = s.ND;
+   std::vector<double> deltaF(N, 0.0), b(N, 0.0), resid(N, 0.0);
+   for (int i = 0; i < N; i++) if (s.ess[i]) deltaF[i] = x[i] - xprev[i];
+   // GetUpdateBCsAction
+   op_setup(s, xprev, false);
+   grad_setup(s);
+   grad_mult(s, deltaF, b, false);
+   residual_action(s, resid);
+   for (int i = 0; i < N; i++) { if (s.ess[i]) b[i] = 0.0; b[i] += resid[i]; }
+   double t0 = now();
+   int kit = cg_solve(s, b, x);
+   if (s.res) s.res->t_krylov += now() - t0;
+   s.krylov_total += (kit > 0 ? kit : 0);
+   for (int i = 0; i < N; i++) x[i] = -x[i] + xprev[i];
+}
+
+inline void update_model(Sim& s, Result& res) {
+   s.stress0.swap(s.stress1); s.state0.swap(s.state1);
+   double a[9];
+   fem::vol_avg(s.Q, s.E, 6, s.re.W.data(), s.J.data(), s.stress0.data(), a, true);
+   for (int i = 0; i < 6; i++) res.avg_stress.push_back(a[i]);
+   if (s.cfg.additional_avgs) {
+      std::vector<double> sv(s.nstatev);
+      fem::vol_avg(s.Q, s.E, s.nstatev, s.re.W.data(), s.J.data(), s.state0.data(), sv.data(), false);
+      res.avg_pl_work.push_back(sv[ecm::iHistA_flowStr]);
+      // deformation gradient: grad of current coordinates w.r.t. the reference configuration   mechanics_operator.cpp:393-427
+      std::vector<double> xe((size_t)3 * s.n * s.E), Jr(9 * s.P), ce((size_t)3 * s.n * s.E), F(9 * s.P, 0.0);
+      fem::restrict_LtoE(s.mesh, s.x_ref.data(), xe.data()); fem::jacobians(s.re, s.E, xe.data(), Jr.data());
+      fem::restrict_LtoE(s.mesh, s.x_cur.data(), ce.data());
+      fem::grad_calc(s.Q, s.E, s.n, Jr.data(), s.re.G.data(), ce.data(), F.data());
+      // (the reference averages with the determinants cached for the current configuration)
+      fem::vol_avg(s.Q, s.E, 9, s.re.W.data(), s.J.data(), F.data(), a, true);
+      for (int i = 0; i < 9; i++) res.avg_def_grad.push_back(a[i]);
+      fem::calc_dp_mat(s.mdl, s.P, s.nstatev, s.state0.data(), F.data());
+      fem::vol_avg(s.Q, s.E, 9, s.re.W.data(), s.J.data(), F.data(), a, true);
+      const int map[6] = { 0, 4, 8, 5, 2, 1 };
+      for (int i = 0; i < 6; i++) res.avg_dp_tensor.push_back(a[map[i]]);
+   }
+}
+
+inline void run_case(const Config& cfg, Result& res) {
+   Sim s; sim_init(s, cfg); s.res = &res;
+   const int nsteps = (int)cfg.dts.size();
+   double t_start = now();
+   for (int ti = 1; ti <= nsteps; ti++) {
+      s.dt = cfg.dts[ti - 1];
+      s.model_calls = 0; s.krylov_total = 0;
+      if (cfg.verbose) std::printf("step %d dt %g\n", ti, s.dt);
+      for (const BCSet& bc : cfg.bcs) if (bc.step == ti) {
+         std::vector<double> v_prev(s.v_sol);
+         update_ess_bdr(s, bc);
+         update_velocity(s, s.v_sol);
+         solve_init(s, v_prev, s.v_sol);
+      }
+      update_velocity(s, s.v_sol);
+      int iters = 0;
+      bool ok = newton_solve(s, s.v_sol, iters);
+      if (!ok) { res.failed += 1000000; if (cfg.verbose) std::printf("Newton failed at step %d\n", ti); }
+      res.newton_iters.push_back(iters); res.krylov_iters.push_back((int)s.krylov_total); res.model_calls.push_back(s.model_calls);
+      update_model(s, res);
+      s.x_beg = s.x_cur;
+   }
+   res.t_total = now() - t_start;
+}
+
+}  // namespace drv

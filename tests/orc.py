@@ -1,0 +1,166 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) + loader for the reference's regression cases.
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The regression-case loader mirrors how the reference's driver interprets its options file
+(reference src/option_parser.cpp:26-932, src/mechanics_driver.cpp:243-546) for the subset the golden cases use.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REFDATA = os.path.join(ROOT, "tests", "golden", "refdata")
+
+XTAL = {"fcc": 0, "bcc": 1}
+KIN = {"powervoce": 0, "powervocenl": 1, "mtsdd": 2}
+ASM = {"pa": 0, "ea": 1, "full": 1}   # FULL assembles the same operator as EA (sparse matrix + AMG in the reference)
+NLS = {"nr": 0, "nrls": 1}
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+def _ip(a):
+    return a.ctypes.data_as(ip)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _lib = C.CDLL(so)
+        _lib.orc_ref_elem.restype = C.c_int
+    return _lib
+
+
+class OrcCase(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("p", C.c_int),
+                ("sx", C.c_double), ("sy", C.c_double), ("sz", C.c_double),
+                ("xtal", C.c_int), ("kin", C.c_int), ("nprops", C.c_int), ("props", dp), ("temp_k", C.c_double),
+                ("ngrains", C.c_int), ("elem_grain", ip), ("quats", dp),
+                ("nsteps", C.c_int), ("dts", dp),
+                ("nbc", C.c_int), ("bc_step", ip), ("bc_nids", ip), ("bc_ids", ip), ("bc_comps", ip), ("bc_vals", dp),
+                ("assembly", C.c_int), ("nl_solver", C.c_int), ("precond", C.c_int),
+                ("newton_rel", C.c_double), ("newton_abs", C.c_double), ("newton_iter", C.c_int),
+                ("krylov_rel", C.c_double), ("krylov_abs", C.c_double), ("krylov_iter", C.c_int),
+                ("additional_avgs", C.c_int), ("second_order_terms", C.c_int), ("use_input_temperature", C.c_int),
+                ("verbose", C.c_int)]
+
+
+class OrcResult(C.Structure):
+    _fields_ = [("avg_stress", dp), ("avg_def_grad", dp), ("avg_pl_work", dp), ("avg_dp_tensor", dp),
+                ("newton_iters", ip), ("krylov_iters", ip), ("model_calls", ip),
+                ("qpt_updates", C.c_int64), ("t_model", C.c_double), ("t_krylov", C.c_double), ("t_total", C.c_double),
+                ("failed", C.c_int)]
+
+
+def load_case(toml_name, datadir=REFDATA):
+    """Parse one of the reference's regression option files into a plain dict (auto mesh + ExaCMech subset)."""
+    import tomli
+    with open(os.path.join(datadir, toml_name), "rb") as f:
+        t = tomli.load(f)
+    props = np.loadtxt(os.path.join(datadir, t["Properties"]["Matl_Props"]["floc"])).ravel()
+    g = t["Properties"]["Grain"]
+    quats = np.loadtxt(os.path.join(datadir, g["ori_floc"]))[: g["num_grains"]]
+    grains = np.loadtxt(os.path.join(datadir, g["grain_floc"])).astype(np.int64).ravel()
+    mesh = t["Mesh"]
+    ncuts = mesh["Auto"]["ncuts"]
+    length = mesh["Auto"]["length"]
+    ref = int(mesh.get("ref_ser", 0))
+    nx, ny, nz = [int(c) * 2 ** ref for c in ncuts]
+    # uniform refinement: children inherit the parent's grain id
+    f = 2 ** ref
+    eg = np.empty(nx * ny * nz, dtype=np.int32)
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                eg[i + nx * (j + ny * k)] = grains[(i // f) + ncuts[0] * ((j // f) + ncuts[1] * (k // f))] - 1
+    tm = t["Time"]
+    if "Custom" in tm:
+        dts = np.loadtxt(os.path.join(datadir, tm["Custom"]["floc"])).ravel()[: tm["Custom"]["nsteps"]]
+        auto = None
+    elif "Auto" in tm:
+        dts = None
+        auto = tm["Auto"]
+    else:
+        dt, tf = tm["Fixed"]["dt"], tm["Fixed"]["t_final"]
+        n = int(round(tf / dt))
+        dts = np.full(n, dt)
+        auto = None
+    bcs = t["BCs"]
+    if bcs.get("changing_ess_bcs", False):
+        steps = bcs["update_steps"]
+        ids, comps, vals = bcs["essential_ids"], bcs["essential_comps"], bcs["essential_vals"]
+    else:
+        steps = [1]
+        ids, comps, vals = [bcs["essential_ids"]], [bcs["essential_comps"]], [bcs["essential_vals"]]
+    sol = t["Solvers"]
+    ecm = t["Model"]["ExaCMech"]
+    vis = t.get("Visualizations", {})
+    return dict(
+        nx=nx, ny=ny, nz=nz, p=int(mesh.get("p_refinement", 1)), length=[float(x) for x in length],
+        xtal=XTAL[ecm["xtal_type"].lower()], kin=KIN[ecm["slip_type"].lower()], props=props,
+        temp_k=float(t["Properties"]["temperature"]), elem_grain=eg, quats=np.ascontiguousarray(quats, dtype=np.float64),
+        dts=dts, auto=auto, bc_steps=steps, bc_ids=ids, bc_comps=comps, bc_vals=vals,
+        assembly=ASM[sol.get("assembly", "FULL").lower()], nl_solver=NLS[sol.get("NR", {}).get("nl_solver", "NR").lower()],
+        newton_rel=sol["NR"]["rel_tol"], newton_abs=sol["NR"]["abs_tol"], newton_iter=sol["NR"]["iter"],
+        krylov_rel=sol["Krylov"]["rel_tol"], krylov_abs=sol["Krylov"]["abs_tol"], krylov_iter=sol["Krylov"]["iter"],
+        additional_avgs=bool(vis.get("additional_avgs", False)),
+    )
+
+
+def run_case(case, nsteps=None, precond=0, second_order_terms=False, use_input_temperature=False, verbose=0):
+    """Run a regression case on the oracle; returns dict of arrays."""
+    L = lib()
+    dts = np.ascontiguousarray(case["dts"], dtype=np.float64)
+    if nsteps is not None:
+        dts = dts[:nsteps]
+    ns = len(dts)
+    props = np.ascontiguousarray(case["props"], dtype=np.float64)
+    eg = np.ascontiguousarray(case["elem_grain"], dtype=np.int32)
+    quats = np.ascontiguousarray(case["quats"], dtype=np.float64)
+    bc_step = np.array(case["bc_steps"], dtype=np.int32)
+    bc_nids = np.array([len(x) for x in case["bc_ids"]], dtype=np.int32)
+    bc_ids = np.array([i for x in case["bc_ids"] for i in x], dtype=np.int32)
+    bc_comps = np.array([i for x in case["bc_comps"] for i in x], dtype=np.int32)
+    bc_vals = np.array([v for x in case["bc_vals"] for v in x], dtype=np.float64)
+    c = OrcCase(case["nx"], case["ny"], case["nz"], case["p"], *case["length"],
+                case["xtal"], case["kin"], len(props), _p(props), case["temp_k"],
+                quats.shape[0], _ip(eg), _p(quats), ns, _p(dts),
+                len(bc_step), _ip(bc_step), _ip(bc_nids), _ip(bc_ids), _ip(bc_comps), _p(bc_vals),
+                case["assembly"], case["nl_solver"], precond,
+                case["newton_rel"], case["newton_abs"], case["newton_iter"],
+                case["krylov_rel"], case["krylov_abs"], case["krylov_iter"],
+                int(case["additional_avgs"]), int(second_order_terms), int(use_input_temperature), verbose)
+    out = dict(avg_stress=np.zeros((ns, 6)), avg_def_grad=np.zeros((ns, 9)), avg_pl_work=np.zeros(ns),
+               avg_dp_tensor=np.zeros((ns, 6)), newton_iters=np.zeros(ns, np.int32), krylov_iters=np.zeros(ns, np.int32),
+               model_calls=np.zeros(ns, np.int32))
+    r = OrcResult(_p(out["avg_stress"]), _p(out["avg_def_grad"]), _p(out["avg_pl_work"]), _p(out["avg_dp_tensor"]),
+                  _ip(out["newton_iters"]), _ip(out["krylov_iters"]), _ip(out["model_calls"]), 0, 0, 0, 0, 0)
+    L.orc_run_case(C.byref(c), C.byref(r))
+    out.update(qpt_updates=r.qpt_updates, t_model=r.t_model, t_krylov=r.t_krylov, t_total=r.t_total, failed=r.failed)
+    return out
+
+
+def golden(name):
+    return np.loadtxt(os.path.join(REFDATA, name), ndmin=2)
+
+
+def fmt6(a):
+    """Round to the 6 significant digits the reference prints (default ostream precision)."""
+    return np.array([float("%.6g" % v) for v in np.ravel(a)]).reshape(np.shape(a))
