@@ -1,0 +1,211 @@
+// C ABI of libexaconstit_hip.so — see include/exaconstit_hip.h for the reference interfaces each entry replaces.
+#include "exa_internal.hpp"
+#include <cstring>
+#include <cstdio>
+
+int exa_launch_model_setup(exa_ctx*, double, const double*, const double*, const double*, const double*, double*, double*, double*, hipStream_t);
+int exa_launch_init_state(exa_ctx*, double*, const double*, const double*, hipStream_t);
+int exa_launch_calc_dp(exa_ctx*, const double*, double*, hipStream_t);
+int exa_launch_jacobians(exa_ctx*, const double*, double*, hipStream_t);
+int exa_launch_grad_calc(exa_ctx*, const double*, const double*, double*, hipStream_t);
+int exa_launch_residual_setup(exa_ctx*, const double*, const double*, hipStream_t);
+int exa_launch_residual_apply(exa_ctx*, double*, hipStream_t);
+int exa_launch_residual_p1(exa_ctx*, const double*, const double*, double*, bool, hipStream_t);
+int exa_launch_grad_setup_pa(exa_ctx*, double, const double*, const double*, hipStream_t);
+int exa_launch_grad_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, hipStream_t);
+int exa_launch_grad_diag_p1(exa_ctx*, double*, hipStream_t);
+int exa_launch_assemble_ea_p1(exa_ctx*, hipStream_t);
+int exa_launch_ea_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, hipStream_t);
+int exa_launch_ea_diag_p1(exa_ctx*, double*, hipStream_t);
+int exa_launch_ea_export_p1(exa_ctx*, double*, hipStream_t);
+int exa_launch_restrict(exa_ctx*, const double*, double*, hipStream_t);
+int exa_launch_restrict_T(exa_ctx*, const double*, double*, hipStream_t);
+int exa_launch_vol_avg(exa_ctx*, const double*, const double*, int, double*, int, hipStream_t);
+
+namespace {
+constexpr int VOL_AVG_BLOCKS = 512;
+inline hipStream_t S(exa_stream s) { return reinterpret_cast<hipStream_t>(s); }
+int fail(exa_ctx* ctx, int code, const char* msg) { if (ctx) ctx->err = msg; return code; }
+}
+
+extern "C" {
+
+exa_ctx* exa_create(const exa_config* cfg, int* err) {
+   auto set = [&](int e) { if (err) *err = e; };
+   if (!cfg || cfg->nelems <= 0 || cfg->order < 1 || cfg->order > 3) { set(EXA_ERR_ARG); return nullptr; }
+   exa_ctx* ctx = new exa_ctx();
+   ctx->cfg = *cfg; ctx->cfg.props = nullptr;
+   if (!exa_fill_mat_params(*cfg, ctx->mp, ctx->hist_init, ctx->err)) { std::fprintf(stderr, "exa_create: %s\n", ctx->err.c_str()); delete ctx; set(EXA_ERR_ARG); return nullptr; }
+   if (cfg->integ != EXA_INTEG_FULL) { std::fprintf(stderr, "exa_create: B-bar integration is not built yet\n"); delete ctx; set(EXA_ERR_UNSUPPORTED); return nullptr; }
+   ctx->p = cfg->order; const int np = ctx->p + 1; ctx->n = np * np * np; ctx->Q = ctx->n; ctx->E = cfg->nelems; ctx->P = (int64_t)ctx->E * ctx->Q;
+   ctx->nstatev = ecmdev::NSTATEV;
+   if (cfg->device >= 0) { if (hipSetDevice(cfg->device) != hipSuccess) { delete ctx; set(EXA_ERR_HIP); return nullptr; } }
+   if (hipGetDevice(&ctx->device) != hipSuccess) { std::fprintf(stderr, "exa_create: no HIP device available\n"); delete ctx; set(EXA_ERR_HIP); return nullptr; }
+   exa_build_ref_elem(ctx->p, ctx->G_host, ctx->W_host);
+   bool ok = true;
+   ok = ok && hipMalloc(&ctx->G_dev, sizeof(double) * ctx->G_host.size()) == hipSuccess;
+   ok = ok && hipMalloc(&ctx->W_dev, sizeof(double) * ctx->W_host.size()) == hipSuccess;
+   ok = ok && hipMalloc(&ctx->fail_count_dev, sizeof(int)) == hipSuccess;
+   ctx->scratch_bytes = sizeof(double) * VOL_AVG_BLOCKS * 64;
+   ok = ok && hipMalloc(&ctx->scratch_dev, ctx->scratch_bytes) == hipSuccess;
+   if (ok) {
+      ok = ok && hipMemcpy(ctx->G_dev, ctx->G_host.data(), sizeof(double) * ctx->G_host.size(), hipMemcpyHostToDevice) == hipSuccess;
+      ok = ok && hipMemcpy(ctx->W_dev, ctx->W_host.data(), sizeof(double) * ctx->W_host.size(), hipMemcpyHostToDevice) == hipSuccess;
+      ok = ok && hipMemset(ctx->fail_count_dev, 0, sizeof(int)) == hipSuccess;
+   }
+   if (!ok) { std::fprintf(stderr, "exa_create: device allocation failed\n"); exa_destroy(ctx); set(EXA_ERR_HIP); return nullptr; }
+   set(EXA_OK);
+   return ctx;
+}
+
+void exa_destroy(exa_ctx* ctx) {
+   if (!ctx) return;
+   (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->scratch_dev);
+   (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat);
+   delete ctx;
+}
+
+const char* exa_last_error(const exa_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int exa_num_state_vars(const exa_ctx* ctx) { return ctx ? ctx->nstatev : EXA_ERR_ARG; }
+int exa_nodes_per_elem(const exa_ctx* ctx) { return ctx ? ctx->n : EXA_ERR_ARG; }
+int exa_qpts_per_elem(const exa_ctx* ctx) { return ctx ? ctx->Q : EXA_ERR_ARG; }
+
+int exa_shape_table(const exa_ctx* ctx, double* G_host, double* W_host) {
+   if (!ctx) return EXA_ERR_ARG;
+   if (G_host) std::memcpy(G_host, ctx->G_host.data(), sizeof(double) * ctx->G_host.size());
+   if (W_host) std::memcpy(W_host, ctx->W_host.data(), sizeof(double) * ctx->W_host.size());
+   return EXA_OK;
+}
+
+int exa_init_state(exa_ctx* ctx, double* state0, const double* quats, exa_stream s) {
+   if (!ctx || !state0 || !quats) return fail(ctx, EXA_ERR_ARG, "exa_init_state: null pointer");
+   double* hist_dev = ctx->scratch_dev;   // 26 doubles
+   EXA_HIP_CHECK(ctx, hipMemcpyAsync(hist_dev, ctx->hist_init, sizeof(double) * ecmdev::NUM_HIST, hipMemcpyHostToDevice, S(s)));
+   return exa_launch_init_state(ctx, state0, quats, hist_dev, S(s));
+}
+
+int exa_model_setup(exa_ctx* ctx, double dt, const double* J, const double* vel, const double* stress0, const double* state0,
+                    double* stress1, double* state1, double* ddsdde, exa_stream s) {
+   if (!ctx || !J || !vel || !stress0 || !state0 || !stress1 || !state1 || !ddsdde) return fail(ctx, EXA_ERR_ARG, "exa_model_setup: null pointer");
+   if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup: dt must be positive");
+   return exa_launch_model_setup(ctx, dt, J, vel, stress0, state0, stress1, state1, ddsdde, S(s));
+}
+
+int exa_model_status(exa_ctx* ctx, exa_stream s) {
+   if (!ctx) return EXA_ERR_ARG;
+   int h = 0;
+   EXA_HIP_CHECK(ctx, hipMemcpyAsync(&h, ctx->fail_count_dev, sizeof(int), hipMemcpyDeviceToHost, S(s)));
+   EXA_HIP_CHECK(ctx, hipStreamSynchronize(S(s)));
+   return h;
+}
+
+int exa_calc_dp(exa_ctx* ctx, const double* state, double* dp, exa_stream s) {
+   if (!ctx || !state || !dp) return fail(ctx, EXA_ERR_ARG, "exa_calc_dp: null pointer");
+   return exa_launch_calc_dp(ctx, state, dp, S(s));
+}
+
+int exa_jacobians(exa_ctx* ctx, const double* xe, double* J, exa_stream s) {
+   if (!ctx || !xe || !J) return fail(ctx, EXA_ERR_ARG, "exa_jacobians: null pointer");
+   return exa_launch_jacobians(ctx, xe, J, S(s));
+}
+
+int exa_grad_calc(exa_ctx* ctx, const double* J, const double* fe, double* out, exa_stream s) {
+   if (!ctx || !J || !fe || !out) return fail(ctx, EXA_ERR_ARG, "exa_grad_calc: null pointer");
+   return exa_launch_grad_calc(ctx, J, fe, out, S(s));
+}
+
+int exa_residual_setup(exa_ctx* ctx, const double* J, const double* stress1, exa_stream s) {
+   if (!ctx || !J || !stress1) return fail(ctx, EXA_ERR_ARG, "exa_residual_setup: null pointer");
+   if (!ctx->dmat) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->dmat, sizeof(double) * 9 * ctx->P));
+   ctx->have_resid = true;
+   return exa_launch_residual_setup(ctx, J, stress1, S(s));
+}
+
+int exa_residual_apply(exa_ctx* ctx, double* y, exa_stream s) {
+   if (!ctx || !y) return fail(ctx, EXA_ERR_ARG, "exa_residual_apply: null pointer");
+   if (!ctx->have_resid) return fail(ctx, EXA_ERR_STATE, "exa_residual_apply called before exa_residual_setup");
+   return exa_launch_residual_apply(ctx, y, S(s));
+}
+
+int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, exa_stream s) {
+   if (!ctx || !J || !C) return fail(ctx, EXA_ERR_ARG, "exa_grad_setup: null pointer");
+   if (ctx->p != 1) return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_grad_setup: only p = 1 is built in this round");
+   if (!ctx->pa) { EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa, pa_bytes(ctx->E, ctx->Q))); EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa, 0, pa_bytes(ctx->E, ctx->Q), S(s))); }
+   int rc = exa_launch_grad_setup_pa(ctx, dt, J, C, S(s));
+   if (rc) return rc;
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
+      const size_t bytes = (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * 576 * PA_BLK * sizeof(double);
+      if (!ctx->emat) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->emat, bytes));
+      rc = exa_launch_assemble_ea_p1(ctx, S(s));
+   }
+   ctx->have_grad = (rc == EXA_OK);
+   return rc;
+}
+
+int exa_grad_apply(exa_ctx* ctx, const double* x, double* y, exa_stream s) {
+   if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply: null pointer");
+   if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply called before exa_grad_setup");
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_apply_p1(ctx, x, y, false, nullptr, S(s));
+   return exa_launch_grad_apply_p1(ctx, x, y, false, nullptr, S(s));
+}
+
+int exa_grad_diagonal(exa_ctx* ctx, double* d, exa_stream s) {
+   if (!ctx || !d) return fail(ctx, EXA_ERR_ARG, "exa_grad_diagonal: null pointer");
+   if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_diagonal called before exa_grad_setup");
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_diag_p1(ctx, d, S(s));
+   return exa_launch_grad_diag_p1(ctx, d, S(s));
+}
+
+int exa_grad_get_ea(exa_ctx* ctx, double* emat, exa_stream s) {
+   if (!ctx || !emat) return fail(ctx, EXA_ERR_ARG, "exa_grad_get_ea: null pointer");
+   if (!ctx->have_grad || ctx->cfg.assembly != EXA_ASSEMBLY_EA) return fail(ctx, EXA_ERR_STATE, "exa_grad_get_ea: no element matrices assembled");
+   return exa_launch_ea_export_p1(ctx, emat, S(s));
+}
+
+int exa_set_connectivity(exa_ctx* ctx, const int32_t* conn, int nnodes) {
+   if (!ctx || !conn || nnodes <= 0) return fail(ctx, EXA_ERR_ARG, "exa_set_connectivity: bad argument");
+   ctx->conn = conn; ctx->nnodes = nnodes;
+   return EXA_OK;
+}
+
+int exa_restrict(exa_ctx* ctx, const double* L, double* Ev, exa_stream s) {
+   if (!ctx || !L || !Ev) return fail(ctx, EXA_ERR_ARG, "exa_restrict: null pointer");
+   if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_restrict: connectivity not set");
+   return exa_launch_restrict(ctx, L, Ev, S(s));
+}
+
+int exa_restrict_transpose_add(exa_ctx* ctx, const double* Ev, double* L, exa_stream s) {
+   if (!ctx || !L || !Ev) return fail(ctx, EXA_ERR_ARG, "exa_restrict_transpose_add: null pointer");
+   if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_restrict_transpose_add: connectivity not set");
+   return exa_launch_restrict_T(ctx, Ev, L, S(s));
+}
+
+int exa_grad_apply_lvec(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, exa_stream s) {
+   if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply_lvec: null pointer");
+   if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec: connectivity not set");
+   if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec called before exa_grad_setup");
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_apply_p1(ctx, x, y, true, mask, S(s));
+   return exa_launch_grad_apply_p1(ctx, x, y, true, mask, S(s));
+}
+
+int exa_residual_lvec(exa_ctx* ctx, const double* J, const double* stress1, double* y, exa_stream s) {
+   if (!ctx || !J || !stress1 || !y) return fail(ctx, EXA_ERR_ARG, "exa_residual_lvec: null pointer");
+   if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_residual_lvec: connectivity not set");
+   if (ctx->p != 1) return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_residual_lvec: only p = 1 is built in this round");
+   return exa_launch_residual_p1(ctx, J, stress1, y, true, S(s));
+}
+
+int exa_vol_avg(exa_ctx* ctx, const double* J, const double* qf, int vdim, int normalise, double* out_host, exa_stream s) {
+   if (!ctx || !J || !qf || !out_host || vdim < 1 || vdim > 63) return fail(ctx, EXA_ERR_ARG, "exa_vol_avg: bad argument");
+   const int nb = VOL_AVG_BLOCKS;
+   int rc = exa_launch_vol_avg(ctx, J, qf, vdim, ctx->scratch_dev, nb, S(s));
+   if (rc) return rc;
+   std::vector<double> part((size_t)(vdim + 1) * nb);
+   EXA_HIP_CHECK(ctx, hipMemcpyAsync(part.data(), ctx->scratch_dev, sizeof(double) * part.size(), hipMemcpyDeviceToHost, S(s)));
+   EXA_HIP_CHECK(ctx, hipStreamSynchronize(S(s)));
+   for (int c = 0; c <= vdim; c++) { double a = 0; for (int b = 0; b < nb; b++) a += part[(size_t)c * nb + b]; out_host[c] = a; }
+   if (normalise) for (int c = 0; c < vdim; c++) out_host[c] /= out_host[vdim];
+   return EXA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// Internal definitions of libexaconstit_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstdint>
+#include "../../include/exaconstit_hip.h"
+#include "ecm_device.hpp"
+
+#define EXA_HIP_CHECK(ctx, call)                                                                 \
+   do {                                                                                          \
+      hipError_t e_ = (call);                                                                    \
+      if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return EXA_ERR_HIP; } \
+   } while (0)
+
+// Internal layout of the partial-assembly gradient data ("pa data"), one record per quadrature point:
+//   36 doubles  Ct(i,j) = C(i,j) * dt * W_q / detJ      (column-major 6x6, Voigt, engineering shear)
+//    9 doubles  adj(J)(r,c) at slot 36 + 3 r + c
+//    1 double   W_q * detJ (quadrature weight in the current configuration)
+// stored as [block of 64 elements][qpt][23 slot-pairs][64 lanes][2] so that lane = element reads 16 B and a wave reads
+// 1 KiB contiguous per instruction.  (The reference stores 81 + 81 doubles per point: src/mechanics_integrators.cpp:395-414.)
+constexpr int PA_SLOTS = 46;
+constexpr int PA_PAIRS = 23;
+constexpr int PA_BLK = 64;
+
+struct exa_ctx {
+   exa_config cfg;
+   ecmdev::MatParams mp;
+   int p, n, Q, E;
+   int64_t P;               // E * Q
+   int nstatev;
+   int device;
+   std::string err;
+   std::vector<double> G_host, W_host;      // (n,3,Q), (Q)
+   double* G_dev = nullptr; double* W_dev = nullptr;
+   // residual PA data (D of AssemblePA), gradient PA data / EA matrices
+   double* dmat = nullptr;                  // (3,3,Q,E)
+   double* pa = nullptr;                    // see layout above
+   double* emat = nullptr;                  // EA: [block of 64 elements][(3n)^2][64]
+   bool have_resid = false, have_grad = false;
+   // L-vector support
+   const int32_t* conn = nullptr; int nnodes = 0;
+   // status
+   int* fail_count_dev = nullptr;
+   double* scratch_dev = nullptr; size_t scratch_bytes = 0;   // reductions
+   double hist_init[ecmdev::NUM_HIST];
+};
+
+// host-side reference element (H1 hex of order p at (p+1)^3 Gauss-Legendre points), src/mechanics_operator.cpp:237-261
+void exa_build_ref_elem(int p, std::vector<double>& G, std::vector<double>& W);
+bool exa_fill_mat_params(const exa_config& cfg, ecmdev::MatParams& mp, double* hist_init, std::string& err);
+
+static inline size_t pa_bytes(int E, int Q) { return (size_t)((E + PA_BLK - 1) / PA_BLK) * Q * PA_SLOTS * PA_BLK * sizeof(double); }

@@ -1,0 +1,115 @@
+// Fused constitutive kernels (gfx950): one launch replaces the seven passes of
+// ExaCMechModel::ModelSetup (reference src/mechanics_ecmech.cpp:192-258):
+//   StressSetup/StateVarsSetup copies, matGrad/vel_grad zero fills, grad_calc (src/mechanics_kernels.cpp:36-77),
+//   kernel_setup (src/mechanics_ecmech.cpp:42-99), getResponseECM, kernel_postprocessing (:116-171).
+// One thread per quadrature point; the reference shape-derivative table is staged in LDS; per-point state is read
+// and written once (928 B per point algorithmic traffic).
+#include "exa_internal.hpp"
+
+using namespace ecmdev;
+
+template <int KIN>
+__global__ __launch_bounds__(256) void k_model_setup(const MatParams mp, const int Q, const int n, const int64_t P, const double dt,
+                                                     const double* __restrict__ J, const double* __restrict__ G,
+                                                     const double* __restrict__ vel, const double* __restrict__ stress0,
+                                                     const double* __restrict__ state0, double* __restrict__ stress1,
+                                                     double* __restrict__ state1, double* __restrict__ cmat, int* __restrict__ fail) {
+   extern __shared__ double sG[];   // (n,3,Q)
+   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
+   __syncthreads();
+   const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (ip >= P) return;
+   const int q = (int)(ip % Q);
+   const int64_t e = ip / Q;
+   // inverse Jacobian (reference src/mechanics_kernels.cpp:38-61)
+   const double* Jq = J + 9 * ip;
+   const double J11 = Jq[0], J21 = Jq[1], J31 = Jq[2], J12 = Jq[3], J22 = Jq[4], J32 = Jq[5], J13 = Jq[6], J23 = Jq[7], J33 = Jq[8];
+   const double detJ = J11 * (J22 * J33 - J32 * J23) - J21 * (J12 * J33 - J32 * J13) + J31 * (J12 * J23 - J22 * J13);
+   const double di = 1.0 / detJ;
+   // Ji[s][t] = dxi_s/dx_t
+   const double Ji[3][3] = { { di * (J22 * J33 - J23 * J32), di * (J32 * J13 - J12 * J33), di * (J12 * J23 - J22 * J13) },
+                             { di * (J31 * J23 - J21 * J33), di * (J11 * J33 - J13 * J31), di * (J21 * J13 - J11 * J23) },
+                             { di * (J21 * J32 - J31 * J22), di * (J31 * J12 - J11 * J32), di * (J11 * J22 - J12 * J21) } };
+   // velocity gradient L(c,t) = sum_r v(r,c) dN_r/dx_t
+   double L[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+   const double* ve = vel + (int64_t)3 * n * e;
+   const double* Gq = sG + 3 * n * q;
+   for (int r = 0; r < n; r++) {
+      const double g0 = Gq[r], g1 = Gq[r + n], g2 = Gq[r + 2 * n];
+      const double b0 = g0 * Ji[0][0] + g1 * Ji[1][0] + g2 * Ji[2][0];
+      const double b1 = g0 * Ji[0][1] + g1 * Ji[1][1] + g2 * Ji[2][1];
+      const double b2 = g0 * Ji[0][2] + g1 * Ji[1][2] + g2 * Ji[2][2];
+      const double v0 = ve[r], v1 = ve[r + n], v2 = ve[r + 2 * n];
+      L[0] += v0 * b0; L[1] += v1 * b0; L[2] += v2 * b0;
+      L[3] += v0 * b1; L[4] += v1 * b1; L[5] += v2 * b1;
+      L[6] += v0 * b2; L[7] += v1 * b2; L[8] += v2 * b2;
+   }
+   const int rc = point_update<KIN>(mp, dt, L, state0 + NSTATEV * ip, stress0 + 6 * ip, state1 + NSTATEV * ip, stress1 + 6 * ip, cmat + 36 * ip);
+   if (rc) atomicAdd(fail, 1);
+}
+
+__global__ void k_init_state(const int Q, const int64_t P, const double* __restrict__ hist, const double* __restrict__ quats, double* __restrict__ state0) {
+   const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (ip >= P) return;
+   const int64_t e = ip / Q;
+   double* sv = state0 + NSTATEV * ip;
+   for (int i = 0; i < NUM_HIST; i++) sv[i] = hist[i];
+   for (int i = 0; i < 4; i++) sv[H_Q + i] = quats[4 * e + i];
+   sv[IND_VOL] = 1.0; sv[IND_EINT] = 0.0;
+}
+
+// calcDpMat (reference src/mechanics_ecmech.hpp:315-356)
+__global__ void k_calc_dp(const double qsign, const int64_t P, const double* __restrict__ state, double* __restrict__ dp) {
+   const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (ip >= P) return;
+   const double* sv = state + NSTATEV * ip;
+   double dphat[5] = { 0, 0, 0, 0, 0 };
+#pragma unroll
+   for (int a = 0; a < NSLIP; a++) {
+      const double g = sv[H_GDOT + a];
+#pragma unroll
+      for (int c = 0; c < 5; c++) dphat[c] += P_TAB[c][a] * g;
+   }
+   (void)qsign;
+   const double q[4] = { sv[H_Q], sv[H_Q + 1], sv[H_Q + 2], sv[H_Q + 3] };
+   double C[9]; quat_to_mat(q, C);
+   double sm[5]; rot_vecd(C, dphat, sm);
+   double t00, t11, t22, t01, t02, t12; vecd_to_sym(sm, t00, t11, t22, t01, t02, t12);
+   double* o = dp + 9 * ip;
+   o[0] = t00; o[1] = t01; o[2] = t02; o[3] = t01; o[4] = t11; o[5] = t12; o[6] = t02; o[7] = t12; o[8] = t22;
+}
+
+int exa_launch_model_setup(exa_ctx* ctx, double dt, const double* J, const double* vel, const double* stress0, const double* state0,
+                           double* stress1, double* state1, double* cmat, hipStream_t s) {
+   const int bs = 256;
+   const int64_t nb = (ctx->P + bs - 1) / bs;
+   const size_t lds = sizeof(double) * ctx->n * 3 * ctx->Q;
+   EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->fail_count_dev, 0, sizeof(int), s));
+   switch (ctx->mp.kin) {
+      case KIN_VOCE:
+         hipLaunchKernelGGL(k_model_setup<KIN_VOCE>, dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
+         break;
+      case KIN_VOCE_NL:
+         hipLaunchKernelGGL(k_model_setup<KIN_VOCE_NL>, dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
+         break;
+      default:
+         hipLaunchKernelGGL(k_model_setup<KIN_KMBALD>, dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
+         break;
+   }
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   return EXA_OK;
+}
+
+int exa_launch_init_state(exa_ctx* ctx, double* state0, const double* quats, const double* hist_dev, hipStream_t s) {
+   const int bs = 256;
+   hipLaunchKernelGGL(k_init_state, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->Q, ctx->P, hist_dev, quats, state0);
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   return EXA_OK;
+}
+
+int exa_launch_calc_dp(exa_ctx* ctx, const double* state, double* dp, hipStream_t s) {
+   const int bs = 256;
+   hipLaunchKernelGGL(k_calc_dp, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->mp.qsign, ctx->P, state, dp);
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   return EXA_OK;
+}

@@ -1,0 +1,115 @@
+"""ctypes binding of libexaconstit_hip.so (the C ABI of include/exaconstit_hip.h).
+
+No CPU fallback: if the library is missing this module raises at import; if no GPU is present exa_create fails.
+Device memory is passed as raw pointers (torch tensors' data_ptr() in the tests/bench — PyTorch is only the allocator).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libexaconstit_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C exaconstit_amd/csrc` (or __graft_entry__.build()); "
+        "there is no CPU fallback for the product path")
+
+# PyTorch bundles its own HIP runtime (soname libamdhip64.so.7).  Two HIP runtimes in one process do not share
+# devices, so when torch is the allocator it must be loaded FIRST: the dynamic loader then resolves this library's
+# NEEDED libamdhip64.so.7 to the copy torch already mapped.
+try:
+    import torch  # noqa: F401
+except ImportError:  # stand-alone use (C++ driver, plain ctypes): the system ROCm runtime is used
+    torch = None
+
+_lib = C.CDLL(LIB_PATH)
+
+EXA_FCC_VOCE, EXA_FCC_VOCE_NL, EXA_BCC_VOCE, EXA_BCC_VOCE_NL, EXA_FCC_KMDD, EXA_BCC_KMDD = range(6)
+EXA_ASSEMBLY_PA, EXA_ASSEMBLY_EA = 0, 1
+EXA_INTEG_FULL, EXA_INTEG_BBAR = 0, 1
+
+dptr = C.c_void_p
+
+
+class ExaConfig(C.Structure):
+    _fields_ = [("model", C.c_int), ("nprops", C.c_int), ("props", C.POINTER(C.c_double)), ("temp_k", C.c_double),
+                ("order", C.c_int), ("nelems", C.c_int), ("assembly", C.c_int), ("integ", C.c_int), ("device", C.c_int)]
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(_lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+# every symbol the header declares (tests check the list against include/exaconstit_hip.h)
+exa_create = _sig("exa_create", C.c_void_p, C.POINTER(ExaConfig), C.POINTER(C.c_int))
+exa_destroy = _sig("exa_destroy", None, C.c_void_p)
+exa_last_error = _sig("exa_last_error", C.c_char_p, C.c_void_p)
+exa_num_state_vars = _sig("exa_num_state_vars", C.c_int, C.c_void_p)
+exa_nodes_per_elem = _sig("exa_nodes_per_elem", C.c_int, C.c_void_p)
+exa_qpts_per_elem = _sig("exa_qpts_per_elem", C.c_int, C.c_void_p)
+exa_shape_table = _sig("exa_shape_table", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+exa_init_state = _sig("exa_init_state", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
+exa_model_setup = _sig("exa_model_setup", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
+exa_model_status = _sig("exa_model_status", C.c_int, C.c_void_p, C.c_void_p)
+exa_calc_dp = _sig("exa_calc_dp", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
+exa_jacobians = _sig("exa_jacobians", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
+exa_grad_calc = _sig("exa_grad_calc", C.c_int, C.c_void_p, dptr, dptr, dptr, C.c_void_p)
+exa_residual_setup = _sig("exa_residual_setup", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
+exa_residual_apply = _sig("exa_residual_apply", C.c_int, C.c_void_p, dptr, C.c_void_p)
+exa_grad_setup = _sig("exa_grad_setup", C.c_int, C.c_void_p, C.c_double, dptr, dptr, C.c_void_p)
+exa_grad_apply = _sig("exa_grad_apply", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
+exa_grad_diagonal = _sig("exa_grad_diagonal", C.c_int, C.c_void_p, dptr, C.c_void_p)
+exa_grad_get_ea = _sig("exa_grad_get_ea", C.c_int, C.c_void_p, dptr, C.c_void_p)
+exa_set_connectivity = _sig("exa_set_connectivity", C.c_int, C.c_void_p, dptr, C.c_int)
+exa_restrict = _sig("exa_restrict", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
+exa_restrict_transpose_add = _sig("exa_restrict_transpose_add", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
+exa_grad_apply_lvec = _sig("exa_grad_apply_lvec", C.c_int, C.c_void_p, dptr, dptr, dptr, C.c_void_p)
+exa_residual_lvec = _sig("exa_residual_lvec", C.c_int, C.c_void_p, dptr, dptr, dptr, C.c_void_p)
+exa_vol_avg = _sig("exa_vol_avg", C.c_int, C.c_void_p, dptr, dptr, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p)
+
+MODEL_IDS = {("fcc", "powervoce"): EXA_FCC_VOCE, ("fcc", "powervocenl"): EXA_FCC_VOCE_NL, ("bcc", "powervoce"): EXA_BCC_VOCE,
+             ("bcc", "powervocenl"): EXA_BCC_VOCE_NL, ("fcc", "mtsdd"): EXA_FCC_KMDD, ("bcc", "mtsdd"): EXA_BCC_KMDD}
+
+
+class Context:
+    """Owns one exa_ctx.  Mirrors how the reference's operator owns its model + integrator (mechanics_operator.cpp:49-225)."""
+
+    def __init__(self, model, props, temp_k, order, nelems, assembly=EXA_ASSEMBLY_PA, integ=EXA_INTEG_FULL, device=-1):
+        import numpy as np
+        self._props = np.ascontiguousarray(props, dtype=np.float64)
+        cfg = ExaConfig(model, len(self._props), self._props.ctypes.data_as(C.POINTER(C.c_double)), float(temp_k),
+                        order, nelems, assembly, integ, device)
+        err = C.c_int(0)
+        self.h = exa_create(C.byref(cfg), C.byref(err))
+        if not self.h:
+            raise RuntimeError(f"exa_create failed with code {err.value} (is a HIP device present and the model/props valid?)")
+        self.n = exa_nodes_per_elem(self.h)
+        self.Q = exa_qpts_per_elem(self.h)
+        self.E = nelems
+        self.nstatev = exa_num_state_vars(self.h)
+
+    def check(self, rc, what=""):
+        if rc < 0:
+            raise RuntimeError(f"{what} failed ({rc}): {exa_last_error(self.h).decode()}")
+        return rc
+
+    def shape_table(self):
+        import numpy as np
+        G = np.zeros(self.n * 3 * self.Q)
+        W = np.zeros(self.Q)
+        self.check(exa_shape_table(self.h, G.ctypes.data_as(C.POINTER(C.c_double)), W.ctypes.data_as(C.POINTER(C.c_double))))
+        return G, W
+
+    def close(self):
+        if self.h:
+            exa_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,120 @@
+/* exaconstit_hip.h — C ABI of libexaconstit_hip.so (MI355X / gfx950).
+ *
+ * The reference (LLNL/ExaConstit v0.7.0) has no C ABI: its replaceable seam for the hot path is two C++ class
+ * interfaces.  Each entry point below cites the reference interface it stands in for; INTEGRATION.md shows the
+ * MFEM-side adapters (HipExaModel : ExaModel, HipExaNLFIntegrator : ExaNLFIntegrator) that bind them.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device pointer owned by the caller; "host" pointers are host memory;
+ *   - every array is FP64 and uses the reference's layouts (column-major = first index fastest):
+ *       E-vector        (node, comp, elem)            reference src/mechanics_kernels.cpp:28-29
+ *       Jacobians       (3, 3, Q, E), J(i,j)=dx_i/dxi_j   reference src/mechanics_operator.cpp:379-390
+ *       shape table     (node, dir, qpt)              reference src/mechanics_operator.cpp:249-260
+ *       quadrature data (vdim, Q, E)                  reference src/mechanics_model.cpp:209-214
+ *       tangent         (6, 6, Q, E) column-major, Voigt (11,22,33,23,13,12), engineering shear
+ *   - every function returns int: 0 ok, <0 invalid argument / HIP error (see exa_last_error), and the work is
+ *     enqueued on the given stream without host synchronisation unless stated otherwise;
+ *   - no global state; one exa_ctx per (mesh partition, material); re-entrant per context.
+ */
+#ifndef EXACONSTIT_HIP_H
+#define EXACONSTIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct exa_ctx exa_ctx;
+typedef void* exa_stream;   /* hipStream_t */
+
+/* model ids: reference src/mechanics_ecmech.hpp:407-414 (Voce), :460-463 (KM-DD); chosen in
+ * reference src/mechanics_operator.cpp:49-210 from Model.ExaCMech.{xtal_type,slip_type} */
+enum { EXA_FCC_VOCE = 0, EXA_FCC_VOCE_NL = 1, EXA_BCC_VOCE = 2, EXA_BCC_VOCE_NL = 3, EXA_FCC_KMDD = 4, EXA_BCC_KMDD = 5 };
+/* reference src/option_types.hpp Assembly / IntegrationType */
+enum { EXA_ASSEMBLY_PA = 0, EXA_ASSEMBLY_EA = 1 };
+enum { EXA_INTEG_FULL = 0, EXA_INTEG_BBAR = 1 };
+
+enum { EXA_OK = 0, EXA_ERR_ARG = -1, EXA_ERR_HIP = -2, EXA_ERR_STATE = -3, EXA_ERR_UNSUPPORTED = -4 };
+
+typedef struct {
+   int model;            /* EXA_* model id */
+   int nprops;           /* 17 (Voce), 18 (Voce NL), 24 (KM-DD) — reference src/option_parser.cpp:396-478 */
+   const double* props;  /* host; parameter order of reference src/mechanics_ecmech.hpp:395-405,444-458 */
+   double temp_k;        /* Properties.temperature (the library overrides it with its EOS temperature, as ExaCMech does) */
+   int order;            /* H1 order p: n = Q = (p+1)^3 */
+   int nelems;           /* elements of this partition */
+   int assembly;         /* EXA_ASSEMBLY_* */
+   int integ;            /* EXA_INTEG_* */
+   int device;           /* HIP device ordinal; -1 = current */
+} exa_config;
+
+/* lifetime -------------------------------------------------------------------------------------------------- */
+exa_ctx* exa_create(const exa_config* cfg, int* err);          /* ECMechXtalModel ctor, src/mechanics_ecmech.hpp:126-262 */
+void     exa_destroy(exa_ctx* ctx);
+const char* exa_last_error(const exa_ctx* ctx);                /* MFEM_ABORT text equivalent */
+int exa_num_state_vars(const exa_ctx* ctx);                    /* numHist + ne + 1 = 28, src/mechanics_ecmech.hpp:136-141 */
+int exa_nodes_per_elem(const exa_ctx* ctx);
+int exa_qpts_per_elem(const exa_ctx* ctx);
+
+/* reference-element tables built on the host once: src/mechanics_operator.cpp:237-261, src/mechanics_integrators.cpp:184-197 */
+int exa_shape_table(const exa_ctx* ctx, double* G_host /*(n,3,Q)*/, double* W_host /*(Q)*/);
+
+/* ExaModel seam ------------------------------------------------------------------------------------------------ */
+/* getHistInfo + init_state_vars (src/mechanics_ecmech.hpp:248-300) with setStateVarData's quaternion splice
+ * (src/mechanics_driver.cpp:1058-1154): fills state0 (28,Q,E) from one quaternion per element. */
+int exa_init_state(exa_ctx* ctx, double* state0_dev, const double* quats_per_elem_dev /*(4,E)*/, exa_stream s);
+
+/* ExaCMechModel::ModelSetup (src/mechanics_ecmech.cpp:192-258), i.e. StressSetup/StateVarsSetup, grad_calc,
+ * kernel_setup, getResponseECM, kernel_postprocessing fused into one launch.  On return (stream order) stress1, state1
+ * and the column-major tangent d sigma/d eps hold end-of-step values.  Points whose local solve did not converge are
+ * counted; read the count with exa_model_status. */
+int exa_model_setup(exa_ctx* ctx, double dt, const double* jacobian_dev /*(3,3,Q,E)*/, const double* vel_evec_dev /*(n,3,E)*/,
+                    const double* stress0_dev, const double* state0_dev,
+                    double* stress1_dev, double* state1_dev, double* ddsdde_dev, exa_stream s);
+/* synchronises the stream; returns the number of non-converged points of the last exa_model_setup (>= 0) */
+int exa_model_status(exa_ctx* ctx, exa_stream s);
+
+/* calcDpMat (src/mechanics_ecmech.hpp:303-357): dp (3,3,Q,E) from the slip rates and orientation stored in state */
+int exa_calc_dp(exa_ctx* ctx, const double* state_dev, double* dp_dev, exa_stream s);
+
+/* geometry helpers (MFEM GeometricFactors + re-layout, src/mechanics_operator.cpp:350-391; grad_calc on any field,
+ * src/mechanics_kernels.cpp:7-78, used for the deformation gradient src/mechanics_operator.cpp:393-427) */
+int exa_jacobians(exa_ctx* ctx, const double* coords_evec_dev /*(n,3,E)*/, double* jacobian_dev, exa_stream s);
+int exa_grad_calc(exa_ctx* ctx, const double* jacobian_dev, const double* field_evec_dev, double* grad_dev /*(3,3,Q,E), overwritten*/, exa_stream s);
+
+/* ExaNLFIntegrator seam ---------------------------------------------------------------------------------------- */
+/* AssemblePA (src/mechanics_integrators.cpp:160-314): D = W sigma adj(J)^T kept inside the context */
+int exa_residual_setup(exa_ctx* ctx, const double* jacobian_dev, const double* stress1_dev, exa_stream s);
+/* AddMultPA (src/mechanics_integrators.cpp:518-557): y_evec += G^T D */
+int exa_residual_apply(exa_ctx* ctx, double* y_evec_dev, exa_stream s);
+/* PA: TransformMatGradTo4D + AssembleGradPA (src/mechanics_model.cpp:949-1061, src/mechanics_integrators.cpp:331-513)
+ * EA: AssembleEA (src/mechanics_integrators.cpp:756-1017).  The tangent is the column-major matGrad of exa_model_setup. */
+int exa_grad_setup(exa_ctx* ctx, double dt, const double* jacobian_dev, const double* ddsdde_dev, exa_stream s);
+/* AddMultGradPA (src/mechanics_integrators.cpp:562-622) | element mat-vec (spec src/mechanics_operator_ext.cpp:303-314):
+ * y_evec += K_e x_evec */
+int exa_grad_apply(exa_ctx* ctx, const double* x_evec_dev, double* y_evec_dev, exa_stream s);
+/* AssembleGradDiagonalPA (src/mechanics_integrators.cpp:625-748) | EA diagonal (spec src/mechanics_operator_ext.cpp:246-252):
+ * diag_evec += diag(K_e) */
+int exa_grad_diagonal(exa_ctx* ctx, double* diag_evec_dev, exa_stream s);
+/* EA only: copy the element matrices out in the reference layout (3n,3n,E) column-major, dof = node + n*comp */
+int exa_grad_get_ea(exa_ctx* ctx, double* emat_dev, exa_stream s);
+
+/* L-vector conveniences for callers without MFEM (element restriction, spec src/mechanics_operator_ext.cpp:149-157) -- */
+/* connectivity (n,E) of local node -> L-vector node; L-vectors are byNODES: [x0..xN, y0.., z0..] with nnodes entries per comp */
+int exa_set_connectivity(exa_ctx* ctx, const int32_t* conn_dev /*(n,E)*/, int nnodes);
+int exa_restrict(exa_ctx* ctx, const double* lvec_dev, double* evec_dev, exa_stream s);                 /* L -> E */
+int exa_restrict_transpose_add(exa_ctx* ctx, const double* evec_dev, double* lvec_dev, exa_stream s);   /* L += E^T */
+/* fused gather / apply / scatter-add of the gradient action on L-vectors (the PCG inner kernel): y_L += K x_L.
+ * mask_dev (nullable, 3*nnodes bytes): essential dofs — x is read as 0 there (spec src/mechanics_operator_ext.cpp:143-146). */
+int exa_grad_apply_lvec(exa_ctx* ctx, const double* x_lvec_dev, double* y_lvec_dev, const uint8_t* mask_dev, exa_stream s);
+/* fused AssemblePA + AddMultPA + E->L: y_L += B^T sigma */
+int exa_residual_lvec(exa_ctx* ctx, const double* jacobian_dev, const double* stress1_dev, double* y_lvec_dev, exa_stream s);
+/* volume average  sum_q W detJ val / sum_q W detJ  (src/mechanics_kernels.hpp:19-134); out_host[vdim] (+ volume in out_host[vdim]).
+ * Synchronises the stream. */
+int exa_vol_avg(exa_ctx* ctx, const double* jacobian_dev, const double* qf_dev, int vdim, int normalise, double* out_host, exa_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -285,7 +285,9 @@ inline void update_model(Sim& s, Result& res) {
       // (the reference averages with the determinants cached for the current configuration)
       fem::vol_avg(s.Q, s.E, 9, s.re.W.data(), s.J.data(), F.data(), a, true);
       for (int i = 0; i < 9; i++) res.avg_def_grad.push_back(a[i]);
-      fem::calc_dp_mat(s.mdl, s.P, s.nstatev, s.state0.data(), F.data());
+      // the reference evaluates calcDpMat on matVars1 AFTER the begin/end pointer swap, i.e. on the previous step's
+      // converged state (mechanics_ecmech.hpp:309 reads matVars1; system_driver.cpp:441,526) — reproduced here.
+      fem::calc_dp_mat(s.mdl, s.P, s.nstatev, s.state1.data(), F.data());
       fem::vol_avg(s.Q, s.E, 9, s.re.W.data(), s.J.data(), F.data(), a, true);
       const int map[6] = { 0, 4, 8, 5, 2, 1 };
       for (int i = 0; i < 6; i++) res.avg_dp_tensor.push_back(a[map[i]]);

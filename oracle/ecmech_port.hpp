@@ -348,7 +348,10 @@ inline void kmbald_gdot(const Model& m, const KinVals& kv, double tau, double& g
    static const double gdot_w_pl_scaling = std::getenv("ORC_PLS") ? std::atof(std::getenv("ORC_PLS")) : 10.0;
    gdot = 0; dgdot_dtau = 0;
    if (tau == 0.0) return;
-   const double g_i = 1.0 / kv.g, gAth = m.tau_a, at = std::fabs(tau);
+   // FCC ("Kin_FCC_B"): athermal threshold tau_a, thermal barrier g.  BCC ("Kin_BCC_A", withGAthermal): athermal
+   // threshold g = go + s*sqrt(rho), thermal (Peierls) barrier tau_a.
+   const bool withGAthermal = (m.xtal == XTAL_BCC);
+   const double g_i = withGAthermal ? 1.0 / m.tau_a : 1.0 / kv.g, gAth = withGAthermal ? kv.g : m.tau_a, at = std::fabs(tau);
    const double at_0 = std::fmax(0.0, at - gAth) * g_i;
    // drag-limited branch
    const double exp_arg_r = (at - gAth) / m.wrD;
@@ -503,6 +506,7 @@ inline bool problem_rj(Problem& pb, const double* x, double* R, double* Jac) {
       if (!std::isfinite(pb.gdot[a])) return false;
       pb.shrate_eff += std::fabs(pb.gdot[a]); pb.dp_dis_rate += tau[a] * pb.gdot[a];
    }
+   pb.dp_dis_rate *= pb.detV_ri;   // per current volume (pinned by test/data/voce_ea_pl_work.txt)
    const double so = pb.second_order_terms ? 1.0 : 0.0;
    double Mef[5][3], Men[5][3];
    m35(e_f, Mef); m35(pb.e_n, Men);

@@ -1,0 +1,210 @@
+"""GPU parity tests: HIP kernels (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (FP64 everywhere; north star: stress within 1e-6 rel-L2 of the CPU reference):
+  stress / state / velocity gradient : rel-L2 <= 1e-9   (both sides converge the same 8x8 point problem to 1e-10 scaled)
+  tangent                            : rel-L2 <= 1e-7
+  integrator actions                 : rel-L2 <= 1e-12  (pure linear algebra)
+The function-evaluation counter (state slot 3) depends on branch decisions of the trust-region solver at rounding level and
+is excluded.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hipref
+from hipref import rel_l2, ptr
+
+pytestmark = pytest.mark.gpu
+
+REFDATA_PROPS = {"voce": "props_cp_voce.txt", "vocenl": "props_cp_vocenl.txt", "mts": "props_cp_mts.txt"}
+
+
+def _props(orc, key):
+    return np.loadtxt(orc.REFDATA + "/" + REFDATA_PROPS[key]).ravel()
+
+
+def _orc_model_setup(orc, xtal, kin, props, rve, dt, J, vel_e, s0, sv0):
+    P = rve["E"] * rve["Q"]
+    s1 = np.zeros(6 * P); sv1 = np.zeros(28 * P); cm = np.zeros(36 * P); vg = np.zeros(9 * P)
+    nf = orc.lib().orc_model_setup(xtal, kin, orc._p(props), len(props), rve["Q"], rve["E"], rve["n"], 28, C.c_double(dt), C.c_double(298.0),
+                                   orc._p(J), orc._p(rve["G"]), orc._p(vel_e), orc._p(s0), orc._p(sv0), orc._p(s1), orc._p(sv1), orc._p(cm),
+                                   orc._p(vg), 1, 0, 0)
+    return nf, s1, sv1, cm, vg
+
+
+CASES = [
+    ("fcc_voce", 0, 0, "voce", 0),      # (name, oracle xtal, oracle kin, props, lib model id)
+    ("bcc_voce", 1, 0, "voce", 2),
+    ("fcc_voce_nl", 0, 1, "vocenl", 1),
+    ("fcc_kmdd", 0, 2, "mts", 4),
+    ("bcc_kmdd", 1, 2, "mts", 5),
+]
+
+
+@pytest.mark.parametrize("name,xtal,kin,pkey,model", CASES)
+def test_model_setup_matches_oracle(oracle, name, xtal, kin, pkey, model):
+    """Drive 8 kinematic steps (elastic -> fully plastic) and compare every output of ModelSetup each step."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    N = 6
+    rve = hipref.make_rve(orc, N, distort=0.15)
+    props = _props(orc, pkey)
+    P = rve["E"] * rve["Q"]
+    ctx = L.Context(model, props, 298.0, 1, rve["E"])
+    # reference-element table of the library == oracle's
+    G, W = ctx.shape_table()
+    assert rel_l2(G, rve["G"]) < 1e-14 and rel_l2(W, rve["W"]) < 1e-14
+    quats = hipref.random_quats(rve["E"])
+    d_quats = dev.up(quats.ravel())
+    d_state0 = dev.zeros(28 * P)
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_state0), ptr(d_quats), None))
+    sv0 = d_state0.cpu().numpy().copy()
+    hist = np.zeros(26); orc.lib().orc_hist_init(xtal, kin, orc._p(props), len(props), orc._p(hist))
+    sv_ref = np.tile(np.concatenate([hist, [1.0, 0.0]]), P).reshape(P, 28)
+    sv_ref[:, 9:13] = np.repeat(quats, rve["Q"], axis=0)
+    assert np.array_equal(sv0.reshape(P, 28), sv_ref)
+    s0 = np.zeros(6 * P)
+    v_nodes = hipref.velocity_field(rve)
+    vel_e = hipref.l_to_e(rve, v_nodes)
+    x = rve["X"].copy()
+    dts = [0.005, 0.195, 0.1, 0.1, 0.2, 0.4, 0.5, 1.0]
+    for step, dt in enumerate(dts):
+        x = x + v_nodes * dt                      # end-of-step coordinates
+        xe = hipref.l_to_e(rve, x)
+        J = np.zeros(9 * P); orc.lib().orc_jacobians(1, rve["E"], orc._p(xe), orc._p(J))
+        d_xe = dev.up(xe); d_J = dev.zeros(9 * P)
+        ctx.check(L.exa_jacobians(ctx.h, ptr(d_xe), ptr(d_J), None))
+        assert rel_l2(d_J.cpu().numpy(), J) < 1e-14
+        nf, s1, sv1, cm, vg = _orc_model_setup(orc, xtal, kin, props, rve, dt, J, vel_e, s0, sv0)
+        assert nf == 0
+        d = [dev.up(a) for a in (vel_e, s0, sv0)]
+        o = [dev.zeros(6 * P), dev.zeros(28 * P), dev.zeros(36 * P)]
+        ctx.check(L.exa_model_setup(ctx.h, dt, ptr(d_J), ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(o[0]), ptr(o[1]), ptr(o[2]), None))
+        assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+        g_s1, g_sv1, g_cm = [t.cpu().numpy() for t in o]
+        d_vg = dev.zeros(9 * P)
+        ctx.check(L.exa_grad_calc(ctx.h, ptr(d_J), ptr(d[0]), ptr(d_vg), None))
+        assert rel_l2(d_vg.cpu().numpy(), vg) < 1e-12
+        keep = np.ones(28, bool); keep[3] = False
+        a = g_sv1.reshape(P, 28)[:, keep]; b = sv1.reshape(P, 28)[:, keep]
+        # compare slot groups separately so that large entries do not hide small ones
+        assert rel_l2(g_s1, s1) < 1e-9, (name, step)
+        for lo, hi in ((0, 3), (3, 8), (8, 12), (12, 13), (13, 25), (25, 27)):
+            assert rel_l2(a[:, lo:hi], b[:, lo:hi]) < 1e-8, (name, step, lo)
+        assert rel_l2(g_cm, cm) < 1e-7, (name, step)
+        s0, sv0 = s1, sv1                          # both sides continue from the oracle's state
+    # the last steps must be plastic for the test to mean anything
+    assert np.abs(sv0.reshape(P, 28)[:, 14:26]).sum(axis=1).min() > 0
+    ctx.close()
+
+
+def _spd_tangent(P, seed=3):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((P, 6, 6))
+    Cm = A @ A.transpose(0, 2, 1) + 6 * np.eye(6)
+    Cm *= 50.0
+    Cm += 0.05 * rng.standard_normal((P, 6, 6))      # slightly non-symmetric, like a plasticity tangent
+    return np.ascontiguousarray(Cm.transpose(0, 2, 1)).ravel()   # (6,6,P) column-major per point
+
+
+@pytest.mark.parametrize("assembly", [0, 1])
+def test_integrators_match_oracle(oracle, assembly):
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    N = 7   # E = 343: not a multiple of the 64-element block
+    rve = hipref.make_rve(orc, N, distort=0.25, seed=11)
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    rng = np.random.default_rng(5)
+    ctx = L.Context(L.EXA_FCC_VOCE, _props(orc, "voce"), 298.0, 1, E, assembly=assembly)
+    xe = hipref.l_to_e(rve, rve["X"])
+    J = np.zeros(9 * P); orc.lib().orc_jacobians(1, E, orc._p(xe), orc._p(J))
+    d_J = dev.up(J)
+    # residual: AssemblePA + AddMultPA, and the dense AssembleElementVector
+    sig = rng.standard_normal(6 * P)
+    dmat = np.zeros(9 * P); orc.lib().orc_assemble_pa(Q, E, orc._p(rve["W"]), orc._p(J), orc._p(sig), orc._p(dmat))
+    y_ref = rng.standard_normal(3 * n * E); y0 = y_ref.copy()
+    orc.lib().orc_add_mult_pa(Q, E, n, orc._p(rve["G"]), orc._p(dmat), orc._p(y_ref))
+    y_dense = y0.copy(); orc.lib().orc_element_vector(Q, E, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(sig), orc._p(y_dense))
+    assert rel_l2(y_ref, y_dense) < 2e-14
+    d_sig = dev.up(sig); d_y = dev.up(y0)
+    ctx.check(L.exa_residual_setup(ctx.h, ptr(d_J), ptr(d_sig), None))
+    ctx.check(L.exa_residual_apply(ctx.h, ptr(d_y), None))
+    assert rel_l2(d_y.cpu().numpy(), y_ref) < 1e-13
+    # fused L-vector residual
+    d_conn = dev.up(rve["conn"])
+    ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+    yL_ref = np.zeros(3 * NN)
+    ye = np.zeros(3 * n * E); orc.lib().orc_add_mult_pa(Q, E, n, orc._p(rve["G"]), orc._p(dmat), orc._p(ye))
+    conn = rve["conn"].reshape(E, n)
+    for c in range(3):
+        np.add.at(yL_ref, conn + NN * c, ye.reshape(E, 3, n)[:, c, :])
+    d_yL = dev.zeros(3 * NN)
+    ctx.check(L.exa_residual_lvec(ctx.h, ptr(d_J), ptr(d_sig), ptr(d_yL), None))
+    assert rel_l2(d_yL.cpu().numpy(), yL_ref) < 1e-12
+    # gradient: PA (TransformMatGradTo4D + AssembleGradPA + AddMultGradPA) or EA (AssembleEA + mat-vec)
+    dt = 0.1
+    Cm = _spd_tangent(P)
+    x_e = rng.standard_normal(3 * n * E)
+    yg0 = rng.standard_normal(3 * n * E)
+    yg_ref = yg0.copy(); diag_ref = np.zeros(3 * n * E)
+    emat = np.zeros(9 * n * n * E)
+    orc.lib().orc_assemble_ea(Q, E, n, C.c_double(dt), orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(Cm), orc._p(emat))
+    if assembly == 0:
+        C4 = np.zeros(81 * P); D4 = np.zeros(81 * P)
+        orc.lib().orc_transform_4d(C.c_int64(P), orc._p(Cm), orc._p(C4))
+        orc.lib().orc_assemble_grad_pa(Q, E, C.c_double(dt), orc._p(rve["W"]), orc._p(J), orc._p(C4), orc._p(D4))
+        orc.lib().orc_add_mult_grad_pa(Q, E, n, orc._p(rve["G"]), orc._p(D4), orc._p(x_e), orc._p(yg_ref))
+        orc.lib().orc_assemble_grad_diag_pa(Q, E, n, C.c_double(dt), orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(Cm), orc._p(diag_ref))
+        # the reference's own unit-test identity: PA action == dense B^T C B action (test/mechanics_test.cpp:51-178)
+        y_ea = yg0.copy(); orc.lib().orc_ea_mult(E, n, orc._p(emat), orc._p(x_e), orc._p(y_ea))
+        # (B^T C B)^T x = B^T C^T B x: only equal for symmetric C, so compare with the transposed-tangent matrices instead
+        CmT = np.ascontiguousarray(Cm.reshape(P, 6, 6).transpose(0, 2, 1)).ravel()
+        ematT = np.zeros(9 * n * n * E)
+        orc.lib().orc_assemble_ea(Q, E, n, C.c_double(dt), orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(CmT), orc._p(ematT))
+        y_eaT = yg0.copy(); orc.lib().orc_ea_mult(E, n, orc._p(ematT), orc._p(x_e), orc._p(y_eaT))
+        assert rel_l2(yg_ref, y_eaT) < 1e-13
+    else:
+        orc.lib().orc_ea_mult(E, n, orc._p(emat), orc._p(x_e), orc._p(yg_ref))
+        orc.lib().orc_ea_diag(E, n, orc._p(emat), orc._p(diag_ref))
+    d_C = dev.up(Cm); d_x = dev.up(x_e); d_yg = dev.up(yg0); d_diag = dev.zeros(3 * n * E)
+    ctx.check(L.exa_grad_setup(ctx.h, dt, ptr(d_J), ptr(d_C), None))
+    ctx.check(L.exa_grad_apply(ctx.h, ptr(d_x), ptr(d_yg), None))
+    ctx.check(L.exa_grad_diagonal(ctx.h, ptr(d_diag), None))
+    assert rel_l2(d_yg.cpu().numpy(), yg_ref) < 1e-12
+    assert rel_l2(d_diag.cpu().numpy(), diag_ref) < 1e-12
+    if assembly == 1:
+        d_em = dev.zeros(9 * n * n * E)
+        ctx.check(L.exa_grad_get_ea(ctx.h, ptr(d_em), None))
+        assert rel_l2(d_em.cpu().numpy(), emat) < 1e-12
+    # fused L-vector action with an essential-dof mask
+    xL = rng.standard_normal(3 * NN)
+    mask = (rng.uniform(size=3 * NN) < 0.1).astype(np.uint8)
+    xm = np.where(mask, 0.0, xL)
+    xe_m = hipref.l_to_e(rve, xm)
+    ye = np.zeros(3 * n * E)
+    if assembly == 0:
+        orc.lib().orc_add_mult_grad_pa(Q, E, n, orc._p(rve["G"]), orc._p(D4), orc._p(xe_m), orc._p(ye))
+    else:
+        orc.lib().orc_ea_mult(E, n, orc._p(emat), orc._p(xe_m), orc._p(ye))
+    yL_ref = np.zeros(3 * NN)
+    for c in range(3):
+        np.add.at(yL_ref, conn + NN * c, ye.reshape(E, 3, n)[:, c, :])
+    d_xL = dev.up(xL); d_mask = dev.up(mask); d_yL = dev.zeros(3 * NN)
+    ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xL), ptr(d_yL), ptr(d_mask), None))
+    assert rel_l2(d_yL.cpu().numpy(), yL_ref) < 1e-12
+    # restriction pair
+    d_e = dev.zeros(3 * n * E)
+    ctx.check(L.exa_restrict(ctx.h, ptr(d_xL), ptr(d_e), None))
+    assert np.array_equal(d_e.cpu().numpy(), hipref.l_to_e(rve, xL))
+    # volume average
+    qf = rng.standard_normal(6 * P)
+    ref = np.zeros(6); orc.lib().orc_vol_avg(Q, E, 6, orc._p(rve["W"]), orc._p(J), orc._p(qf), orc._p(ref), 1)
+    out = np.zeros(7)
+    d_qf = dev.up(qf)
+    ctx.check(L.exa_vol_avg(ctx.h, ptr(d_J), ptr(d_qf), 6, 1, out.ctypes.data_as(C.POINTER(C.c_double)), None))
+    assert rel_l2(out[:6], ref) < 1e-12
+    ctx.close()
