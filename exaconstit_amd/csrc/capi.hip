@@ -12,10 +12,10 @@ int exa_launch_residual_setup(exa_ctx*, const double*, const double*, hipStream_
 int exa_launch_residual_apply(exa_ctx*, double*, hipStream_t);
 int exa_launch_residual_p1(exa_ctx*, const double*, const double*, double*, bool, hipStream_t);
 int exa_launch_grad_setup_pa(exa_ctx*, double, const double*, const double*, hipStream_t);
-int exa_launch_grad_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, hipStream_t);
+int exa_launch_grad_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t);
 int exa_launch_grad_diag_p1(exa_ctx*, double*, hipStream_t);
 int exa_launch_assemble_ea_p1(exa_ctx*, hipStream_t);
-int exa_launch_ea_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, hipStream_t);
+int exa_launch_ea_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t);
 int exa_launch_ea_diag_p1(exa_ctx*, double*, hipStream_t);
 int exa_launch_ea_export_p1(exa_ctx*, double*, hipStream_t);
 int exa_launch_restrict(exa_ctx*, const double*, double*, hipStream_t);
@@ -145,8 +145,8 @@ int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, ex
 int exa_grad_apply(exa_ctx* ctx, const double* x, double* y, exa_stream s) {
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply: null pointer");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply called before exa_grad_setup");
-   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_apply_p1(ctx, x, y, false, nullptr, S(s));
-   return exa_launch_grad_apply_p1(ctx, x, y, false, nullptr, S(s));
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_apply_p1(ctx, x, y, false, nullptr, nullptr, S(s));
+   return exa_launch_grad_apply_p1(ctx, x, y, false, nullptr, nullptr, S(s));
 }
 
 int exa_grad_diagonal(exa_ctx* ctx, double* d, exa_stream s) {
@@ -180,12 +180,18 @@ int exa_restrict_transpose_add(exa_ctx* ctx, const double* Ev, double* L, exa_st
    return exa_launch_restrict_T(ctx, Ev, L, S(s));
 }
 
-int exa_grad_apply_lvec(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, exa_stream s) {
+// driver-internal variant: `gate` (nullable) is a device flag; a non-zero value turns the launch into a no-op so that a
+// PCG loop whose scalars live on the device can be enqueued without host synchronisation.
+int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, exa_stream s) {
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec: connectivity not set");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec called before exa_grad_setup");
-   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_apply_p1(ctx, x, y, true, mask, S(s));
-   return exa_launch_grad_apply_p1(ctx, x, y, true, mask, S(s));
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_apply_p1(ctx, x, y, true, mask, gate, S(s));
+   return exa_launch_grad_apply_p1(ctx, x, y, true, mask, gate, S(s));
+}
+
+int exa_grad_apply_lvec(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, exa_stream s) {
+   return exa_grad_apply_lvec_gated(ctx, x, y, mask, nullptr, s);
 }
 
 int exa_residual_lvec(exa_ctx* ctx, const double* J, const double* stress1, double* y, exa_stream s) {

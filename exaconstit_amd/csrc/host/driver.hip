@@ -1,0 +1,471 @@
+// Implementation of the stand-alone host driver (see driver.hpp for the reference classes each part follows).
+#include "driver.hpp"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+extern "C" int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, exa_stream s);
+
+namespace exa_host {
+
+// =====================================================================================================================
+// Comm: RCCL loaded at run time so that single-GPU use has no collective-library dependency
+// =====================================================================================================================
+namespace {
+struct RcclApi {
+   void* h = nullptr;
+   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*GroupStart)() = nullptr;
+   ncclResult_t (*GroupEnd)() = nullptr;
+   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi& rccl() {
+   static RcclApi api;
+   if (!api.h) {
+      for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1" }) { api.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (api.h) break; }
+      if (!api.h) throw std::runtime_error(std::string("cannot load RCCL: ") + dlerror());
+      auto sym = [&](const char* n) { void* p = dlsym(api.h, n); if (!p) throw std::runtime_error(std::string("RCCL symbol missing: ") + n); return p; };
+      api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+      api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+      api.Send = (decltype(api.Send))sym("ncclSend");
+      api.Recv = (decltype(api.Recv))sym("ncclRecv");
+      api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+      api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+      api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+   }
+   return api;
+}
+void nccl_check(ncclResult_t r, const char* what) { if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + rccl().GetErrorString(r)); }
+}  // namespace
+
+void Comm::get_unique_id(void* out128) { ncclUniqueId id; nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId"); std::memcpy(out128, &id, sizeof(id)); }
+
+void Comm::init(int rank_, int nranks_, const void* uid) {
+   rank = rank_; nranks = nranks_;
+   if (nranks > 1) {
+      if (!uid) throw std::runtime_error("Comm::init: a RCCL unique id is required for nranks > 1");
+      ncclUniqueId id; std::memcpy(&id, uid, sizeof(id));
+      ncclComm_t c; nccl_check(rccl().CommInitRank(&c, nranks, id, rank), "ncclCommInitRank");
+      comm_ = c;
+   }
+   tmp_.alloc(64);
+}
+Comm::~Comm() { if (comm_) rccl().CommDestroy((ncclComm_t)comm_); }
+
+void Comm::allreduce_sum(double* dev, int n, hipStream_t s) { if (nranks > 1) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)comm_, s), "ncclAllReduce"); }
+void Comm::allreduce_min(double* dev, int n, hipStream_t s) { if (nranks > 1) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclMin, (ncclComm_t)comm_, s), "ncclAllReduce"); }
+
+double Comm::max_over_ranks(double v) {
+   if (nranks == 1) return v;
+   EXA_HC(hipMemcpy(tmp_.p, &v, sizeof(double), hipMemcpyHostToDevice));
+   nccl_check(rccl().AllReduce(tmp_.p, tmp_.p, 1, ncclDouble, ncclMax, (ncclComm_t)comm_, nullptr), "ncclAllReduce");
+   EXA_HC(hipMemcpy(&v, tmp_.p, sizeof(double), hipMemcpyDeviceToHost));
+   return v;
+}
+
+void Comm::setup_halo(const Partition& part) {
+   idx_.clear(); sbuf_.clear(); rbuf_.clear();
+   for (const Neighbor& nb : part.nbrs) {
+      idx_.emplace_back(nb.dofs.size()); idx_.back().upload(nb.dofs);
+      sbuf_.emplace_back(nb.dofs.size()); rbuf_.emplace_back(nb.dofs.size());
+   }
+}
+
+void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
+   if (nranks == 1) return;
+   const size_t nb = part.nbrs.size();
+   for (size_t i = 0; i < nb; i++) vk_pack((int64_t)idx_[i].n, idx_[i].p, y, sbuf_[i].p, s);
+   nccl_check(rccl().GroupStart(), "ncclGroupStart");
+   for (size_t i = 0; i < nb; i++) {
+      nccl_check(rccl().Send(sbuf_[i].p, sbuf_[i].n, ncclDouble, part.nbrs[i].rank, (ncclComm_t)comm_, s), "ncclSend");
+      nccl_check(rccl().Recv(rbuf_[i].p, rbuf_[i].n, ncclDouble, part.nbrs[i].rank, (ncclComm_t)comm_, s), "ncclRecv");
+   }
+   nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+   for (size_t i = 0; i < nb; i++) vk_unpack_add((int64_t)idx_[i].n, idx_[i].p, rbuf_[i].p, y, s);
+}
+
+// =====================================================================================================================
+// model seam
+// =====================================================================================================================
+static void abi_check(exa_ctx* ctx, int rc, const char* what) { if (rc < 0) throw std::runtime_error(std::string(what) + ": " + exa_last_error(ctx)); }
+
+void ExaCMechModel::ModelSetup(const double* jacobian, const double* vel_evec, hipStream_t s) {
+   abi_check(ctx_, exa_model_setup(ctx_, dt_, jacobian, vel_evec, stress0_->p, matVars0_->p, stress1_->p, matVars1_->p, matGrad_->p, s), "exa_model_setup");
+}
+void ExaCMechModel::calcDpMat(double* dp, hipStream_t s) const { abi_check(ctx_, exa_calc_dp(ctx_, matVars1_->p, dp, s), "exa_calc_dp"); }
+
+// =====================================================================================================================
+// NonlinearMechOperator
+// =====================================================================================================================
+static int model_id(const ExaOptions& o) {
+   const bool bcc = o.xtal == XtalType::BCC;
+   switch (o.slip) {
+      case SlipType::POWERVOCE: return bcc ? EXA_BCC_VOCE : EXA_FCC_VOCE;
+      case SlipType::POWERVOCENL: return bcc ? EXA_BCC_VOCE_NL : EXA_FCC_VOCE_NL;
+      default: return bcc ? EXA_BCC_KMDD : EXA_FCC_KMDD;
+   }
+}
+
+NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partition& part, Comm& comm, const std::vector<double>& props,
+                                             const std::vector<double>& quats_per_elem)
+   : opt_(opt), part_(part), comm_(comm) {
+   EXA_HC(hipStreamCreate(&stream_)); EXA_HC(hipEventCreate(&ev0_)); EXA_HC(hipEventCreate(&ev1_));
+   exa_config cfg; cfg.model = model_id(opt); cfg.nprops = (int)props.size(); cfg.props = props.data(); cfg.temp_k = opt.temp_k; cfg.order = 1;
+   cfg.nelems = part.E; cfg.assembly = opt.assembly == Assembly::PA ? EXA_ASSEMBLY_PA : EXA_ASSEMBLY_EA; cfg.integ = EXA_INTEG_FULL; cfg.device = -1;
+   int err = 0; ctx_ = exa_create(&cfg, &err);
+   if (!ctx_) throw std::runtime_error("exa_create failed (" + std::to_string(err) + ")");
+   nn_ = part.NN; nd_ = 3 * nn_; E_ = part.E;
+   const size_t P = (size_t)E_ * 8;
+   conn.upload(part.conn); abi_check(ctx_, exa_set_connectivity(ctx_, conn.p, nn_), "exa_set_connectivity");
+   x_ref.upload(part.X); x_beg.upload(part.X); x_cur.upload(part.X);
+   weight.upload(part.weight);
+   el_x.alloc(24 * (size_t)E_); el_v.alloc(24 * (size_t)E_); el_y_.alloc(24 * (size_t)E_); el_jac.alloc(9 * P);
+   stress0.alloc(6 * P); stress1.alloc(6 * P); matVars0.alloc(28 * P); matVars1.alloc(28 * P); matGrad.alloc(36 * P);
+   stress0.zero(); stress1.zero(); matVars1.zero(); matGrad.zero();
+   diag.alloc(nd_); dinv.alloc(nd_); tmp_l_.alloc(nd_); ess_mask.alloc(nd_); ess_mask.zero();
+   partial.alloc(DOT_BLOCKS * 4); scal.alloc(16); scal.zero();
+   { DevBuf<double> q; q.upload(quats_per_elem); abi_check(ctx_, exa_init_state(ctx_, matVars0.p, q.p, stream_), "exa_init_state"); EXA_HC(hipStreamSynchronize(stream_)); }
+   model_.reset(new ExaCMechModel(ctx_, &stress0, &stress1, &matGrad, &matVars0, &matVars1));
+   comm_.setup_halo(part);
+}
+
+NonlinearMechOperator::~NonlinearMechOperator() { exa_destroy(ctx_); (void)hipEventDestroy(ev0_); (void)hipEventDestroy(ev1_); (void)hipStreamDestroy(stream_); }
+
+void NonlinearMechOperator::UpdateEssTDofs(const std::vector<uint8_t>& mask) { ess_mask.upload(mask); }
+
+template <bool upd_crds>
+void NonlinearMechOperator::Setup(const double* k) {
+   if (upd_crds) vk_update_coords(nd_, x_beg.p, k, dt_, x_cur.p, stream_);   // ExaModel::UpdateEndCoords (halo copies stay consistent)
+   abi_check(ctx_, exa_restrict(ctx_, x_cur.p, el_x.p, stream_), "exa_restrict");
+   abi_check(ctx_, exa_jacobians(ctx_, el_x.p, el_jac.p, stream_), "exa_jacobians");   // SetupJacobianTerms
+   abi_check(ctx_, exa_restrict(ctx_, k, el_v.p, stream_), "exa_restrict");
+   EXA_HC(hipEventRecord(ev0_, stream_));
+   model_->ModelSetup(el_jac.p, el_v.p, stream_);
+   EXA_HC(hipEventRecord(ev1_, stream_));
+   EXA_HC(hipEventSynchronize(ev1_));
+   float ms = 0; EXA_HC(hipEventElapsedTime(&ms, ev0_, ev1_));
+   timers.t_model_ms += ms; timers.qpt_updates += (int64_t)E_ * 8; model_calls++;
+}
+template void NonlinearMechOperator::Setup<true>(const double*);
+template void NonlinearMechOperator::Setup<false>(const double*);
+
+void NonlinearMechOperator::ResidualAction(double* y) {
+   EXA_HC(hipMemsetAsync(y, 0, sizeof(double) * nd_, stream_));
+   abi_check(ctx_, exa_residual_lvec(ctx_, el_jac.p, stress1.p, y, stream_), "exa_residual_lvec");
+   comm_.halo_sum(part_, y, stream_);
+   vk_mask_zero(nd_, ess_mask.p, y, stream_);
+}
+
+void NonlinearMechOperator::Mult(const double* k, double* y) { Setup<true>(k); ResidualAction(y); }
+
+void NonlinearMechOperator::GetGradient() {
+   abi_check(ctx_, exa_grad_setup(ctx_, dt_, el_jac.p, matGrad.p, stream_), "exa_grad_setup");
+   el_y_.zero(stream_);
+   abi_check(ctx_, exa_grad_diagonal(ctx_, el_y_.p, stream_), "exa_grad_diagonal");
+   diag.zero(stream_);
+   abi_check(ctx_, exa_restrict_transpose_add(ctx_, el_y_.p, diag.p, stream_), "exa_restrict_transpose_add");
+   comm_.halo_sum(part_, diag.p, stream_);
+   vk_mask_one(nd_, ess_mask.p, diag.p, stream_);
+   vk_jacobi_setup(nd_, ess_mask.p, diag.p, precond == Precond::IDENTITY ? 1 : 0, dinv.p, stream_);
+}
+
+void NonlinearMechOperator::GradMult(const double* x, double* y, bool constrained, const double* done_flag) {
+   vk_fill_if(nd_, done_flag, 0.0, y, stream_);
+   abi_check(ctx_, exa_grad_apply_lvec_gated(ctx_, x, y, constrained ? ess_mask.p : nullptr, done_flag, stream_), "exa_grad_apply_lvec");
+   comm_.halo_sum(part_, y, stream_);
+   if (constrained) vk_mask_zero(nd_, ess_mask.p, y, stream_);
+}
+
+void NonlinearMechOperator::GetUpdateBCsAction(const double* k, const double* x, double* y) {
+   Setup<false>(k);
+   GetGradient();                              // Hform->Setup + gradient data
+   GradMult(x, y, false);                      // local action without essential constraints
+   ResidualAction(tmp_l_.p);                   // Hform->Mult(k, resid), essential rows zeroed
+   vk_mask_zero(nd_, ess_mask.p, y, stream_);
+   vk_axpby(nd_, 1.0, tmp_l_.p, 1.0, y, stream_);
+}
+
+double NonlinearMechOperator::dot(const double* a, const double* b) {
+   vk_dot(nd_, nn_, weight.p, a, b, nullptr, partial.p, scal.p + 9, stream_);
+   comm_.allreduce_sum(scal.p + 9, 1, stream_);
+   double h; EXA_HC(hipMemcpyAsync(&h, scal.p + 9, sizeof(double), hipMemcpyDeviceToHost, stream_)); EXA_HC(hipStreamSynchronize(stream_));
+   return h;
+}
+
+void NonlinearMechOperator::UpdateModel() { model_->UpdateModelVars(); model_->UpdateStress(); model_->UpdateStateVars(); }
+void NonlinearMechOperator::SwapCoords() { x_beg.copy_from(x_cur, stream_); }
+
+// =====================================================================================================================
+// SystemDriver
+// =====================================================================================================================
+static void load_case_data(const ExaOptions& opt, const Partition& part, std::vector<double>& props, std::vector<double>& quats_local) {
+   props = ExaOptions::load_numbers(opt.resolve(opt.props_file));
+   if ((int)props.size() != opt.nprops) throw std::runtime_error("Properties file does not hold num_props values");
+   std::vector<double> ori = ExaOptions::load_numbers(opt.resolve(opt.ori_file));
+   std::vector<double> gmap = ExaOptions::load_numbers(opt.resolve(opt.grain_file));
+   const int f = 1 << opt.ref_ser;
+   const int c0 = opt.ncuts[0], c1 = opt.ncuts[1], c2 = opt.ncuts[2];
+   if ((int)gmap.size() < c0 * c1 * c2) throw std::runtime_error("Grain map is smaller than the mesh");
+   quats_local.resize((size_t)4 * part.E);
+   for (int e = 0; e < part.E; e++) {
+      const int64_t g = part.elem_gid[e];
+      const int i = (int)(g % part.N[0]), j = (int)((g / part.N[0]) % part.N[1]), k = (int)(g / ((int64_t)part.N[0] * part.N[1]));
+      // uniform refinement: children inherit the parent's grain id (setElementGrainIDs, src/mechanics_driver.cpp:1257-1270)
+      const int grain = (int)gmap[(i / f) + c0 * ((j / f) + c1 * (k / f))] - 1;
+      if (grain < 0 || 4 * (grain + 1) > (int)ori.size()) throw std::runtime_error("Grain id outside the orientation file");
+      for (int q = 0; q < 4; q++) quats_local[4 * (size_t)e + q] = ori[4 * (size_t)grain + q];
+   }
+}
+
+SystemDriver::SystemDriver(const ExaOptions& opt, int rank, int nranks, const void* uid) : opt_(opt) {
+   comm.init(rank, nranks, uid);
+   const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
+   part.build(N, opt.length, rank, nranks);
+   std::vector<double> props, quats; load_case_data(opt, part, props, quats);
+   init(props, quats);
+}
+
+SystemDriver::SystemDriver(const ExaOptions& opt, const std::vector<double>& props, const std::vector<double>& quats_global, int rank, int nranks, const void* uid) : opt_(opt) {
+   comm.init(rank, nranks, uid);
+   const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
+   part.build(N, opt.length, rank, nranks);
+   std::vector<double> quats((size_t)4 * part.E);
+   for (int e = 0; e < part.E; e++) for (int q = 0; q < 4; q++) quats[4 * (size_t)e + q] = quats_global[4 * (size_t)part.elem_gid[e] + q];
+   init(props, quats);
+}
+
+void SystemDriver::init(const std::vector<double>& props, const std::vector<double>& quats_local) {
+   oper_.reset(new NonlinearMechOperator(opt_, part, comm, props, quats_local));
+   oper_->precond = precond;
+   const int nd = oper_->Height();
+   v_sol.alloc(nd); v_sol.zero(); r_.alloc(nd); c_.alloc(nd); xt_.alloc(nd); cg_r_.alloc(nd); cg_z_.alloc(nd); cg_d_.alloc(nd); ess_val_.alloc(nd);
+   ess_host_.assign(nd, 0); ess_val_host_.assign(nd, 0.0);
+   dt_class = opt_.dt;
+}
+
+// BCManager::updateBCData + UpdateEssTDofs; component codes reference src/BCData.cpp:25-116
+void SystemDriver::UpdateEssBdr(const BCEntry& bc) {
+   const int nn = part.NN;
+   std::fill(ess_host_.begin(), ess_host_.end(), 0); std::fill(ess_val_host_.begin(), ess_val_host_.end(), 0.0);
+   for (size_t b = 0; b < bc.ids.size(); b++) {
+      bool c[3] = { false, false, false };
+      switch (bc.comps[b]) { case 1: c[0] = true; break; case 2: c[1] = true; break; case 3: c[2] = true; break; case 4: c[0] = c[1] = true; break;
+                             case 5: c[1] = c[2] = true; break; case 6: c[0] = c[2] = true; break; case 7: c[0] = c[1] = c[2] = true; break; default: break; }
+      for (int g = 0; g < nn; g++) if (part.on_face(g, bc.ids[b])) for (int k = 0; k < 3; k++) if (c[k]) { ess_host_[g + nn * k] = 1; ess_val_host_[g + nn * k] = bc.vals[3 * b + k]; }
+   }
+   oper_->UpdateEssTDofs(ess_host_);
+   ess_val_.upload(ess_val_host_);
+}
+
+void SystemDriver::UpdateVelocity(double* v) { vk_mask_set(oper_->Height(), oper_->ess_mask.p, ess_val_.p, v, oper_->stream()); }
+
+// device PCG (MFEM CGSolver::Mult with iterative_mode = false); all scalars stay on the device, the host only polls the
+// done-flag every cg_check_every iterations.
+int SystemDriver::CGSolve(const double* b, double* x) {
+   NonlinearMechOperator& op = *oper_;
+   hipStream_t s = op.stream();
+   const int64_t nd = op.Height(), nn = part.NN;
+   double* S = op.scal.p;
+   hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1)); EXA_HC(hipEventRecord(e0, s));
+   EXA_HC(hipMemsetAsync(x, 0, sizeof(double) * nd, s));
+   EXA_HC(hipMemcpyAsync(cg_r_.p, b, sizeof(double) * nd, hipMemcpyDeviceToDevice, s));
+   vk_pointwise(nd, op.dinv.p, cg_r_.p, cg_z_.p, s);
+   EXA_HC(hipMemcpyAsync(cg_d_.p, cg_z_.p, sizeof(double) * nd, hipMemcpyDeviceToDevice, s));
+   EXA_HC(hipMemsetAsync(S, 0, sizeof(double) * 9, s));
+   vk_dot(nd, nn, op.weight.p, cg_d_.p, cg_r_.p, nullptr, op.partial.p, S + 8, s);
+   comm.allreduce_sum(S + 8, 1, s);
+   vk_cg_init(S, opt_.krylov_rel, opt_.krylov_abs, s);
+   op.GradMult(cg_d_.p, cg_z_.p, true, S + 6);
+   vk_dot(nd, nn, op.weight.p, cg_z_.p, cg_d_.p, S + 6, op.partial.p, S + 8, s);
+   comm.allreduce_sum(S + 8, 1, s);
+   vk_cg_den(S, s);
+   double hS[9]; int launched = 0; bool done = false;
+   while (!done) {
+      for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) {
+         vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, s);
+         comm.allreduce_sum(S + 8, 1, s);
+         vk_cg_beta(S, opt_.krylov_iter, s);
+         vk_cg_step2(nd, S, cg_z_.p, cg_d_.p, s);
+         op.GradMult(cg_d_.p, cg_z_.p, true, S + 6);
+         vk_dot(nd, nn, op.weight.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s);
+         comm.allreduce_sum(S + 8, 1, s);
+         vk_cg_den(S, s);
+      }
+      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 9, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+      done = (hS[6] != 0.0) || launched >= opt_.krylov_iter;
+   }
+   EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
+   float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+   const int iters = (hS[6] == 1.0 && hS[7] == 0.0) ? 0 : (int)hS[7];
+   op.timers.t_krylov_ms += ms; op.timers.krylov_iters += iters;
+   return iters;
+}
+
+// ExaNewtonSolver::Mult / ExaNewtonLSSolver::Mult with b = 0 (reference src/mechanics_solver.cpp:39-143,155-281)
+bool SystemDriver::NewtonSolve(double* x, SolverStats& st) {
+   NonlinearMechOperator& op = *oper_;
+   hipStream_t s = op.stream();
+   const int64_t nd = op.Height();
+   const int calls0 = op.model_calls;
+   op.Mult(x, r_.p);
+   double norm = std::sqrt(op.dot(r_.p, r_.p)), norm_prev;
+   const double norm_max = std::max(opt_.newton_rel * norm, opt_.newton_abs);
+   double scale = 1.0; bool converged = false; int it;
+   for (it = 0; true; it++) {
+      if (!std::isfinite(norm)) { converged = false; break; }
+      if (norm <= norm_max) { converged = true; break; }
+      if (it >= opt_.newton_iter) { converged = false; break; }
+      op.GetGradient();
+      st.krylov_iters += CGSolve(r_.p, c_.p);
+      if (opt_.nl_solver == NLSolver::NRLS) {
+         const double q1 = norm;
+         EXA_HC(hipMemcpyAsync(xt_.p, x, sizeof(double) * nd, hipMemcpyDeviceToDevice, s)); vk_axpby(nd, -1.0, c_.p, 1.0, xt_.p, s);
+         op.Mult(xt_.p, r_.p); const double q3 = std::sqrt(op.dot(r_.p, r_.p));
+         EXA_HC(hipMemcpyAsync(xt_.p, x, sizeof(double) * nd, hipMemcpyDeviceToDevice, s)); vk_axpby(nd, -0.5, c_.p, 1.0, xt_.p, s);
+         op.Mult(xt_.p, r_.p); const double q2 = std::sqrt(op.dot(r_.p, r_.p));
+         const double eps = (3.0 * q1 - 4.0 * q2 + q3) / (4.0 * (q1 - 2.0 * q2 + q3));
+         if ((q1 - 2.0 * q2 + q3) > 0 && eps > 0 && eps < 1) scale = eps; else if (q3 < q1) scale = 1.0; else scale = 0.05;
+      }
+      if (scale == 0.0) { converged = false; break; }
+      vk_axpby(nd, -scale, c_.p, 1.0, x, s);
+      op.Mult(x, r_.p);
+      norm_prev = norm; norm = std::sqrt(op.dot(r_.p, r_.p));
+      if (opt_.nl_solver == NLSolver::NR) scale = (norm / norm_prev > 0.5) ? 0.5 : 1.0;
+   }
+   st.newton_iters = it; st.converged = converged; st.model_calls += op.model_calls - calls0;
+   return converged;
+}
+
+// reference src/system_driver.cpp:293-319
+void SystemDriver::SolveInit(const double* xprev, double* x) {
+   NonlinearMechOperator& op = *oper_;
+   hipStream_t s = op.stream(); const int64_t nd = op.Height();
+   DevBuf<double> deltaF(nd), b(nd);
+   deltaF.zero(s);
+   // deltaF[ess] = x[ess] - xprev[ess]
+   EXA_HC(hipMemcpyAsync(xt_.p, x, sizeof(double) * nd, hipMemcpyDeviceToDevice, s)); vk_axpby(nd, -1.0, xprev, 1.0, xt_.p, s);
+   vk_mask_set(nd, op.ess_mask.p, xt_.p, deltaF.p, s);
+   op.GetUpdateBCsAction(xprev, deltaF.p, b.p);
+   SolverStats dummy; (void)dummy;
+   const int it = CGSolve(b.p, x);
+   if (!stats.empty()) stats.back().krylov_iters += it;
+   vk_axpby(nd, 1.0, xprev, -1.0, x, s);   // x = -x + xprev
+}
+
+// reference src/system_driver.cpp:221-288 (auto time stepping included)
+bool SystemDriver::Solve(double* x) {
+   NonlinearMechOperator& op = *oper_;
+   SolverStats& st = stats.back();
+   if (!opt_.dt_auto) return NewtonSolve(x, st);
+   const int64_t nd = op.Height();
+   DevBuf<double> xprev(nd); xprev.copy_from(v_sol, op.stream());
+   const double dt_old = dt_class;
+   bool ok = NewtonSolve(x, st);
+   int iter = 0;
+   while (!ok && iter < 2) {
+      EXA_HC(hipMemcpyAsync(x, xprev.p, sizeof(double) * nd, hipMemcpyDeviceToDevice, op.stream()));
+      dt_class *= opt_.dt_scale; if (dt_class < opt_.dt_min) dt_class = opt_.dt_min;
+      op.SetDt(dt_class);
+      ok = NewtonSolve(x, st); iter++;
+   }
+   if (iter > 0) time = time - dt_old + dt_class;
+   last_dt_ = dt_class;
+   const double niter_scale = (double)opt_.newton_iter * opt_.dt_scale;
+   const double nr_iter = std::max(1, st.newton_iters);
+   dt_class *= niter_scale / nr_iter; if (dt_class < opt_.dt_min) dt_class = opt_.dt_min;
+   return ok;
+}
+
+static void append_row(const std::string& path, const double* v, int n) {
+   std::ofstream f(path, std::ios_base::app);
+   for (int i = 0; i < n; i++) { f << v[i]; f << (i + 1 == n ? '\n' : ' '); }   // mfem::Vector::Print(out, width = n)
+}
+
+// reference src/system_driver.cpp:429-558
+void SystemDriver::UpdateModel() {
+   NonlinearMechOperator& op = *oper_;
+   hipStream_t s = op.stream();
+   exa_ctx* ctx = op.GetModel()->ctx();
+   op.UpdateModel();
+   auto vol_avg = [&](const double* qf, int vdim, bool normalise, double* out) {
+      std::vector<double> h(vdim + 1);
+      abi_check(ctx, exa_vol_avg(ctx, op.el_jac.p, qf, vdim, 0, h.data(), s), "exa_vol_avg");
+      if (comm.nranks > 1) { DevBuf<double> t(vdim + 1); t.upload(h.data(), vdim + 1, s); comm.allreduce_sum(t.p, vdim + 1, s); t.download(h.data(), vdim + 1, s); }
+      for (int i = 0; i < vdim; i++) out[i] = normalise ? h[i] / h[vdim] : h[i];
+   };
+   double a[28];
+   vol_avg(op.stress0.p, 6, true, a);
+   avg_stress.insert(avg_stress.end(), a, a + 6);
+   const bool root = comm.rank == 0 && write_files;
+   if (root) append_row(out_dir + "/" + opt_.avg_stress_fname, a, 6);
+   if (opt_.additional_avgs) {
+      vol_avg(op.matVars0.p, 28, false, a);
+      avg_pl_work.push_back(a[2]);
+      if (root) append_row(out_dir + "/" + opt_.avg_pl_work_fname, a + 2, 1);
+      // CalculateDeformationGradient: gradient of the current coordinates on the reference configuration
+      const size_t P = (size_t)part.E * 8;
+      DevBuf<double> jref(9 * P), F(9 * P), xe(24 * (size_t)part.E);
+      abi_check(ctx, exa_restrict(ctx, op.x_ref.p, xe.p, s), "exa_restrict");
+      abi_check(ctx, exa_jacobians(ctx, xe.p, jref.p, s), "exa_jacobians");
+      abi_check(ctx, exa_grad_calc(ctx, jref.p, op.el_x.p, F.p, s), "exa_grad_calc");
+      vol_avg(F.p, 9, true, a);
+      avg_def_grad.insert(avg_def_grad.end(), a, a + 9);
+      if (root) append_row(out_dir + "/" + opt_.avg_def_grad_fname, a, 9);
+      op.GetModel()->calcDpMat(F.p, s);
+      vol_avg(F.p, 9, true, a);
+      const double dpv[6] = { a[0], a[4], a[8], a[5], a[2], a[1] };
+      avg_dp_tensor.insert(avg_dp_tensor.end(), dpv, dpv + 6);
+      if (root) append_row(out_dir + "/" + opt_.avg_dp_tensor_fname, dpv, 6);
+   }
+}
+
+// one pass of the reference's time-step loop body (src/mechanics_driver.cpp:837-907)
+bool SystemDriver::Step(int ti) {
+   NonlinearMechOperator& op = *oper_;
+   hipStream_t s = op.stream(); const int64_t nd = op.Height();
+   double dt_real;
+   if (opt_.dt_cust) dt_real = opt_.cust_dt[ti - 1];
+   else if (opt_.dt_auto) dt_real = std::min(dt_class, opt_.t_final - time);
+   else dt_real = std::min(opt_.dt, opt_.t_final - time);
+   time += dt_real; dt_class = dt_real;
+   op.SetDt(dt_real);
+   stats.emplace_back();
+   hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1)); EXA_HC(hipEventRecord(e0, s));
+   for (const BCEntry& bc : opt_.bcs) if (bc.step == ti) {
+      DevBuf<double> v_prev(nd); v_prev.copy_from(v_sol, s);
+      UpdateEssBdr(bc);
+      UpdateVelocity(v_sol.p);
+      SolveInit(v_prev.p, v_sol.p);
+   }
+   UpdateVelocity(v_sol.p);
+   const bool ok = Solve(v_sol.p);
+   EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
+   float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+   op.timers.t_solve_ms += ms;
+   if (!ok) return false;
+   UpdateModel();
+   op.SwapCoords();
+   steps_done++;
+   return true;
+}
+
+int SystemDriver::RunAll() {
+   for (int ti = 1; ti <= opt_.nsteps; ti++) {
+      if (!Step(ti)) { if (comm.rank == 0) std::cerr << "Newton Solver did not converge.\n"; return -ti; }
+      if (!opt_.dt_cust) { const double dtl = opt_.dt_auto ? last_dt_ : opt_.dt; if (std::fabs(time - opt_.t_final) <= std::fabs(1e-3 * dtl)) break; }
+   }
+   return steps_done;
+}
+
+}  // namespace exa_host

@@ -1,0 +1,146 @@
+// Stand-alone host driver above the C ABI: the reference's operator / solver / system-driver classes re-expressed for
+// device-resident data (MFEM is not available in this image, so the data containers are plain device buffers; the class
+// and method names, argument meaning and control flow follow the reference so that its regression cases run unchanged).
+//   ExaModel / ExaCMechModel            reference src/mechanics_model.hpp:17-241, src/mechanics_ecmech.hpp:12-109
+//   ExaNLFIntegrator                     reference src/mechanics_integrators.hpp:14-76
+//   NonlinearMechOperator                reference src/mechanics_operator.hpp:18-100, src/mechanics_operator.cpp:288-483
+//   MechOperatorJacobiSmoother           reference src/mechanics_operator_ext.cpp:11-55
+//   ExaNewtonSolver / ExaNewtonLSSolver  reference src/mechanics_solver.cpp:39-281
+//   SystemDriver                         reference src/system_driver.cpp:221-558
+//   time-step loop                       reference src/mechanics_driver.cpp:837-907
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../../include/exaconstit_hip.h"
+#include "device_utils.hpp"
+#include "mesh.hpp"
+#include "options.hpp"
+
+namespace exa_host {
+
+// ---- communication: RCCL over xGMI when nranks > 1 (loaded at run time), no-ops on one rank -----------------------
+class Comm {
+ public:
+   int rank = 0, nranks = 1;
+   ~Comm();
+   void init(int rank_, int nranks_, const void* nccl_unique_id /*128 bytes, identical on all ranks*/);
+   static void get_unique_id(void* out128);
+   void allreduce_sum(double* dev, int n, hipStream_t s);
+   void allreduce_min(double* dev, int n, hipStream_t s);
+   // y(shared dofs) <- sum over all ranks holding them
+   void halo_sum(const Partition& part, double* y, hipStream_t s);
+   void setup_halo(const Partition& part);
+   double max_over_ranks(double v);
+ private:
+   void* comm_ = nullptr;
+   std::vector<DevBuf<int32_t>> idx_; std::vector<DevBuf<double>> sbuf_, rbuf_;
+   DevBuf<double> tmp_;
+};
+
+enum class Precond { IDENTITY, JACOBI };
+
+struct SolverStats { int newton_iters = 0; int krylov_iters = 0; int model_calls = 0; bool converged = false; };
+
+struct Timers {
+   double t_model_ms = 0, t_krylov_ms = 0, t_solve_ms = 0; int64_t qpt_updates = 0; int64_t krylov_iters = 0;
+};
+
+// Per-quadrature-point model seam (ExaModel): owns nothing but scratch; the driver owns the quadrature functions.
+class ExaCMechModel {
+ public:
+   ExaCMechModel(exa_ctx* ctx, DevBuf<double>* stress0, DevBuf<double>* stress1, DevBuf<double>* matGrad, DevBuf<double>* matVars0, DevBuf<double>* matVars1)
+      : ctx_(ctx), stress0_(stress0), stress1_(stress1), matGrad_(matGrad), matVars0_(matVars0), matVars1_(matVars1) {}
+   void SetModelDt(double dt) { dt_ = dt; }
+   double GetModelDt() const { return dt_; }
+   // ExaCMechModel::ModelSetup (reference src/mechanics_ecmech.cpp:192-258)
+   void ModelSetup(const double* jacobian, const double* vel_evec, hipStream_t s);
+   void UpdateModelVars() {}
+   void UpdateStress() { stress0_->swap(*stress1_); }        // reference src/mechanics_model.cpp:435-438
+   void UpdateStateVars() { matVars0_->swap(*matVars1_); }   // reference src/mechanics_model.cpp:440-443
+   void calcDpMat(double* dp, hipStream_t s) const;          // reads matVars1 (reference src/mechanics_ecmech.hpp:309)
+   DevBuf<double>* GetStress0() { return stress0_; } DevBuf<double>* GetStress1() { return stress1_; }
+   DevBuf<double>* GetMatVars0() { return matVars0_; } DevBuf<double>* GetMatVars1() { return matVars1_; } DevBuf<double>* GetMatGrad() { return matGrad_; }
+   exa_ctx* ctx() const { return ctx_; }
+ private:
+   exa_ctx* ctx_; double dt_ = 1.0;
+   DevBuf<double>*stress0_, *stress1_, *matGrad_, *matVars0_, *matVars1_;
+};
+
+class NonlinearMechOperator {
+ public:
+   NonlinearMechOperator(const ExaOptions& opt, const Partition& part, Comm& comm, const std::vector<double>& props, const std::vector<double>& quats_per_elem);
+   ~NonlinearMechOperator();
+   int Height() const { return nd_; }
+   void SetDt(double dt) { dt_ = dt; model_->SetModelDt(dt); }
+   void UpdateEssTDofs(const std::vector<uint8_t>& mask);
+   // y = F(k): residual with essential rows zeroed (reference src/mechanics_operator.cpp:288-308)
+   void Mult(const double* k, double* y);
+   template <bool upd_crds> void Setup(const double* k);
+   // Jacobian set-up + Jacobi diagonal (reference src/mechanics_operator.cpp:436-443)
+   void GetGradient();
+   // y = K x with essential columns/rows masked (constrained) or the plain local action
+   void GradMult(const double* x, double* y, bool constrained, const double* done_flag = nullptr);
+   // reference src/mechanics_operator.cpp:446-483
+   void GetUpdateBCsAction(const double* k, const double* x, double* y);
+   void ResidualAction(double* y);
+   void UpdateModel();                     // swap begin/end state, x_beg <- x_cur
+   void SwapCoords();
+   ExaCMechModel* GetModel() { return model_.get(); }
+   hipStream_t stream() const { return stream_; }
+   const Partition& part() const { return part_; }
+   Comm& comm() { return comm_; }
+   // data (device)
+   DevBuf<double> x_ref, x_beg, x_cur, el_x, el_v, el_jac, diag, dinv, weight;
+   DevBuf<double> stress0, stress1, matVars0, matVars1, matGrad;
+   DevBuf<uint8_t> ess_mask;
+   DevBuf<int32_t> conn;
+   Precond precond = Precond::IDENTITY;
+   Timers timers;
+   int model_calls = 0;
+   double dot(const double* a, const double* b);   // weighted, all-reduced, synchronising
+   DevBuf<double> partial, scal;
+ private:
+   ExaOptions opt_; const Partition& part_; Comm& comm_;
+   exa_ctx* ctx_ = nullptr; std::unique_ptr<ExaCMechModel> model_;
+   hipStream_t stream_ = nullptr; hipEvent_t ev0_, ev1_;
+   int nn_, nd_, E_; double dt_ = 1.0;
+   DevBuf<double> tmp_l_, el_y_;
+};
+
+class SystemDriver {
+ public:
+   SystemDriver(const ExaOptions& opt, int rank, int nranks, const void* nccl_uid);
+   // synthetic RVE without files (bench): N^3 elements, one grain per element, seeded orientations
+   SystemDriver(const ExaOptions& opt, const std::vector<double>& props, const std::vector<double>& quats_per_global_elem, int rank, int nranks, const void* nccl_uid);
+   void UpdateEssBdr(const BCEntry& bc);
+   void UpdateVelocity(double* v);
+   void SolveInit(const double* xprev, double* x);
+   bool Solve(double* x);
+   void UpdateModel();
+   // one time step of the reference's loop (src/mechanics_driver.cpp:837-907); returns false if Newton failed
+   bool Step(int ti);
+   int RunAll();
+   bool NewtonSolve(double* x, SolverStats& st);
+   int CGSolve(const double* b, double* x);   // device PCG, returns iterations
+   NonlinearMechOperator& oper() { return *oper_; }
+   const ExaOptions& options() const { return opt_; }
+   std::vector<double> avg_stress, avg_def_grad, avg_pl_work, avg_dp_tensor;   // one row per completed step (rank 0 view, all ranks identical)
+   std::vector<SolverStats> stats;
+   DevBuf<double> v_sol;
+   double time = 0.0, dt_class = 0.0; int steps_done = 0;
+   bool write_files = true; std::string out_dir = ".";
+   Precond precond = Precond::IDENTITY;
+   int cg_check_every = 16;
+   Partition part;
+   Comm comm;
+ private:
+   void init(const std::vector<double>& props, const std::vector<double>& quats_local);
+   ExaOptions opt_;
+   std::unique_ptr<NonlinearMechOperator> oper_;
+   DevBuf<double> r_, c_, xt_, cg_r_, cg_z_, cg_d_, ess_val_;
+   std::vector<uint8_t> ess_host_; std::vector<double> ess_val_host_;
+   double last_dt_ = 0.0;
+};
+
+}  // namespace exa_host

@@ -1,0 +1,174 @@
+// C entry points of the stand-alone driver (used by the `mechanics` executable, the tests and bench.py through ctypes).
+// They expose the reference's run-time surface: `mechanics -opt options.toml` (reference src/mechanics_driver.cpp:139-144),
+// the per-step loop, the avg_* outputs (reference src/system_driver.cpp:444-553) and the timing regions the reference marks
+// with Caliper (ecmech_kernel, krylov_solver: src/mechanics_ecmech.cpp:237-257, src/mechanics_solver.cpp:99-103).
+#include "driver.hpp"
+#include "driver_capi.h"
+#include <cmath>
+#include <cstring>
+
+using namespace exa_host;
+
+struct exa_driver {
+   std::unique_ptr<SystemDriver> sd;
+   std::vector<double> v_kin;   // kinematic velocity field of the bench (host copy)
+};
+
+namespace {
+void set_err(char* err, int n, const std::string& m) { if (err && n > 0) { std::strncpy(err, m.c_str(), n - 1); err[n - 1] = 0; } }
+}
+
+extern "C" {
+
+int exa_rccl_unique_id(void* out128) {
+   try { Comm::get_unique_id(out128); return 0; } catch (const std::exception& e) { std::fprintf(stderr, "exa_rccl_unique_id: %s\n", e.what()); return -1; }
+}
+
+exa_driver* exa_driver_create(const char* toml_path, const char* out_dir, int rank, int nranks, const void* uid, int jacobi, int write_files, char* err, int errlen) {
+   try {
+      ExaOptions opt; opt.parse_options(toml_path);
+      auto d = new exa_driver();
+      d->sd.reset(new SystemDriver(opt, rank, nranks, uid));
+      d->sd->out_dir = out_dir ? out_dir : "."; d->sd->write_files = write_files != 0;
+      d->sd->precond = jacobi ? Precond::JACOBI : Precond::IDENTITY; d->sd->oper().precond = d->sd->precond;
+      return d;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return nullptr; }
+}
+
+exa_driver* exa_driver_create_synthetic(const exa_synth_config* c, int rank, int nranks, const void* uid, char* err, int errlen) {
+   try {
+      ExaOptions opt;
+      opt.temp_k = c->temp_k;
+      opt.xtal = c->bcc ? XtalType::BCC : XtalType::FCC;
+      opt.slip = c->slip == 0 ? SlipType::POWERVOCE : (c->slip == 1 ? SlipType::POWERVOCENL : SlipType::MTSDD);
+      for (int i = 0; i < 3; i++) { opt.ncuts[i] = c->N; opt.length[i] = 1.0; }
+      opt.assembly = c->assembly == 0 ? Assembly::PA : Assembly::EA;
+      opt.nl_solver = c->nrls ? NLSolver::NRLS : NLSolver::NR;
+      opt.newton_iter = c->newton_iter; opt.newton_rel = c->newton_rel; opt.newton_abs = c->newton_abs;
+      opt.krylov_iter = c->krylov_iter; opt.krylov_rel = c->krylov_rel; opt.krylov_abs = c->krylov_abs;
+      opt.dt_cust = true; opt.nsteps = c->nsteps; opt.cust_dt.assign(c->dts, c->dts + c->nsteps);
+      // uniaxial z-tension with three symmetry planes (reference test/data/voce_pa.toml [BCs])
+      BCEntry bc; bc.step = 1; bc.ids = { 1, 2, 3, 4 }; bc.comps = { 3, 1, 2, 3 }; bc.vals = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, c->vz };
+      opt.bcs.push_back(bc);
+      std::vector<double> props(c->props, c->props + c->nprops);
+      const size_t Eg = (size_t)c->N * c->N * c->N;
+      std::vector<double> quats(c->quats, c->quats + 4 * Eg);
+      auto d = new exa_driver();
+      d->sd.reset(new SystemDriver(opt, props, quats, rank, nranks, uid));
+      d->sd->write_files = false;
+      d->sd->precond = c->jacobi ? Precond::JACOBI : Precond::IDENTITY; d->sd->oper().precond = d->sd->precond;
+      return d;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return nullptr; }
+}
+
+void exa_driver_destroy(exa_driver* d) { delete d; }
+
+int exa_driver_num_steps(exa_driver* d) { return d->sd->options().nsteps; }
+int64_t exa_driver_local_qpts(exa_driver* d) { return (int64_t)d->sd->part.E * 8; }
+int64_t exa_driver_local_dofs(exa_driver* d) { return (int64_t)d->sd->part.NN * 3; }
+
+int exa_driver_step(exa_driver* d, int ti, char* err, int errlen) {
+   try { return d->sd->Step(ti) ? 1 : 0; } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
+int exa_driver_run(exa_driver* d, char* err, int errlen) {
+   try { return d->sd->RunAll(); } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1000000; }
+}
+
+// which: 0 stress (6), 1 def_grad (9), 2 pl_work (1), 3 dp_tensor (6); returns rows copied
+int exa_driver_get_avgs(exa_driver* d, int which, double* out, int maxrows) {
+   const std::vector<double>* v = which == 0 ? &d->sd->avg_stress : (which == 1 ? &d->sd->avg_def_grad : (which == 2 ? &d->sd->avg_pl_work : &d->sd->avg_dp_tensor));
+   const int w = which == 0 ? 6 : (which == 1 ? 9 : (which == 2 ? 1 : 6));
+   int rows = (int)(v->size() / w); if (rows > maxrows) rows = maxrows;
+   std::memcpy(out, v->data(), sizeof(double) * rows * w);
+   return rows;
+}
+
+int exa_driver_get_stats(exa_driver* d, int* newton, int* krylov, int* model_calls, int maxrows) {
+   int rows = (int)d->sd->stats.size(); if (rows > maxrows) rows = maxrows;
+   for (int i = 0; i < rows; i++) { newton[i] = d->sd->stats[i].newton_iters; krylov[i] = d->sd->stats[i].krylov_iters; model_calls[i] = d->sd->stats[i].model_calls; }
+   return rows;
+}
+
+// out[0] ms in the fused constitutive kernel, out[1] ms in PCG, out[2] ms in Solve (+SolveInit), out[3] qpt updates, out[4] PCG iterations
+void exa_driver_get_timers(exa_driver* d, double* out) {
+   const Timers& t = d->sd->oper().timers;
+   out[0] = t.t_model_ms; out[1] = t.t_krylov_ms; out[2] = t.t_solve_ms; out[3] = (double)t.qpt_updates; out[4] = (double)t.krylov_iters;
+}
+void exa_driver_reset_timers(exa_driver* d) { d->sd->oper().timers = Timers(); }
+
+// ---- benchmark hooks --------------------------------------------------------------------------------------------------
+// Kinematically drive the RVE into the plastic regime: nodal velocity v = L0 x (+ seeded perturbation), `nsteps` constitutive
+// passes with state/coordinate updates and no equilibrium solve (SURVEY 8(d) kernel micro-benchmark).
+int exa_driver_bench_prepare(exa_driver* d, int nsteps, const double* dts, double perturb, char* err, int errlen) {
+   try {
+      SystemDriver& sd = *d->sd; NonlinearMechOperator& op = sd.oper();
+      const Partition& part = sd.part; const int nn = part.NN;
+      d->v_kin.assign((size_t)3 * nn, 0.0);
+      const double L0[3][3] = { { -0.45e-3, 0.3e-4, -0.2e-4 }, { -0.3e-4, -0.45e-3, 0.1e-4 }, { 0.2e-4, -0.1e-4, 1.0e-3 } };
+      for (int g = 0; g < nn; g++) {
+         const double x[3] = { part.X[g], part.X[g + nn], part.X[g + 2 * (size_t)nn] };
+         // deterministic perturbation from the GLOBAL node coordinates so that duplicated interface nodes agree across ranks
+         for (int c = 0; c < 3; c++) {
+            const double ph = std::sin(12.9898 * x[0] * part.N[0] + 78.233 * x[1] * part.N[1] + 37.719 * x[2] * part.N[2] + 4.0 * c) * 43758.5453;
+            const double u = 2.0 * (ph - std::floor(ph)) - 1.0;
+            d->v_kin[g + (size_t)nn * c] = L0[c][0] * x[0] + L0[c][1] * x[1] + L0[c][2] * x[2] + perturb * 1.0e-4 / part.N[0] * u;
+         }
+      }
+      sd.v_sol.upload(d->v_kin);
+      for (int i = 0; i < nsteps; i++) {
+         op.SetDt(dts[i]);
+         op.Setup<true>(sd.v_sol.p);
+         op.UpdateModel(); op.SwapCoords();
+      }
+      op.SetDt(dts[nsteps - 1]);
+      EXA_HC(hipStreamSynchronize(op.stream()));
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
+// `steps` constitutive passes (restriction + geometric factors + fused model kernel) from the fixed begin-of-step state, as the
+// residual evaluations of one Newton solve do.  out[0] = wall ms of the whole loop (HIP events), out[1] = ms inside the fused
+// constitutive kernel only, out[2] = non-converged points of the last pass.
+int exa_driver_bench_model(exa_driver* d, int steps, double* out, char* err, int errlen) {
+   try {
+      SystemDriver& sd = *d->sd; NonlinearMechOperator& op = sd.oper();
+      hipStream_t s = op.stream();
+      hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1));
+      const double t0 = op.timers.t_model_ms;
+      EXA_HC(hipEventRecord(e0, s));
+      for (int i = 0; i < steps; i++) op.Setup<true>(sd.v_sol.p);
+      EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
+      float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      out[0] = ms; out[1] = op.timers.t_model_ms - t0; out[2] = (double)exa_model_status(op.GetModel()->ctx(), s);
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
+// Fixed-length PCG: residual + Jacobian set-up at the prepared state, then exactly `iters` PCG iterations (tolerances disabled).
+// out[0] = ms of the PCG loop, out[1] = iterations executed, out[2] = ms of `iters` back-to-back gradient-action launches alone.
+int exa_driver_bench_pcg(exa_driver* d, int iters, double* out, char* err, int errlen) {
+   try {
+      SystemDriver& sd = *d->sd; NonlinearMechOperator& op = sd.oper();
+      hipStream_t s = op.stream(); const int nd = op.Height();
+      DevBuf<double> r(nd), c(nd);
+      op.Mult(sd.v_sol.p, r.p);
+      op.GetGradient();
+      ExaOptions& o = const_cast<ExaOptions&>(sd.options());
+      const double rel = o.krylov_rel, ab = o.krylov_abs; const int mi = o.krylov_iter;
+      o.krylov_rel = 0.0; o.krylov_abs = 0.0; o.krylov_iter = iters;
+      const double t0 = op.timers.t_krylov_ms;
+      const int it = sd.CGSolve(r.p, c.p);
+      out[0] = op.timers.t_krylov_ms - t0; out[1] = it;
+      o.krylov_rel = rel; o.krylov_abs = ab; o.krylov_iter = mi;
+      hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1));
+      EXA_HC(hipEventRecord(e0, s));
+      for (int i = 0; i < iters; i++) exa_grad_apply_lvec(op.GetModel()->ctx(), r.p, c.p, op.ess_mask.p, s);
+      EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
+      float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      out[2] = ms;
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
+}  // extern "C"

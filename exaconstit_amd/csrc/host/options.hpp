@@ -1,0 +1,177 @@
+// options.toml reader for the stand-alone driver: the reference's option SCHEMA (reference src/options.toml,
+// src/option_parser.cpp:26-932, src/option_types.hpp) for the subset of its hot path — auto-generated hex mesh,
+// ExaCMech models, PA/EA assembly, NR/NRLS + PCG — parsed with a small TOML-subset reader (the reference vendors toml11;
+// out of scope here).  Unknown keys are ignored like the reference's `toml::find_or` defaults; unsupported values abort
+// with the reference's wording where one exists.
+#pragma once
+#include <cctype>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace exa_host {
+
+struct TomlValue {
+   enum Kind { NONE, NUM, STR, BOOL, ARR } kind = NONE;
+   double num = 0; std::string str; bool b = false; std::vector<TomlValue> arr;
+};
+
+class TomlDoc {
+ public:
+   std::map<std::string, TomlValue> kv;   // "Table.Sub.key" -> value
+   static TomlDoc parse_file(const std::string& path) {
+      std::ifstream f(path);
+      if (!f) throw std::runtime_error("Cannot open options file: " + path);
+      std::stringstream ss; ss << f.rdbuf();
+      return parse(ss.str());
+   }
+   static TomlDoc parse(const std::string& text) {
+      TomlDoc d; size_t pos = 0; std::string table;
+      const size_t n = text.size();
+      auto skip_ws = [&](bool newlines) { while (pos < n) { char c = text[pos]; if (c == '#') { while (pos < n && text[pos] != '\n') pos++; } else if (c == ' ' || c == '\t' || c == '\r' || (newlines && c == '\n')) pos++; else break; } };
+      while (true) {
+         skip_ws(true);
+         if (pos >= n) break;
+         if (text[pos] == '[') {
+            size_t e = text.find(']', pos); if (e == std::string::npos) throw std::runtime_error("toml: unterminated table header");
+            table = trim(text.substr(pos + 1, e - pos - 1)); pos = e + 1; continue;
+         }
+         size_t eq = text.find('=', pos); if (eq == std::string::npos) throw std::runtime_error("toml: expected key = value");
+         std::string key = trim(text.substr(pos, eq - pos)); pos = eq + 1;
+         skip_ws(false);
+         TomlValue v = parse_value(text, pos);
+         d.kv[table.empty() ? key : table + "." + key] = v;
+      }
+      return d;
+   }
+   bool has(const std::string& k) const { return kv.count(k) > 0; }
+   bool has_table(const std::string& t) const { for (auto& p : kv) if (p.first.compare(0, t.size() + 1, t + ".") == 0) return true; return false; }
+   double num(const std::string& k, double def) const { auto it = kv.find(k); return (it != kv.end() && it->second.kind == TomlValue::NUM) ? it->second.num : def; }
+   std::string str(const std::string& k, const std::string& def) const { auto it = kv.find(k); return (it != kv.end() && it->second.kind == TomlValue::STR) ? it->second.str : def; }
+   bool boolean(const std::string& k, bool def) const { auto it = kv.find(k); return (it != kv.end() && it->second.kind == TomlValue::BOOL) ? it->second.b : def; }
+   const TomlValue* get(const std::string& k) const { auto it = kv.find(k); return it == kv.end() ? nullptr : &it->second; }
+
+ private:
+   static std::string trim(const std::string& s) { size_t a = 0, b = s.size(); while (a < b && std::isspace((unsigned char)s[a])) a++; while (b > a && std::isspace((unsigned char)s[b - 1])) b--; return s.substr(a, b - a); }
+   static TomlValue parse_value(const std::string& t, size_t& pos) {
+      TomlValue v; const size_t n = t.size();
+      auto skip = [&]() { while (pos < n) { char c = t[pos]; if (c == '#') { while (pos < n && t[pos] != '\n') pos++; } else if (std::isspace((unsigned char)c)) pos++; else break; } };
+      if (t[pos] == '"' || t[pos] == '\'') {
+         const char q = t[pos]; size_t e = t.find(q, pos + 1); if (e == std::string::npos) throw std::runtime_error("toml: unterminated string");
+         v.kind = TomlValue::STR; v.str = t.substr(pos + 1, e - pos - 1); pos = e + 1;
+      } else if (t[pos] == '[') {
+         v.kind = TomlValue::ARR; pos++;
+         while (true) { skip(); if (pos >= n) throw std::runtime_error("toml: unterminated array"); if (t[pos] == ']') { pos++; break; } if (t[pos] == ',') { pos++; continue; } v.arr.push_back(parse_value(t, pos)); }
+      } else if (t.compare(pos, 4, "true") == 0) { v.kind = TomlValue::BOOL; v.b = true; pos += 4; }
+      else if (t.compare(pos, 5, "false") == 0) { v.kind = TomlValue::BOOL; v.b = false; pos += 5; }
+      else {
+         size_t e = pos; while (e < n && (std::isalnum((unsigned char)t[e]) || t[e] == '+' || t[e] == '-' || t[e] == '.' || t[e] == '_')) e++;
+         std::string tok = t.substr(pos, e - pos); std::string clean; for (char c : tok) if (c != '_') clean += c;
+         char* endp = nullptr; v.num = std::strtod(clean.c_str(), &endp);
+         if (endp == clean.c_str()) throw std::runtime_error("toml: cannot parse value near '" + tok + "'");
+         v.kind = TomlValue::NUM; pos = e;
+      }
+      return v;
+   }
+};
+
+enum class Assembly { PA, EA };            // reference src/option_types.hpp (FULL is mapped to EA: same operator, no sparse matrix/AMG)
+enum class NLSolver { NR, NRLS };
+enum class XtalType { FCC, BCC };
+enum class SlipType { POWERVOCE, POWERVOCENL, MTSDD };
+
+struct BCEntry { int step; std::vector<int> ids, comps; std::vector<double> vals; };
+
+struct ExaOptions {
+   std::string basedir;
+   double temp_k = 298.0;
+   std::string props_file; int nprops = 0;
+   std::string ori_file, grain_file; int num_grains = 0; std::string ori_type = "quat";
+   std::vector<BCEntry> bcs;
+   XtalType xtal = XtalType::FCC; SlipType slip = SlipType::POWERVOCE;
+   bool dt_cust = false, dt_auto = false; std::vector<double> cust_dt; double dt = 1.0, t_final = 1.0;
+   double dt_min = 1.0, dt_scale = 0.25; int nsteps = 1;
+   std::string avg_stress_fname = "avg_stress.txt", avg_def_grad_fname = "avg_def_grad.txt", avg_pl_work_fname = "avg_pl_work.txt", avg_dp_tensor_fname = "avg_dp_tensor.txt";
+   bool additional_avgs = false;
+   Assembly assembly = Assembly::EA; NLSolver nl_solver = NLSolver::NR; std::string integ_model = "FULL";
+   int newton_iter = 25; double newton_rel = 1e-5, newton_abs = 1e-10;
+   int krylov_iter = 200; double krylov_rel = 1e-10, krylov_abs = 1e-30; std::string krylov_solver = "PCG";
+   int ref_ser = 0, order = 1; int ncuts[3] = { 1, 1, 1 }; double length[3] = { 1, 1, 1 }; std::string mesh_type = "auto";
+
+   static std::vector<double> load_numbers(const std::string& path) {
+      std::ifstream f(path); if (!f) throw std::runtime_error("Cannot open data file: " + path);
+      std::vector<double> v; double x; while (f >> x) v.push_back(x); return v;
+   }
+   std::string resolve(const std::string& f) const { return (f.empty() || f[0] == '/') ? f : basedir + "/" + f; }
+
+   static std::string lower(std::string s) { for (auto& c : s) c = (char)std::tolower((unsigned char)c); return s; }
+
+   void parse_options(const std::string& path) {
+      const size_t sl = path.find_last_of('/'); basedir = sl == std::string::npos ? "." : path.substr(0, sl);
+      TomlDoc d = TomlDoc::parse_file(path);
+      temp_k = d.num("Properties.temperature", 298.0);
+      props_file = d.str("Properties.Matl_Props.floc", "props.txt"); nprops = (int)d.num("Properties.Matl_Props.num_props", 1);
+      ori_file = d.str("Properties.Grain.ori_floc", "ori.txt"); grain_file = d.str("Properties.Grain.grain_floc", "grain_map.txt");
+      num_grains = (int)d.num("Properties.Grain.num_grains", 0); ori_type = lower(d.str("Properties.Grain.ori_type", "euler"));
+      if (ori_type != "quat" && ori_type != "quaternion") throw std::runtime_error("Only quaternion orientations (ori_type = \"quat\") are supported by this driver");
+      // BCs (reference src/option_parser.cpp get_bcs): either flat arrays or arrays-of-arrays keyed by update_steps
+      const bool changing = d.boolean("BCs.changing_ess_bcs", false);
+      const TomlValue* ids = d.get("BCs.essential_ids"); const TomlValue* comps = d.get("BCs.essential_comps"); const TomlValue* vals = d.get("BCs.essential_vals");
+      if (!ids || !comps || !vals) throw std::runtime_error("BCs.essential_ids / essential_comps / essential_vals are required");
+      auto flat = [](const TomlValue& a) { std::vector<double> o; for (auto& e : a.arr) o.push_back(e.num); return o; };
+      if (changing) {
+         const TomlValue* us = d.get("BCs.update_steps"); if (!us) throw std::runtime_error("BCs.update_steps is required with changing_ess_bcs");
+         for (size_t b = 0; b < us->arr.size(); b++) {
+            BCEntry e; e.step = (int)us->arr[b].num;
+            for (double v : flat(ids->arr[b])) e.ids.push_back((int)v);
+            for (double v : flat(comps->arr[b])) e.comps.push_back((int)v);
+            e.vals = flat(vals->arr[b]); bcs.push_back(e);
+         }
+      } else {
+         BCEntry e; e.step = 1;
+         for (double v : flat(*ids)) e.ids.push_back((int)v);
+         for (double v : flat(*comps)) e.comps.push_back((int)v);
+         e.vals = flat(*vals); bcs.push_back(e);
+      }
+      for (auto& e : bcs) { if (e.vals.size() != 3 * e.ids.size() || e.comps.size() != e.ids.size()) throw std::runtime_error("BCs: essential_vals must hold 3 values per essential id"); for (int c : e.comps) if (c < 0) throw std::runtime_error("Velocity-gradient BCs (negative essential_comps) are not built yet"); }
+      if (lower(d.str("Model.mech_type", "")) != "exacmech") throw std::runtime_error("Only mech_type = \"exacmech\" is supported (UMAT is CPU-only in the reference)");
+      const std::string xt = lower(d.str("Model.ExaCMech.xtal_type", "")), st = lower(d.str("Model.ExaCMech.slip_type", ""));
+      if (xt == "fcc") xtal = XtalType::FCC; else if (xt == "bcc") xtal = XtalType::BCC; else throw std::runtime_error("Unknown xtal_type: " + xt);
+      if (st == "powervoce") slip = SlipType::POWERVOCE; else if (st == "powervocenl") slip = SlipType::POWERVOCENL; else if (st == "mtsdd") slip = SlipType::MTSDD; else throw std::runtime_error("Unknown slip_type: " + st);
+      // time: Custom > Auto > Fixed (reference src/mechanics_driver.cpp:842-851)
+      if (d.has_table("Time.Custom")) {
+         dt_cust = true; nsteps = (int)d.num("Time.Custom.nsteps", 1);
+         cust_dt = load_numbers(resolve(d.str("Time.Custom.floc", "custom_dt.txt")));
+         if ((int)cust_dt.size() < nsteps) throw std::runtime_error("Custom dt file has fewer entries than nsteps");
+      } else if (d.has_table("Time.Auto")) {
+         dt_auto = true; dt = d.num("Time.Auto.dt_start", 1.0); dt_min = d.num("Time.Auto.dt_min", 1.0); dt_scale = d.num("Time.Auto.dt_scale", 0.25); t_final = d.num("Time.Auto.t_final", 1.0);
+         nsteps = 1000000;
+      } else { dt = d.num("Time.Fixed.dt", 1.0); t_final = d.num("Time.Fixed.t_final", 1.0); nsteps = (int)std::ceil(t_final / dt - 1e-9); }
+      avg_stress_fname = d.str("Visualizations.avg_stress_fname", "avg_stress.txt");
+      additional_avgs = d.boolean("Visualizations.additional_avgs", false);
+      avg_def_grad_fname = d.str("Visualizations.avg_def_grad_fname", "avg_def_grad.txt");
+      avg_pl_work_fname = d.str("Visualizations.avg_pl_work_fname", "avg_pl_work.txt");
+      avg_dp_tensor_fname = d.str("Visualizations.avg_dp_tensor_fname", "avg_dp_tensor.txt");
+      const std::string as = lower(d.str("Solvers.assembly", "FULL"));
+      if (as == "pa") assembly = Assembly::PA; else if (as == "ea" || as == "full") assembly = Assembly::EA; else throw std::runtime_error("Unknown assembly: " + as);
+      integ_model = d.str("Solvers.integ_model", "FULL");
+      if (lower(integ_model) != "full") throw std::runtime_error("integ_model = \"BBAR\" is not built yet");
+      newton_iter = (int)d.num("Solvers.NR.iter", 25); newton_rel = d.num("Solvers.NR.rel_tol", 1e-5); newton_abs = d.num("Solvers.NR.abs_tol", 1e-10);
+      nl_solver = lower(d.str("Solvers.NR.nl_solver", "NR")) == "nrls" ? NLSolver::NRLS : NLSolver::NR;
+      krylov_iter = (int)d.num("Solvers.Krylov.iter", 200); krylov_rel = d.num("Solvers.Krylov.rel_tol", 1e-10); krylov_abs = d.num("Solvers.Krylov.abs_tol", 1e-30);
+      krylov_solver = d.str("Solvers.Krylov.solver", "PCG");
+      ref_ser = (int)d.num("Mesh.ref_ser", 0); order = (int)d.num("Mesh.p_refinement", 1);   // tests write "prefinement": ignored like the reference (src/option_parser.cpp:677)
+      mesh_type = lower(d.str("Mesh.type", "other"));
+      if (mesh_type != "auto") throw std::runtime_error("Only Mesh.type = \"auto\" is supported by this driver");
+      const TomlValue* nc = d.get("Mesh.Auto.ncuts"); const TomlValue* ln = d.get("Mesh.Auto.length");
+      if (!nc || !ln || nc->arr.size() != 3 || ln->arr.size() != 3) throw std::runtime_error("Must input mesh geometry/discretization for hex_mesh_gen");
+      for (int i = 0; i < 3; i++) { ncuts[i] = (int)nc->arr[i].num; length[i] = ln->arr[i].num; }
+      if (order != 1) throw std::runtime_error("Only p_refinement = 1 is built in this round");
+   }
+};
+
+}  // namespace exa_host

@@ -136,9 +136,11 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_setup_pa(const int Q, const int
 // ---- p = 1 specialised kernels: one lane per element, 64-element block per wave ------------------------------------
 template <bool LVEC>
 __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const double* __restrict__ pa, const double* __restrict__ x, double* __restrict__ y,
-                                                          const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask) {
+                                                          const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
+                                                          const double* __restrict__ gate) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
    if (e >= E) return;
+   if (gate != nullptr && gate[0] != 0.0) return;   // device-side "solver already converged" flag
    double X[3][8], Y[3][8];
    int g[8];
    if (LVEC) {
@@ -341,9 +343,11 @@ __global__ __launch_bounds__(PA_BLK) void k_assemble_ea_p1(const int E, const do
 // y(j,e) += sum_i A(i,j,e) x(i,e)
 template <bool LVEC>
 __global__ __launch_bounds__(PA_BLK) void k_ea_apply_p1(const int E, const double* __restrict__ emat, const double* __restrict__ x, double* __restrict__ y,
-                                                        const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask) {
+                                                        const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
+                                                        const double* __restrict__ gate) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
    if (e >= E) return;
+   if (gate != nullptr && gate[0] != 0.0) return;
    double X[24]; int g[8];
    if (LVEC) {
 #pragma unroll
@@ -450,10 +454,10 @@ int exa_launch_grad_setup_pa(exa_ctx* ctx, double dt, const double* J, const dou
    hipLaunchKernelGGL(k_grad_setup_pa, dim3(nblk(ctx->E, PA_BLK)), dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
-int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, hipStream_t s) {
+int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s) {
    const unsigned nb = nblk(ctx->E, PA_BLK);
-   if (lvec) hipLaunchKernelGGL(k_grad_apply_p1<true>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask);
-   else hipLaunchKernelGGL(k_grad_apply_p1<false>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask);
+   if (lvec) hipLaunchKernelGGL(k_grad_apply_p1<true>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask, gate);
+   else hipLaunchKernelGGL(k_grad_apply_p1<false>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask, gate);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_grad_diag_p1(exa_ctx* ctx, double* y, hipStream_t s) {
@@ -464,10 +468,10 @@ int exa_launch_assemble_ea_p1(exa_ctx* ctx, hipStream_t s) {
    hipLaunchKernelGGL(k_assemble_ea_p1, dim3(nblk(ctx->E, PA_BLK), 24), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, ctx->emat);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
-int exa_launch_ea_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, hipStream_t s) {
+int exa_launch_ea_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s) {
    const unsigned nb = nblk(ctx->E, PA_BLK);
-   if (lvec) hipLaunchKernelGGL(k_ea_apply_p1<true>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask);
-   else hipLaunchKernelGGL(k_ea_apply_p1<false>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask);
+   if (lvec) hipLaunchKernelGGL(k_ea_apply_p1<true>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
+   else hipLaunchKernelGGL(k_ea_apply_p1<false>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_ea_diag_p1(exa_ctx* ctx, double* y, hipStream_t s) {

@@ -1,0 +1,177 @@
+// Vector-level kernels of the Newton / PCG loop (gfx950), all on device-resident scalars so that one PCG iteration is a
+// fixed sequence of launches with no host synchronisation:
+//   MFEM CGSolver vector ops + dots (used at reference src/system_driver.cpp:166-177, src/mechanics_solver.cpp:62-121)
+//   MechOperatorJacobiSmoother::Mult  (reference src/mechanics_operator_ext.cpp:38-55)            -> fused into cg_step1
+//   essential-dof masking             (reference src/mechanics_operator_ext.cpp:146,172)
+//   ExaModel::UpdateEndCoords         (reference src/mechanics_model.cpp:472-474)
+// Dot products are weighted by 1/multiplicity of a node across ranks so that duplicated interface nodes count once.
+#include "host/device_utils.hpp"
+
+namespace {
+
+constexpr int RBLK = 256;
+
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+   sm[threadIdx.x] = v; __syncthreads();
+   for (int s = RBLK / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
+   const double r = sm[0]; __syncthreads();
+   return r;
+}
+
+__global__ void k_update_coords(int64_t n, const double* __restrict__ xb, const double* __restrict__ v, double dt, double* __restrict__ xe) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) xe[i] = xb[i] + v[i] * dt;
+}
+
+__global__ void k_mask_zero(int64_t n, const uint8_t* __restrict__ m, double* __restrict__ y) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n && m[i]) y[i] = 0.0;
+}
+
+__global__ void k_mask_set(int64_t n, const uint8_t* __restrict__ m, const double* __restrict__ val, double* __restrict__ y) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n && m[i]) y[i] = val[i];
+}
+
+// y = a*x + b*y
+__global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) y[i] = a * x[i] + b * y[i];
+}
+
+// dinv = mask ? 1 : 1/diag   (MechOperatorJacobiSmoother::Setup); identity mode: all ones
+__global__ void k_jacobi_setup(int64_t n, const uint8_t* __restrict__ m, const double* __restrict__ diag, int identity, double* __restrict__ dinv) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) dinv[i] = (identity || m[i]) ? 1.0 : 1.0 / diag[i];
+}
+
+__global__ void k_mask_one(int64_t n, const uint8_t* __restrict__ m, double* __restrict__ y) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n && m[i]) y[i] = 1.0;
+}
+
+// partial weighted dot: partial[b] = sum_i w[i % nn] a[i] b[i]
+__global__ void k_dot_partial(int64_t n, int64_t nn, const double* __restrict__ w, const double* __restrict__ a, const double* __restrict__ b,
+                              const double* __restrict__ flag, double* __restrict__ partial) {
+   __shared__ double sm[RBLK];
+   if (flag && flag[0] != 0.0) return;
+   double acc = 0;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += w[i % nn] * a[i] * b[i];
+   const double s = block_sum(acc, sm);
+   if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// out[slot] = sum partial
+__global__ void k_reduce(int nb, const double* __restrict__ partial, const double* __restrict__ flag, double* __restrict__ out) {
+   __shared__ double sm[RBLK];
+   if (flag && flag[0] != 0.0) return;
+   double acc = 0;
+   for (int i = threadIdx.x; i < nb; i += RBLK) acc += partial[i];
+   const double s = block_sum(acc, sm);
+   if (threadIdx.x == 0) out[0] = s;
+}
+
+// PCG scalars: S[0]=nom S[1]=den S[2]=betanom S[3]=r0 S[4]=alpha S[5]=beta S[6]=done flag (0 run, 1 converged, -1 breakdown) S[7]=iterations
+// S[8]=scratch for reductions
+__global__ void k_cg_init(double* S, double rel, double abs_) {       // after nom was reduced into S[8]
+   const double nom = S[8];
+   S[0] = nom; S[3] = fmax(nom * rel * rel, abs_ * abs_); S[7] = 0.0;
+   S[6] = (nom < 0.0) ? -1.0 : ((nom <= S[3]) ? 1.0 : 0.0);
+}
+__global__ void k_cg_den(double* S) {                                  // den reduced into S[8]
+   if (S[6] != 0.0) return;
+   const double den = S[8];
+   S[1] = den;
+   if (den <= 0.0) { S[6] = -1.0; return; }
+   S[4] = S[0] / den;
+}
+__global__ void k_cg_beta(double* S, double max_iter) {                // betanom reduced into S[8]
+   if (S[6] != 0.0) return;
+   const double bn = S[8];
+   S[2] = bn; S[7] += 1.0;
+   if (bn <= S[3]) { S[6] = 1.0; return; }
+   if (S[7] >= max_iter) { S[6] = 2.0; return; }
+   S[5] = bn / S[0]; S[0] = bn;
+}
+
+// x += alpha d; r -= alpha z; z = dinv r; partial of (r, z)_w
+__global__ void k_cg_step1(int64_t n, int64_t nn, const double* __restrict__ S, const double* __restrict__ w, const double* __restrict__ dinv,
+                           const double* __restrict__ d, double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial) {
+   __shared__ double sm[RBLK];
+   if (S[6] != 0.0) return;
+   const double alpha = S[4];
+   double acc = 0;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      x[i] += alpha * d[i];
+      const double ri = r[i] - alpha * z[i];
+      r[i] = ri;
+      const double zi = dinv[i] * ri;
+      z[i] = zi;
+      acc += w[i % nn] * ri * zi;
+   }
+   const double s = block_sum(acc, sm);
+   if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// d = z + beta d
+__global__ void k_cg_step2(int64_t n, const double* __restrict__ S, const double* __restrict__ z, double* __restrict__ d) {
+   if (S[6] != 0.0) return;
+   const double beta = S[5];
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = z[i] + beta * d[i];
+}
+
+__global__ void k_fill_if(int64_t n, const double* __restrict__ flag, double val, double* __restrict__ y) {
+   if (flag && flag[0] != 0.0) return;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = val;
+}
+
+// z = dinv .* r
+__global__ void k_pointwise(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ y) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) y[i] = a[i] * b[i];
+}
+
+// halo pack / unpack-add on lists of local dof indices
+__global__ void k_pack(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ y, double* __restrict__ buf) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) buf[i] = y[idx[i]];
+}
+__global__ void k_unpack_add(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ buf, double* __restrict__ y) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) y[idx[i]] += buf[i];
+}
+
+inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+inline unsigned gblk(int64_t n) { const int64_t b = (n + RBLK - 1) / RBLK; return (unsigned)(b < exa_host::DOT_BLOCKS ? (b > 0 ? b : 1) : exa_host::DOT_BLOCKS); }
+
+}  // namespace
+
+namespace exa_host {
+
+void vk_update_coords(int64_t n, const double* xb, const double* v, double dt, double* xe, hipStream_t s) { hipLaunchKernelGGL(k_update_coords, dim3(nblk(n)), dim3(256), 0, s, n, xb, v, dt, xe); }
+void vk_mask_zero(int64_t n, const uint8_t* m, double* y, hipStream_t s) { hipLaunchKernelGGL(k_mask_zero, dim3(nblk(n)), dim3(256), 0, s, n, m, y); }
+void vk_mask_set(int64_t n, const uint8_t* m, const double* val, double* y, hipStream_t s) { hipLaunchKernelGGL(k_mask_set, dim3(nblk(n)), dim3(256), 0, s, n, m, val, y); }
+void vk_mask_one(int64_t n, const uint8_t* m, double* y, hipStream_t s) { hipLaunchKernelGGL(k_mask_one, dim3(nblk(n)), dim3(256), 0, s, n, m, y); }
+void vk_axpby(int64_t n, double a, const double* x, double b, double* y, hipStream_t s) { hipLaunchKernelGGL(k_axpby, dim3(nblk(n)), dim3(256), 0, s, n, a, x, b, y); }
+void vk_jacobi_setup(int64_t n, const uint8_t* m, const double* diag, int identity, double* dinv, hipStream_t s) { hipLaunchKernelGGL(k_jacobi_setup, dim3(nblk(n)), dim3(256), 0, s, n, m, diag, identity, dinv); }
+void vk_pointwise(int64_t n, const double* a, const double* b, double* y, hipStream_t s) { hipLaunchKernelGGL(k_pointwise, dim3(nblk(n)), dim3(256), 0, s, n, a, b, y); }
+void vk_fill_if(int64_t n, const double* flag, double val, double* y, hipStream_t s) { hipLaunchKernelGGL(k_fill_if, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, flag, val, y); }
+// local part of the weighted dot: result in out[0] (device)
+void vk_dot(int64_t n, int64_t nn, const double* w, const double* a, const double* b, const double* flag, double* partial, double* out, hipStream_t s) {
+   const unsigned nb = gblk(n);
+   hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(RBLK), 0, s, n, nn, w, a, b, flag, partial);
+   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out);
+}
+void vk_cg_init(double* S, double rel, double abs_, hipStream_t s) { hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1), 0, s, S, rel, abs_); }
+void vk_cg_den(double* S, hipStream_t s) { hipLaunchKernelGGL(k_cg_den, dim3(1), dim3(1), 0, s, S); }
+void vk_cg_beta(double* S, int max_iter, hipStream_t s) { hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1), 0, s, S, (double)max_iter); }
+void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, hipStream_t s) {
+   const unsigned nb = gblk(n);
+   hipLaunchKernelGGL(k_cg_step1, dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial);
+   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S + 6, S + 8);
+}
+void vk_cg_step2(int64_t n, const double* S, const double* z, double* d, hipStream_t s) { hipLaunchKernelGGL(k_cg_step2, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, d); }
+void vk_pack(int64_t n, const int32_t* idx, const double* y, double* buf, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_pack, dim3(nblk(n)), dim3(256), 0, s, n, idx, y, buf); }
+void vk_unpack_add(int64_t n, const int32_t* idx, const double* buf, double* y, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_unpack_add, dim3(nblk(n)), dim3(256), 0, s, n, idx, buf, y); }
+
+}  // namespace exa_host

@@ -113,3 +113,124 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+# ---- stand-alone driver (exaconstit_amd/csrc/host/driver_capi.h) ---------------------------------------------------
+class ExaSynthConfig(C.Structure):
+    _fields_ = [("N", C.c_int), ("bcc", C.c_int), ("slip", C.c_int), ("nprops", C.c_int), ("props", C.POINTER(C.c_double)),
+                ("temp_k", C.c_double), ("quats", C.POINTER(C.c_double)), ("assembly", C.c_int), ("nrls", C.c_int), ("jacobi", C.c_int),
+                ("newton_iter", C.c_int), ("newton_rel", C.c_double), ("newton_abs", C.c_double),
+                ("krylov_iter", C.c_int), ("krylov_rel", C.c_double), ("krylov_abs", C.c_double),
+                ("nsteps", C.c_int), ("dts", C.POINTER(C.c_double)), ("vz", C.c_double)]
+
+
+exa_rccl_unique_id = _sig("exa_rccl_unique_id", C.c_int, C.c_void_p)
+exa_driver_create = _sig("exa_driver_create", C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int)
+exa_driver_create_synthetic = _sig("exa_driver_create_synthetic", C.c_void_p, C.POINTER(ExaSynthConfig), C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int)
+exa_driver_destroy = _sig("exa_driver_destroy", None, C.c_void_p)
+exa_driver_num_steps = _sig("exa_driver_num_steps", C.c_int, C.c_void_p)
+exa_driver_local_qpts = _sig("exa_driver_local_qpts", C.c_int64, C.c_void_p)
+exa_driver_local_dofs = _sig("exa_driver_local_dofs", C.c_int64, C.c_void_p)
+exa_driver_step = _sig("exa_driver_step", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_int)
+exa_driver_run = _sig("exa_driver_run", C.c_int, C.c_void_p, C.c_char_p, C.c_int)
+exa_driver_get_avgs = _sig("exa_driver_get_avgs", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int)
+exa_driver_get_stats = _sig("exa_driver_get_stats", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
+exa_driver_get_timers = _sig("exa_driver_get_timers", None, C.c_void_p, C.POINTER(C.c_double))
+exa_driver_reset_timers = _sig("exa_driver_reset_timers", None, C.c_void_p)
+exa_driver_bench_prepare = _sig("exa_driver_bench_prepare", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_char_p, C.c_int)
+exa_driver_bench_model = _sig("exa_driver_bench_model", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
+exa_driver_bench_pcg = _sig("exa_driver_bench_pcg", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
+
+
+class Driver:
+    """SystemDriver of the reference (src/system_driver.hpp:101-143) running on the GPU behind the C ABI."""
+
+    def __init__(self, handle, errbuf):
+        if not handle:
+            raise RuntimeError("driver creation failed: " + errbuf.value.decode())
+        self.h = handle
+        self._err = C.create_string_buffer(512)
+
+    @classmethod
+    def from_toml(cls, path, out_dir=".", rank=0, nranks=1, uid=None, jacobi=False, write_files=True):
+        err = C.create_string_buffer(512)
+        h = exa_driver_create(path.encode(), out_dir.encode(), rank, nranks, uid, int(jacobi), int(write_files), err, 512)
+        return cls(h, err)
+
+    @classmethod
+    def synthetic(cls, N, props, quats, dts, bcc=False, slip=0, temp_k=298.0, assembly=0, nrls=False, jacobi=False,
+                  newton=(25, 5e-5, 5e-10), krylov=(1000, 1e-7, 1e-27), vz=1.0e-3, rank=0, nranks=1, uid=None):
+        import numpy as np
+        props = np.ascontiguousarray(props, dtype=np.float64)
+        quats = np.ascontiguousarray(quats, dtype=np.float64)
+        dts = np.ascontiguousarray(dts, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        cfg = ExaSynthConfig(N, int(bcc), slip, len(props), props.ctypes.data_as(dp), temp_k, quats.ctypes.data_as(dp), assembly, int(nrls),
+                             int(jacobi), newton[0], newton[1], newton[2], krylov[0], krylov[1], krylov[2], len(dts), dts.ctypes.data_as(dp), vz)
+        err = C.create_string_buffer(512)
+        h = exa_driver_create_synthetic(C.byref(cfg), rank, nranks, uid, err, 512)
+        return cls(h, err)
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RuntimeError(self._err.value.decode())
+        return rc
+
+    def step(self, ti):
+        rc = exa_driver_step(self.h, ti, self._err, 512)
+        if rc < 0:
+            raise RuntimeError(self._err.value.decode())
+        return rc == 1
+
+    def run(self):
+        rc = exa_driver_run(self.h, self._err, 512)
+        if rc == -1000000:
+            raise RuntimeError(self._err.value.decode())
+        return rc
+
+    def avgs(self, which, width, maxrows=4096):
+        import numpy as np
+        out = np.zeros((maxrows, width))
+        rows = exa_driver_get_avgs(self.h, which, out.ctypes.data_as(C.POINTER(C.c_double)), maxrows)
+        return out[:rows].copy()
+
+    def stats(self, maxrows=4096):
+        import numpy as np
+        a = [np.zeros(maxrows, np.int32) for _ in range(3)]
+        ip = C.POINTER(C.c_int)
+        rows = exa_driver_get_stats(self.h, a[0].ctypes.data_as(ip), a[1].ctypes.data_as(ip), a[2].ctypes.data_as(ip), maxrows)
+        return [x[:rows].copy() for x in a]
+
+    def timers(self):
+        import numpy as np
+        t = np.zeros(5)
+        exa_driver_get_timers(self.h, t.ctypes.data_as(C.POINTER(C.c_double)))
+        return dict(model_ms=t[0], krylov_ms=t[1], solve_ms=t[2], qpt_updates=int(t[3]), krylov_iters=int(t[4]))
+
+    def bench_prepare(self, dts, perturb=1.0):
+        import numpy as np
+        dts = np.ascontiguousarray(dts, dtype=np.float64)
+        self._chk(exa_driver_bench_prepare(self.h, len(dts), dts.ctypes.data_as(C.POINTER(C.c_double)), perturb, self._err, 512))
+
+    def bench_model(self, steps):
+        import numpy as np
+        o = np.zeros(3)
+        self._chk(exa_driver_bench_model(self.h, steps, o.ctypes.data_as(C.POINTER(C.c_double)), self._err, 512))
+        return dict(loop_ms=o[0], kernel_ms=o[1], failed=int(o[2]))
+
+    def bench_pcg(self, iters):
+        import numpy as np
+        o = np.zeros(3)
+        self._chk(exa_driver_bench_pcg(self.h, iters, o.ctypes.data_as(C.POINTER(C.c_double)), self._err, 512))
+        return dict(pcg_ms=o[0], iters=int(o[1]), apply_ms=o[2])
+
+    def close(self):
+        if self.h:
+            exa_driver_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
