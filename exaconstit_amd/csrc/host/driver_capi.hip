@@ -3,7 +3,7 @@
 // the per-step loop, the avg_* outputs (reference src/system_driver.cpp:444-553) and the timing regions the reference marks
 // with Caliper (ecmech_kernel, krylov_solver: src/mechanics_ecmech.cpp:237-257, src/mechanics_solver.cpp:99-103).
 #include "driver.hpp"
-#include "driver_capi.h"
+#include "../../../include/exaconstit_driver.h"
 #include <cmath>
 #include <cstring>
 
@@ -169,6 +169,38 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out, char* err, int e
       out[2] = ms;
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
+int exa_options_query(const char* toml_path, double* out, char* err, int errlen) {
+   try {
+      ExaOptions o; o.parse_options(toml_path);
+      const double v[20] = { o.temp_k, (double)o.nprops, (double)o.num_grains, o.xtal == XtalType::BCC ? 1.0 : 0.0, (double)(int)o.slip, o.dt_cust ? 1.0 : 0.0,
+                             o.dt_auto ? 1.0 : 0.0, (double)o.nsteps, o.assembly == Assembly::PA ? 0.0 : 1.0, o.nl_solver == NLSolver::NRLS ? 1.0 : 0.0,
+                             (double)o.newton_iter, o.newton_rel, o.newton_abs, (double)o.krylov_iter, o.krylov_rel, o.krylov_abs, (double)o.ref_ser,
+                             (double)o.ncuts[0], o.additional_avgs ? 1.0 : 0.0, (double)o.bcs.size() };
+      std::memcpy(out, v, sizeof(v));
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
+int exa_partition_query(const int* N, int rank, int nranks, int64_t* info, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
+                        int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs) {
+   Partition p; const double L[3] = { 1.0, 1.0, 1.0 };
+   p.build(N, L, rank, nranks);
+   int64_t shared = 0; for (auto& nb : p.nbrs) shared += (int64_t)nb.dofs.size();
+   info[0] = p.E; info[1] = p.NN; info[2] = (int64_t)p.nbrs.size(); info[3] = p.pg[0]; info[4] = p.pg[1]; info[5] = p.pg[2]; info[6] = shared; info[7] = 0;
+   if (conn) std::memcpy(conn, p.conn.data(), sizeof(int32_t) * p.conn.size());
+   if (X) std::memcpy(X, p.X.data(), sizeof(double) * p.X.size());
+   if (elem_gid) std::memcpy(elem_gid, p.elem_gid.data(), sizeof(int64_t) * p.elem_gid.size());
+   if (weight) std::memcpy(weight, p.weight.data(), sizeof(double) * p.weight.size());
+   size_t off = 0;
+   for (size_t i = 0; i < p.nbrs.size(); i++) {
+      if (nbr_rank) nbr_rank[i] = p.nbrs[i].rank;
+      if (nbr_count) nbr_count[i] = (int32_t)p.nbrs[i].dofs.size();
+      if (nbr_dofs) std::memcpy(nbr_dofs + off, p.nbrs[i].dofs.data(), sizeof(int32_t) * p.nbrs[i].dofs.size());
+      off += p.nbrs[i].dofs.size();
+   }
+   return 0;
 }
 
 }  // extern "C"

@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
-#include "driver_capi.h"
+#include "../../../include/exaconstit_driver.h"
 
 int main(int argc, char** argv) {
    std::string opt = "options.toml";

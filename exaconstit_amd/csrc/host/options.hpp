@@ -121,6 +121,7 @@ struct ExaOptions {
       // BCs (reference src/option_parser.cpp get_bcs): either flat arrays or arrays-of-arrays keyed by update_steps
       const bool changing = d.boolean("BCs.changing_ess_bcs", false);
       const TomlValue* ids = d.get("BCs.essential_ids"); const TomlValue* comps = d.get("BCs.essential_comps"); const TomlValue* vals = d.get("BCs.essential_vals");
+      if (d.has("BCs.essential_vel_grad") || d.boolean("BCs.constant_strain_rate", false)) throw std::runtime_error("Velocity-gradient BCs (essential_vel_grad / negative essential_comps) are not built yet");
       if (!ids || !comps || !vals) throw std::runtime_error("BCs.essential_ids / essential_comps / essential_vals are required");
       auto flat = [](const TomlValue& a) { std::vector<double> o; for (auto& e : a.arr) o.push_back(e.num); return o; };
       if (changing) {

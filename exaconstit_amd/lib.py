@@ -115,7 +115,7 @@ class Context:
             pass
 
 
-# ---- stand-alone driver (exaconstit_amd/csrc/host/driver_capi.h) ---------------------------------------------------
+# ---- stand-alone driver (include/exaconstit_driver.h) ---------------------------------------------------
 class ExaSynthConfig(C.Structure):
     _fields_ = [("N", C.c_int), ("bcc", C.c_int), ("slip", C.c_int), ("nprops", C.c_int), ("props", C.POINTER(C.c_double)),
                 ("temp_k", C.c_double), ("quats", C.POINTER(C.c_double)), ("assembly", C.c_int), ("nrls", C.c_int), ("jacobi", C.c_int),
@@ -140,6 +140,8 @@ exa_driver_reset_timers = _sig("exa_driver_reset_timers", None, C.c_void_p)
 exa_driver_bench_prepare = _sig("exa_driver_bench_prepare", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_char_p, C.c_int)
 exa_driver_bench_model = _sig("exa_driver_bench_model", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_driver_bench_pcg = _sig("exa_driver_bench_pcg", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
+exa_options_query = _sig("exa_options_query", C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int)
+exa_partition_query = _sig("exa_partition_query", C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 class Driver:

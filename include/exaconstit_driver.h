@@ -1,5 +1,10 @@
-/* C entry points of the stand-alone driver inside libexaconstit_hip.so (run-time surface of the reference's `mechanics`
- * executable: reference src/mechanics_driver.cpp:112-1022).  Used by the `mechanics` binary, tests and bench.py. */
+/* exaconstit_driver.h — C entry points of the stand-alone driver inside libexaconstit_hip.so.
+ *
+ * Run-time surface of the reference's `mechanics -opt options.toml` executable (reference src/mechanics_driver.cpp:112-1022) and
+ * of its SystemDriver (reference src/system_driver.hpp:101-143) for callers without MFEM: the `mechanics` binary of this repo,
+ * the tests and bench.py.  Multi-GPU: one process per GPU; rank 0 obtains a RCCL unique id (exa_rccl_unique_id), the launcher
+ * distributes the 128 bytes (bench.py uses torch.distributed), every rank passes them to exa_driver_create*.
+ */
 #ifndef EXA_DRIVER_CAPI_H
 #define EXA_DRIVER_CAPI_H
 #include <stdint.h>
@@ -38,6 +43,17 @@ void exa_driver_reset_timers(exa_driver* d);
 int exa_driver_bench_prepare(exa_driver* d, int nsteps, const double* dts, double perturb, char* err, int errlen);
 int exa_driver_bench_model(exa_driver* d, int steps, double* out3, char* err, int errlen);
 int exa_driver_bench_pcg(exa_driver* d, int iters, double* out3, char* err, int errlen);
+
+/* host-logic queries that need no GPU (used by the CPU tests) ------------------------------------------------------------ */
+/* options.toml reader (reference src/option_parser.cpp:26-932): fills out[0..19] =
+ * {temp_k, nprops, num_grains, xtal, slip, dt_cust, dt_auto, nsteps, assembly(0 PA,1 EA), nl_solver(0 NR,1 NRLS), newton_iter, newton_rel,
+ *  newton_abs, krylov_iter, krylov_rel, krylov_abs, ref_ser, ncuts0, additional_avgs, number of BC change steps}; returns 0 or -1 (err) */
+int exa_options_query(const char* toml_path, double* out20, char* err, int errlen);
+/* block decomposition of an N0 x N1 x N2 element grid (reference: ParMesh/METIS, src/mechanics_driver.cpp:312): sizes first
+ * (info[0..7] = {E, NN, nneighbors, pg0, pg1, pg2, total shared dofs, 0}), then the arrays when the pointers are non-null:
+ * conn (8,E), X (NN,3 byNODES), elem_gid (E), weight (NN), nbr_rank (nneighbors), nbr_count (nneighbors), nbr_dofs (concatenated) */
+int exa_partition_query(const int* N, int rank, int nranks, int64_t* info8, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
+                        int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs);
 #ifdef __cplusplus
 }
 #endif
