@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--pcg-iters", type=int, default=100)
     ap.add_argument("--assembly", default="PA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solve-steps", type=int, default=0, help="additionally run this many real Newton/PCG time steps and report their rates")
     args = ap.parse_args()
 
     import torch
@@ -143,6 +144,23 @@ def main():
     t_pcg_wall = max_over_ranks(time.perf_counter() - t0)
     pcg_ms = max_over_ranks(pc["pcg_ms"]); apply_ms = max_over_ranks(pc["apply_ms"]) / args.pcg_iters
     pcg_it_s = pc["iters"] / (pcg_ms * 1e-3)
+    solve = None
+    if args.solve_steps > 0:
+        # real time stepping (Newton + PCG with the reference's tolerances) on a fresh driver: rates of the actual solve
+        drv.close()
+        rng = np.random.default_rng(20240928)
+        quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
+        sched = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "custom_dt.txt")).ravel()[:args.solve_steps]
+        drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=0 if args.assembly.upper() == "PA" else 1, rank=rank, nranks=world, uid=uid)
+        barrier(); t0 = time.perf_counter()
+        for ti in range(1, args.solve_steps + 1):
+            assert drv.step(ti), f"Newton failed at step {ti}"
+        barrier(); wall = max_over_ranks(time.perf_counter() - t0)
+        tm = drv.timers(); nw, kr, mc = drv.stats()
+        solve = {"steps": args.solve_steps, "wall_s": wall, "newton_iters": [int(x) for x in nw], "krylov_iters": [int(x) for x in kr],
+                 "model_calls": [int(x) for x in mc], "qpt_updates_per_s_in_kernel": 8 * N ** 3 * int(sum(mc)) / (max_over_ranks(tm["model_ms"]) * 1e-3),
+                 "pcg_iters_per_s": tm["krylov_iters"] / (max_over_ranks(tm["krylov_ms"]) * 1e-3),
+                 "avg_stress_zz": [float(x) for x in drv.avgs(0, 6)[:, 2]]}
     if rank == 0:
         ndof_local = L.exa_driver_local_dofs(drv.h)
         model_gbs = MODEL_BYTES_PER_QPT * P_local / (kern_ms * 1e-3) / 1e9
@@ -168,6 +186,8 @@ def main():
                                    "bytes_per_qpt": APPLY_BYTES_PER_QPT, "avg_kernel_ms": apply_ms,
                                    "pcg_iteration_frac": iter_bytes / (pcg_ms * 1e-3 / max(pc["iters"], 1)) / 1e9 / HBM_PEAK_GBS},
         }
+        if solve is not None:
+            out["newton_pcg_solve"] = solve
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(props)

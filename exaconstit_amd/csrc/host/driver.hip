@@ -53,9 +53,13 @@ void Comm::get_unique_id(void* out128) { ncclUniqueId id; nccl_check(rccl().GetU
 
 void Comm::init(int rank_, int nranks_, const void* uid) {
    rank = rank_; nranks = nranks_;
-   if (nranks > 1) {
-      if (!uid) throw std::runtime_error("Comm::init: a RCCL unique id is required for nranks > 1");
-      ncclUniqueId id; std::memcpy(&id, uid, sizeof(id));
+   // EXA_FORCE_RCCL=1 routes the one-rank case through RCCL too (plumbing check on a single-GPU box)
+   force_ = (nranks == 1 && std::getenv("EXA_FORCE_RCCL") != nullptr);
+   if (nranks > 1 || force_) {
+      ncclUniqueId id;
+      if (uid) std::memcpy(&id, uid, sizeof(id));
+      else if (force_) nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+      else throw std::runtime_error("Comm::init: a RCCL unique id is required for nranks > 1");
       ncclComm_t c; nccl_check(rccl().CommInitRank(&c, nranks, id, rank), "ncclCommInitRank");
       comm_ = c;
    }
@@ -63,8 +67,8 @@ void Comm::init(int rank_, int nranks_, const void* uid) {
 }
 Comm::~Comm() { if (comm_) rccl().CommDestroy((ncclComm_t)comm_); }
 
-void Comm::allreduce_sum(double* dev, int n, hipStream_t s) { if (nranks > 1) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)comm_, s), "ncclAllReduce"); }
-void Comm::allreduce_min(double* dev, int n, hipStream_t s) { if (nranks > 1) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclMin, (ncclComm_t)comm_, s), "ncclAllReduce"); }
+void Comm::allreduce_sum(double* dev, int n, hipStream_t s) { if (nranks > 1 || force_) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)comm_, s), "ncclAllReduce"); }
+void Comm::allreduce_min(double* dev, int n, hipStream_t s) { if (nranks > 1 || force_) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclMin, (ncclComm_t)comm_, s), "ncclAllReduce"); }
 
 double Comm::max_over_ranks(double v) {
    if (nranks == 1) return v;
@@ -83,7 +87,7 @@ void Comm::setup_halo(const Partition& part) {
 }
 
 void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
-   if (nranks == 1) return;
+   if (nranks == 1 && !force_) return;
    const size_t nb = part.nbrs.size();
    for (size_t i = 0; i < nb; i++) vk_pack((int64_t)idx_[i].n, idx_[i].p, y, sbuf_[i].p, s);
    nccl_check(rccl().GroupStart(), "ncclGroupStart");

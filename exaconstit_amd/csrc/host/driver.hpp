@@ -33,7 +33,7 @@ class Comm {
    void setup_halo(const Partition& part);
    double max_over_ranks(double v);
  private:
-   void* comm_ = nullptr;
+   void* comm_ = nullptr; bool force_ = false;
    std::vector<DevBuf<int32_t>> idx_; std::vector<DevBuf<double>> sbuf_, rbuf_;
    DevBuf<double> tmp_;
 };
