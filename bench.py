@@ -163,6 +163,15 @@ def main():
                  "avg_stress_zz": [float(x) for x in drv.avgs(0, 6)[:, 2]]}
     if rank == 0:
         ndof_local = L.exa_driver_local_dofs(drv.h)
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench): bytes/qpt x local qpts
+        traffic = {}
+        try:
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+            if cands:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["bytes_per_qpt"]
+                traffic["_file"] = "profiles/" + cands[-1]
+        except Exception:
+            traffic = {}
         model_gbs = MODEL_BYTES_PER_QPT * P_local / (kern_ms * 1e-3) / 1e9
         apply_gbs = APPLY_BYTES_PER_QPT * P_local / (apply_ms * 1e-3) / 1e9
         iter_bytes = APPLY_BYTES_PER_QPT * P_local + PCG_VEC_BYTES_PER_DOF * ndof_local
@@ -177,12 +186,14 @@ def main():
             "pcg_iters_per_s": pcg_it_s, "pcg_iters": pc["iters"], "pcg_ms_per_iter": pcg_ms / max(pc["iters"], 1),
             "pcg_wall_s": t_pcg_wall, "nonconverged_points": m["failed"],
             "roofline": {"kernel": "k_model_setup<Voce> (fused grad_calc + ExaCMech update + tangent)", "bound": "hbm",
-                         "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic["k_model_setup"] * P_local if "k_model_setup" in traffic else None, "traffic_source": traffic.get("_file"),
                          "bytes_per_qpt": MODEL_BYTES_PER_QPT, "avg_kernel_ms": kern_ms,
                          "note": "FP64-VALU/transcendental-bound kernel (SURVEY 8(d)): the HBM fraction is reported as the contract asks; "
                                  "see roofline_pcg_apply for the HBM-bound half of the metric"},
             "roofline_pcg_apply": {"kernel": "k_grad_apply_p1<LVEC> (AddMultGradPA + gather/scatter)", "bound": "hbm", "achieved": apply_gbs,
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": apply_gbs / HBM_PEAK_GBS, "traffic": None,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": apply_gbs / HBM_PEAK_GBS,
+                                   "traffic": traffic["k_grad_apply_p1"] * P_local if "k_grad_apply_p1" in traffic else None,
                                    "bytes_per_qpt": APPLY_BYTES_PER_QPT, "avg_kernel_ms": apply_ms,
                                    "pcg_iteration_frac": iter_bytes / (pcg_ms * 1e-3 / max(pc["iters"], 1)) / 1e9 / HBM_PEAK_GBS},
         }
