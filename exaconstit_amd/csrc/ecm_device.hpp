@@ -17,8 +17,12 @@
 namespace ecmdev {
 
 #define ECM_DI __device__ __forceinline__
+#ifndef ECM_SLIP_UNROLL
+#define ECM_SLIP_UNROLL 1   // slip-system loop unroll factor of the point problem (ILP vs registers; tuned on MI355X)
+#endif
 
 constexpr int NSLIP = 12;
+constexpr int kSlipUnroll = ECM_SLIP_UNROLL;
 constexpr double SQR2 = 1.4142135623730951, SQR3 = 1.7320508075688772;
 constexpr double SQR2I = 0.70710678118654752, SQR6I = 0.40824829046386302, SQR2B3 = 0.81649658092772603;
 constexpr double TINY_SQRT = 1.0e-90, EPS_SQRT = 1.0e-8;
@@ -44,11 +48,21 @@ __device__ constexpr double Q_TAB[3][NSLIP] = {
    { -2 * PB, PB, PB, -PB, 2 * PB, -PB, 2 * PB, -PB, -PB, PB, -2 * PB, PB },
    { PB, -2 * PB, PB, -2 * PB, PB, PB, -PB, 2 * PB, -PB, 2 * PB, -PB, -PB },
    { PB, PB, -2 * PB, PB, PB, -2 * PB, PB, PB, -2 * PB, PB, PB, -2 * PB } };
+// the same numbers, one row of 8 per slip system (P0..P4, Q0..Q2): the slip-system loop of the point problem is kept ROLLED
+// (uniform index -> scalar loads), which more than halves the register footprint of the fused kernel
+__device__ const double PQ_TAB[NSLIP][8] = {
+   { -PA, -0.5, PA, -PA, 0.0, -2 * PB, PB, PB },       { -PA, 0.5, -PA, 0.0, PA, PB, -2 * PB, PB },
+   { 2 * PA, 0.0, 0.0, PA, -PA, PB, PB, -2 * PB },     { PA, -0.5, -PA, 0.0, -PA, -PB, -2 * PB, PB },
+   { PA, 0.5, PA, -PA, 0.0, 2 * PB, PB, PB },          { -2 * PA, 0.0, 0.0, PA, PA, -PB, PB, -2 * PB },
+   { -PA, -0.5, PA, PA, 0.0, 2 * PB, -PB, PB },        { -PA, 0.5, -PA, 0.0, -PA, -PB, 2 * PB, PB },
+   { 2 * PA, 0.0, 0.0, -PA, PA, -PB, -PB, -2 * PB },   { PA, -0.5, -PA, 0.0, PA, PB, 2 * PB, PB },
+   { PA, 0.5, PA, PA, 0.0, -2 * PB, -PB, PB },         { -2 * PA, 0.0, 0.0, -PA, -PA, PB, -PB, -2 * PB } };
 
 // Material description, passed by value as a kernel argument (lives in SGPRs / kernarg segment).
 struct MatParams {
    int kin;                 // KIN_*
    int with_g_athermal;     // KMBalD: 1 for BCC ("Kin_BCC_A"), 0 for FCC ("Kin_FCC_B")
+   int xn_int;              // 1/m - 1 when it is a small integer (m = 0.02 -> 49): power by repeated multiplication, else 0
    double qsign;            // +1 FCC, -1 BCC: sign of the plastic-spin vectors
    double kd0, kd2;         // Kirchhoff' = diag(kd0,kd0,kd2,kd2,kd2) e'
    double bulk, gmod, gamma, tK0, dtde, tol;
@@ -131,6 +145,15 @@ ECM_DI void exp_map(const double xi[3], double A[9], double Tr[9]) {
 // ------------------------------------------------------------------------------------------------------------
 struct KinVals { double g, gam_w, gam_r, c_e; };
 
+ECM_DI double pow_xn(const MatParams& mp, double at) {   // at^(1/m - 1)
+   if (mp.xn_int > 0) {
+      double r = 1.0, b = at;
+      for (int e = mp.xn_int; e; e >>= 1) { if (e & 1) r *= b; b *= b; }   // uniform trip count
+      return r;
+   }
+   return exp(mp.xn * log(at));
+}
+
 ECM_DI void voce_gdot(const MatParams& mp, double g_i, double tau, double& gdot, double& dg) {
    gdot = 0.0; dg = 0.0;
    const double t_frac = tau * g_i, at = fabs(t_frac);
@@ -139,7 +162,7 @@ ECM_DI void voce_gdot(const MatParams& mp, double g_i, double tau, double& gdot,
          gdot = copysign(mp.gam_w * GAM_RATIO_OVF, t_frac);
          dg = fabs(gdot) * mp.xnn / fabs(tau);
       } else {
-         const double temp = mp.gam_w * exp(mp.xn * log(at));
+         const double temp = mp.gam_w * pow_xn(mp, at);
          gdot = temp * t_frac; dg = temp * mp.xnn * g_i;
       }
    }
@@ -182,7 +205,7 @@ ECM_DI void kmbald_gdot(const MatParams& mp, const KinVals& kv, double tau, doub
    double gdot_w = kv.gam_w * (ef - eb);
    double dgdot_w = kv.gam_w * (ef * df_f + eb * df_b) * g_i;
    if (at_0 > mp.t_min) {
-      const double temp = (kv.gam_w * 10.0) * exp(mp.xn * log(at_0));
+      const double temp = (kv.gam_w * 10.0) * pow_xn(mp, at_0);
       gdot_w += temp * at_0; dgdot_w += temp * mp.xnn * g_i;
    }
    if (gdot_w <= 0.0) return;
@@ -231,62 +254,53 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
    return (KIN == KIN_KMBALD) ? exp(h_n) : h_n;
 }
 
+// Register budget.  Two waves per SIMD need <= 256 VGPRs; the naive point update wants ~370.  What is not touched inside the
+// slip-system loop is therefore parked outside the register file:
+//   * per-thread LDS stash (slot s of thread t at stash[s * ECM_STASH_STRIDE + t], conflict-free): the vectors an evaluation reads
+//     once (e_n, d_n, w_n), the rotation data of the last evaluation (Tr, d_lat, w_lat: written once per evaluation, read by the
+//     solve) and the restore copy of x — 38 doubles, so two 256-thread blocks fit the 160 KB of a CU;
+//   * values only needed after the local solve (D', old stress, quaternion, volumes, energy ...) are parked in the point's own
+//     36-double tangent slot in global memory, which is written last.
+#ifndef ECM_STASH_STRIDE
+#define ECM_STASH_STRIDE 256
+#endif
+constexpr int ST_EN = 0, ST_DN = 5, ST_WN = 10, ST_TR = 13, ST_DL = 22, ST_WL = 27, ST_XS = 30, ST_SLOTS = 38;
+constexpr int CD_DSM = 0, CD_SOLD = 5, CD_QN = 10, CD_VOLD = 14, CD_VNEW = 15, CD_ENEW = 16, CD_DEFF = 17, CD_BULK = 18, CD_HU = 19;
+#define ECM_ST(p, slot) (p)[(slot) * ECM_STASH_STRIDE]
+// compiler-only barrier: what was parked must be re-loaded later instead of being kept alive in registers
+#define ECM_PARK_BARRIER() asm volatile("" ::: "memory")
+
 // ------------------------------------------------------------------------------------------------------------
 // the point problem: unknowns x = (delta e' / E_SCALE, xi / R_SCALE)
 // ------------------------------------------------------------------------------------------------------------
 struct Prob {
-   double dt_ri, detV_ri, sc;   // sc = epsdot_scale_inv
-   double e_n[5], d_n[5], w_n[3];   // begin-of-step strain; D' and spin vector pulled back with C_n
+   double dt_ri, detV_ri, sc, sc_i, g_i;   // sc = epsdot_scale_inv, sc_i = 1/sc, g_i = 1/g
+   double* st;                             // per-thread stash
    KinVals kv;
 };
 
-// Jacobian blocks (un-scaled):  Jee = I/dt + A Kd,  Jer = -Mer,  Jre = B Kd,  Jrr = I/dt - Wt
-struct Jac { double A[15], B[3][5], Mer[5][3], Wt[3][3]; };
+// Jacobian (un-scaled):
+//   Jee = I/dt + A Kd      A = P G P^T (packed symmetric 15); after jac_factor the same 15 slots hold the LDL^T factor of
+//                          M = diag(1/(kd dt)) + A  (Jee = M Kd)
+//   Jre = B Kd             B = Q G P^T
+//   Jer = -M35(d_lat) Tr,  Jrr = I/dt - hat(w_lat) Tr      with Tr, d_lat, w_lat of the last evaluation in the stash
+struct Jac { double A[15], B[3][5]; };
 
 ECM_DI constexpr int sidx(int i, int j) { return i <= j ? (i * (11 - i)) / 2 + (j - i) : (j * (11 - j)) / 2 + (i - j); }   // 5x5 symmetric packing
 
+// One evaluation of residual (+ Jacobian).  gdot_out: nullable pointer (global memory) receiving the 12 slip rates.
 template <int KIN, bool WITHJ>
 ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], double r[8], Jac& jac,
-                    double gdot[NSLIP], double& dis_rate) {
-   double e_f[5], xi[3];
+                    double* __restrict__ gdot_out, double& dis_rate, double& shrate) {
+   // resolved shear stress from the Kirchhoff stress K e'
+   double k[5];
+   { double e_f[5];
 #pragma unroll
-   for (int i = 0; i < 5; i++) e_f[i] = pb.e_n[i] + x[i] * E_SCALE;
-#pragma unroll
-   for (int i = 0; i < 3; i++) xi[i] = x[5 + i] * R_SCALE;
-   double A[9], Tr[9]; exp_map(xi, A, Tr);
-   double d_lat[5]; rot_vecd_T(A, pb.d_n, d_lat);
-   double w_lat[3];
-#pragma unroll
-   for (int i = 0; i < 3; i++) w_lat[i] = A[i] * pb.w_n[0] + A[3 + i] * pb.w_n[1] + A[6 + i] * pb.w_n[2];
-   // resolved shear stress from the Kirchhoff stress
-   const double k[5] = { mp.kd0 * e_f[0], mp.kd0 * e_f[1], mp.kd2 * e_f[2], mp.kd2 * e_f[3], mp.kd2 * e_f[4] };
-   double dgdt[NSLIP];
-   const double g_i = 1.0 / pb.kv.g;
-   dis_rate = 0.0;
-   bool ok = true;
-#pragma unroll
-   for (int a = 0; a < NSLIP; a++) {
-      double tau = 0.0;
-#pragma unroll
-      for (int c = 0; c < 5; c++) if (P_TAB[c][a] != 0.0) tau += P_TAB[c][a] * k[c];
-      if (KIN == KIN_KMBALD) kmbald_gdot(mp, pb.kv, tau, gdot[a], dgdt[a]);
-      else voce_gdot(mp, g_i, tau, gdot[a], dgdt[a]);
-      dis_rate += tau * gdot[a];
-      ok = ok && isfinite(gdot[a]);
-   }
-   dis_rate *= pb.detV_ri;
+     for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(pb.st, ST_EN + i) + x[i] * E_SCALE;
+     k[0] = mp.kd0 * e_f[0]; k[1] = mp.kd0 * e_f[1]; k[2] = mp.kd2 * e_f[2]; k[3] = mp.kd2 * e_f[3]; k[4] = mp.kd2 * e_f[4]; }
+   const double g_i = pb.g_i;
+   double dis = 0.0, shr = 0.0;
    double dp[5] = { 0, 0, 0, 0, 0 }, wp[3] = { 0, 0, 0 };
-#pragma unroll
-   for (int a = 0; a < NSLIP; a++) {
-#pragma unroll
-      for (int c = 0; c < 5; c++) if (P_TAB[c][a] != 0.0) dp[c] += P_TAB[c][a] * gdot[a];
-#pragma unroll
-      for (int c = 0; c < 3; c++) wp[c] += Q_TAB[c][a] * gdot[a];
-   }
-#pragma unroll
-   for (int c = 0; c < 5; c++) r[c] = (x[c] * (E_SCALE * pb.dt_ri) + dp[c] - d_lat[c]) * pb.sc;
-#pragma unroll
-   for (int c = 0; c < 3; c++) r[5 + c] = (xi[c] * pb.dt_ri + mp.qsign * wp[c] - w_lat[c]) * pb.sc;
    if (WITHJ) {
 #pragma unroll
       for (int i = 0; i < 15; i++) jac.A[i] = 0.0;
@@ -294,148 +308,246 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       for (int i = 0; i < 3; i++)
 #pragma unroll
          for (int j = 0; j < 5; j++) jac.B[i][j] = 0.0;
+   }
+   bool ok = true;
+#pragma unroll kSlipUnroll
+   for (int a = 0; a < NSLIP; a++) {
+      double pq[8];
 #pragma unroll
-      for (int a = 0; a < NSLIP; a++) {
+      for (int c = 0; c < 8; c++) pq[c] = PQ_TAB[a][c];
+      const double tau = pq[0] * k[0] + pq[1] * k[1] + pq[2] * k[2] + pq[3] * k[3] + pq[4] * k[4];
+      double gd, dg;
+      if (KIN == KIN_KMBALD) kmbald_gdot(mp, pb.kv, tau, gd, dg);
+      else voce_gdot(mp, g_i, tau, gd, dg);
+      if (gdot_out) gdot_out[a] = gd;
+      dis += tau * gd; shr += fabs(gd);
+      ok = ok && isfinite(gd);
+#pragma unroll
+      for (int c = 0; c < 5; c++) dp[c] += pq[c] * gd;
+#pragma unroll
+      for (int c = 0; c < 3; c++) wp[c] += pq[5 + c] * gd;
+      if (WITHJ) {
          double gp[5];
 #pragma unroll
-         for (int c = 0; c < 5; c++) gp[c] = dgdt[a] * P_TAB[c][a];
+         for (int c = 0; c < 5; c++) gp[c] = dg * pq[c];
 #pragma unroll
          for (int i = 0; i < 5; i++)
 #pragma unroll
-            for (int j = i; j < 5; j++) if (P_TAB[i][a] != 0.0 && P_TAB[j][a] != 0.0) jac.A[sidx(i, j)] += P_TAB[i][a] * gp[j];
+            for (int j = i; j < 5; j++) jac.A[sidx(i, j)] += pq[i] * gp[j];
 #pragma unroll
          for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = 0; j < 5; j++) if (P_TAB[j][a] != 0.0) jac.B[i][j] += (mp.qsign * Q_TAB[i][a]) * gp[j];
+            for (int j = 0; j < 5; j++) jac.B[i][j] += pq[5 + i] * gp[j];
       }
-      double M[5][3]; m35(d_lat, M);
-#pragma unroll
-      for (int c = 0; c < 5; c++)
-#pragma unroll
-         for (int j = 0; j < 3; j++) jac.Mer[c][j] = M[c][0] * Tr[j] + M[c][1] * Tr[3 + j] + M[c][2] * Tr[6 + j];
-      // hat(w_lat) Tr
-      const double W[3][3] = { { 0.0, -w_lat[2], w_lat[1] }, { w_lat[2], 0.0, -w_lat[0] }, { -w_lat[1], w_lat[0], 0.0 } };
+   }
+   dis_rate = dis * pb.detV_ri; shrate = shr;
+   if (WITHJ && mp.qsign < 0.0) {
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
-         for (int j = 0; j < 3; j++) jac.Wt[i][j] = W[i][0] * Tr[j] + W[i][1] * Tr[3 + j] + W[i][2] * Tr[6 + j];
+         for (int j = 0; j < 5; j++) jac.B[i][j] = -jac.B[i][j];
    }
+   // rotation part after the slip loop so that nothing of it is live across the loop
+   double xi[3];
+#pragma unroll
+   for (int i = 0; i < 3; i++) xi[i] = x[5 + i] * R_SCALE;
+   double A[9], Tr[9]; exp_map(xi, A, Tr);
+   if (WITHJ) {
+#pragma unroll
+      for (int c = 0; c < 9; c++) ECM_ST(pb.st, ST_TR + c) = Tr[c];
+   }
+   {
+      double dn[5], d_lat[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) dn[i] = ECM_ST(pb.st, ST_DN + i);
+      rot_vecd_T(A, dn, d_lat);
+#pragma unroll
+      for (int c = 0; c < 5; c++) {
+         r[c] = (x[c] * (E_SCALE * pb.dt_ri) + dp[c] - d_lat[c]) * pb.sc;
+         if (WITHJ) ECM_ST(pb.st, ST_DL + c) = d_lat[c];
+      }
+   }
+   {
+      const double w0 = ECM_ST(pb.st, ST_WN), w1 = ECM_ST(pb.st, ST_WN + 1), w2 = ECM_ST(pb.st, ST_WN + 2);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+         const double w_lat = A[c] * w0 + A[3 + c] * w1 + A[6 + c] * w2;
+         r[5 + c] = (xi[c] * pb.dt_ri + mp.qsign * wp[c] - w_lat) * pb.sc;
+         if (WITHJ) ECM_ST(pb.st, ST_WL + c) = w_lat;
+      }
+   }
+   ECM_PARK_BARRIER();
    return ok;
 }
 
-// y = J v  (un-scaled blocks)
-ECM_DI void jac_mult(const MatParams& mp, const Prob& pb, const Jac& J, const double v[8], double y[8]) {
-   const double kv[5] = { mp.kd0 * v[0], mp.kd0 * v[1], mp.kd2 * v[2], mp.kd2 * v[3], mp.kd2 * v[4] };
+// ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
+ECM_DI void load_tr(const Prob& pb, double Tr[9]) { for (int c = 0; c < 9; c++) Tr[c] = ECM_ST(pb.st, ST_TR + c); }
+ECM_DI void load_dl(const Prob& pb, double d[5]) { for (int c = 0; c < 5; c++) d[c] = ECM_ST(pb.st, ST_DL + c); }
+
+// Jer v_r = -M35(d_lat) (Tr v_r)
+ECM_DI void jer_mult(const Prob& pb, const double vr[3], double out[5]) {
+   double Tr[9]; load_tr(pb, Tr);
+   double th[3];
 #pragma unroll
-   for (int i = 0; i < 5; i++) {
-      double s = v[i] * pb.dt_ri;
+   for (int i = 0; i < 3; i++) th[i] = Tr[3 * i] * vr[0] + Tr[3 * i + 1] * vr[1] + Tr[3 * i + 2] * vr[2];
+   double d[5]; load_dl(pb, d);
+   double M[5][3]; m35(d, M);
 #pragma unroll
-      for (int j = 0; j < 5; j++) s += J.A[sidx(i, j)] * kv[j];
-      s -= J.Mer[i][0] * v[5] + J.Mer[i][1] * v[6] + J.Mer[i][2] * v[7];
-      y[i] = s;
-   }
+   for (int k = 0; k < 5; k++) out[k] = -(M[k][0] * th[0] + M[k][1] * th[1] + M[k][2] * th[2]);
+}
+// Jer^T u_e
+ECM_DI void jer_mult_T(const Prob& pb, const double ue[5], double out[3]) {
+   double d[5]; load_dl(pb, d);
+   double M[5][3]; m35(d, M);
+   double th[3];
 #pragma unroll
-   for (int i = 0; i < 3; i++) {
-      double s = v[5 + i] * pb.dt_ri;
+   for (int j = 0; j < 3; j++) { double v = 0; for (int k = 0; k < 5; k++) v += M[k][j] * ue[k]; th[j] = -v; }
+   double Tr[9]; load_tr(pb, Tr);
 #pragma unroll
-      for (int j = 0; j < 5; j++) s += J.B[i][j] * kv[j];
-      s -= J.Wt[i][0] * v[5] + J.Wt[i][1] * v[6] + J.Wt[i][2] * v[7];
-      y[5 + i] = s;
-   }
+   for (int j = 0; j < 3; j++) out[j] = Tr[j] * th[0] + Tr[3 + j] * th[1] + Tr[6 + j] * th[2];
+}
+// hat(w_lat) Tr as a 3x3 (row-major)
+ECM_DI void wt_matrix(const Prob& pb, double Wt[9]) {
+   double Tr[9]; load_tr(pb, Tr);
+   const double w0 = ECM_ST(pb.st, ST_WL), w1 = ECM_ST(pb.st, ST_WL + 1), w2 = ECM_ST(pb.st, ST_WL + 2);
+   const double W[3][3] = { { 0.0, -w2, w1 }, { w2, 0.0, -w0 }, { -w1, w0, 0.0 } };
+#pragma unroll
+   for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Wt[3 * i + j] = W[i][0] * Tr[j] + W[i][1] * Tr[3 + j] + W[i][2] * Tr[6 + j];
 }
 
-// y = J^T u
-ECM_DI void jac_mult_T(const MatParams& mp, const Prob& pb, const Jac& J, const double u[8], double y[8]) {
-   const double kd[5] = { mp.kd0, mp.kd0, mp.kd2, mp.kd2, mp.kd2 };
-#pragma unroll
-   for (int j = 0; j < 5; j++) {
-      double s = 0.0;
-#pragma unroll
-      for (int i = 0; i < 5; i++) s += J.A[sidx(i, j)] * u[i];
-      s += J.B[0][j] * u[5] + J.B[1][j] * u[6] + J.B[2][j] * u[7];
-      y[j] = u[j] * pb.dt_ri + kd[j] * s;
-   }
-#pragma unroll
-   for (int j = 0; j < 3; j++) {
-      double s = u[5 + j] * pb.dt_ri;
-#pragma unroll
-      for (int i = 0; i < 5; i++) s -= J.Mer[i][j] * u[i];
-      s -= J.Wt[0][j] * u[5] + J.Wt[1][j] * u[6] + J.Wt[2][j] * u[7];
-      y[5 + j] = s;
-   }
-}
+// Factorisation.  In place: J.A <- LDL^T of M = diag(1/(kd dt)) + A (unit lower L stored in the strict upper slots, 1/D on the
+// diagonal); Ri = Jrr^-1.  The coupling blocks are O(|D| dt) ~ 1e-4 relative, so J dx = rhs is solved by block Gauss-Seidel
+// sweeps on (e, r) with these two exact diagonal-block inverses: contraction ~1e-4 per sweep, 3 sweeps reach round-off.
+struct Fact { double Ri[9]; bool ok; };
 
-// Factorisation of J in its block form.  Ri = Jrr^-1, Y = Ri Jre, LU = un-pivoted LU of S = Jee - Jer Y.
-struct Fact { double Ri[3][3], Y[3][5], LU[5][5]; bool ok; };
-
-ECM_DI void jac_factor(const MatParams& mp, const Prob& pb, const Jac& J, Fact& F) {
-   const double kd[5] = { mp.kd0, mp.kd0, mp.kd2, mp.kd2, mp.kd2 };
+ECM_DI void jac_factor(const MatParams& mp, const Prob& pb, Jac& J, Fact& F) {
+   const double kdi0 = pb.dt_ri / mp.kd0, kdi2 = pb.dt_ri / mp.kd2;
+   J.A[sidx(0, 0)] += kdi0; J.A[sidx(1, 1)] += kdi0; J.A[sidx(2, 2)] += kdi2; J.A[sidx(3, 3)] += kdi2; J.A[sidx(4, 4)] += kdi2;
+   bool ok = true;
+#pragma unroll
+   for (int k = 0; k < 5; k++) {
+      const double d = J.A[sidx(k, k)];
+      ok = ok && (d > 0.0);
+      const double inv = 1.0 / d;
+      double li[5];
+#pragma unroll
+      for (int i = k + 1; i < 5; i++) li[i] = J.A[sidx(k, i)] * inv;
+#pragma unroll
+      for (int i = k + 1; i < 5; i++)
+#pragma unroll
+         for (int j = i; j < 5; j++) J.A[sidx(i, j)] -= li[i] * J.A[sidx(k, j)];
+#pragma unroll
+      for (int i = k + 1; i < 5; i++) J.A[sidx(k, i)] = li[i];
+      J.A[sidx(k, k)] = inv;
+   }
+   double Wt[9]; wt_matrix(pb, Wt);
    double R[3][3];
 #pragma unroll
    for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = 0; j < 3; j++) R[i][j] = (i == j ? pb.dt_ri : 0.0) - J.Wt[i][j];
+      for (int j = 0; j < 3; j++) R[i][j] = (i == j ? pb.dt_ri : 0.0) - Wt[3 * i + j];
    const double c00 = R[1][1] * R[2][2] - R[1][2] * R[2][1], c01 = R[1][2] * R[2][0] - R[1][0] * R[2][2], c02 = R[1][0] * R[2][1] - R[1][1] * R[2][0];
    const double det = R[0][0] * c00 + R[0][1] * c01 + R[0][2] * c02;
    const double di = 1.0 / det;
-   F.Ri[0][0] = c00 * di; F.Ri[1][0] = c01 * di; F.Ri[2][0] = c02 * di;
-   F.Ri[0][1] = (R[0][2] * R[2][1] - R[0][1] * R[2][2]) * di; F.Ri[1][1] = (R[0][0] * R[2][2] - R[0][2] * R[2][0]) * di; F.Ri[2][1] = (R[0][1] * R[2][0] - R[0][0] * R[2][1]) * di;
-   F.Ri[0][2] = (R[0][1] * R[1][2] - R[0][2] * R[1][1]) * di; F.Ri[1][2] = (R[0][2] * R[1][0] - R[0][0] * R[1][2]) * di; F.Ri[2][2] = (R[0][0] * R[1][1] - R[0][1] * R[1][0]) * di;
-#pragma unroll
-   for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 5; j++) F.Y[i][j] = (F.Ri[i][0] * J.B[0][j] + F.Ri[i][1] * J.B[1][j] + F.Ri[i][2] * J.B[2][j]) * kd[j];
-#pragma unroll
-   for (int i = 0; i < 5; i++)
-#pragma unroll
-      for (int j = 0; j < 5; j++)
-         F.LU[i][j] = (i == j ? pb.dt_ri : 0.0) + J.A[sidx(i, j)] * kd[j] + J.Mer[i][0] * F.Y[0][j] + J.Mer[i][1] * F.Y[1][j] + J.Mer[i][2] * F.Y[2][j];
-   bool ok = isfinite(di);
-#pragma unroll
-   for (int k = 0; k < 5; k++) {
-      const double piv = F.LU[k][k];
-      ok = ok && (piv > 0.0);
-      const double inv = 1.0 / piv;
-      F.LU[k][k] = inv;   // store the reciprocal pivot
-#pragma unroll
-      for (int i = k + 1; i < 5; i++) {
-         const double f = F.LU[i][k] * inv; F.LU[i][k] = f;
-#pragma unroll
-         for (int j = k + 1; j < 5; j++) F.LU[i][j] -= f * F.LU[k][j];
-      }
-   }
-   F.ok = ok;
+   F.Ri[0] = c00 * di; F.Ri[3] = c01 * di; F.Ri[6] = c02 * di;
+   F.Ri[1] = (R[0][2] * R[2][1] - R[0][1] * R[2][2]) * di; F.Ri[4] = (R[0][0] * R[2][2] - R[0][2] * R[2][0]) * di; F.Ri[7] = (R[0][1] * R[2][0] - R[0][0] * R[2][1]) * di;
+   F.Ri[2] = (R[0][1] * R[1][2] - R[0][2] * R[1][1]) * di; F.Ri[5] = (R[0][2] * R[1][0] - R[0][0] * R[1][2]) * di; F.Ri[8] = (R[0][0] * R[1][1] - R[0][1] * R[1][0]) * di;
+   F.ok = ok && isfinite(di);
 }
 
-// solve J dx = rhs  (rhs_r may be identically zero: pass ZERO_R = true)
-template <bool ZERO_R>
-ECM_DI void jac_solve(const Jac& J, const Fact& F, const double rhs[8], double dx[8]) {
-   double t[3] = { 0, 0, 0 }, b[5];
-   if (!ZERO_R) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) t[i] = F.Ri[i][0] * rhs[5] + F.Ri[i][1] * rhs[6] + F.Ri[i][2] * rhs[7];
-   }
-#pragma unroll
-   for (int i = 0; i < 5; i++) b[i] = rhs[i] + (ZERO_R ? 0.0 : (J.Mer[i][0] * t[0] + J.Mer[i][1] * t[1] + J.Mer[i][2] * t[2]));
+// b <- Jee^-1 b  using the in-place factor:  Jee = M Kd  =>  x = Kd^-1 M^-1 b
+ECM_DI void jee_solve(const MatParams& mp, const Jac& J, double b[5]) {
 #pragma unroll
    for (int k = 0; k < 5; k++)
 #pragma unroll
-      for (int i = k + 1; i < 5; i++) b[i] -= F.LU[i][k] * b[k];
+      for (int i = k + 1; i < 5; i++) b[i] -= J.A[sidx(k, i)] * b[k];
 #pragma unroll
-   for (int k = 4; k >= 0; k--) {
+   for (int k = 0; k < 5; k++) b[k] *= J.A[sidx(k, k)];
 #pragma unroll
-      for (int j = k + 1; j < 5; j++) b[k] -= F.LU[k][j] * b[j];
-      b[k] *= F.LU[k][k];
+   for (int k = 4; k >= 0; k--)
+#pragma unroll
+      for (int j = k + 1; j < 5; j++) b[k] -= J.A[sidx(k, j)] * b[j];
+   const double i0 = 1.0 / mp.kd0, i2 = 1.0 / mp.kd2;
+   b[0] *= i0; b[1] *= i0; b[2] *= i2; b[3] *= i2; b[4] *= i2;
+}
+
+// w <- M w from the factor (M = L D L^T)
+ECM_DI void m_mult_factored(const Jac& J, double w[5]) {
+#pragma unroll
+   for (int k = 0; k < 5; k++) {
+      double t = w[k];
+#pragma unroll
+      for (int j = k + 1; j < 5; j++) t += J.A[sidx(k, j)] * w[j];
+      w[k] = t / J.A[sidx(k, k)];
    }
 #pragma unroll
-   for (int i = 0; i < 5; i++) dx[i] = b[i];
+   for (int i = 4; i >= 0; i--) {
+      double t = w[i];
 #pragma unroll
-   for (int i = 0; i < 3; i++) {
-      double s = t[i];
-#pragma unroll
-      for (int j = 0; j < 5; j++) s -= F.Y[i][j] * b[j];
-      dx[5 + i] = s;
+      for (int k = 0; k < i; k++) t += J.A[sidx(k, i)] * w[k];
+      w[i] = t;
    }
+}
+
+ECM_DI void jre_mult(const MatParams& mp, const Jac& J, const double ve[5], double out[3]) {
+   const double kv[5] = { mp.kd0 * ve[0], mp.kd0 * ve[1], mp.kd2 * ve[2], mp.kd2 * ve[3], mp.kd2 * ve[4] };
+#pragma unroll
+   for (int i = 0; i < 3; i++) { double t = 0; for (int j = 0; j < 5; j++) t += J.B[i][j] * kv[j]; out[i] = t; }
+}
+
+// y = J v and y = J^T u with the FACTORED J: only needed when the Newton step leaves the trust region
+ECM_DI void jac_mult(const MatParams& mp, const Prob& pb, const Jac& J, const double v[8], double y[8]) {
+   double a[5] = { mp.kd0 * v[0], mp.kd0 * v[1], mp.kd2 * v[2], mp.kd2 * v[3], mp.kd2 * v[4] };
+   m_mult_factored(J, a);                       // Jee v = M (Kd v)
+   double b[5]; jer_mult(pb, v + 5, b);
+   double c[3]; jre_mult(mp, J, v, c);
+   double Wt[9]; wt_matrix(pb, Wt);
+#pragma unroll
+   for (int i = 0; i < 5; i++) y[i] = a[i] + b[i];
+#pragma unroll
+   for (int i = 0; i < 3; i++) y[5 + i] = c[i] + v[5 + i] * pb.dt_ri - (Wt[3 * i] * v[5] + Wt[3 * i + 1] * v[6] + Wt[3 * i + 2] * v[7]);
+}
+
+ECM_DI void jac_mult_T(const MatParams& mp, const Prob& pb, const Jac& J, const double u[8], double y[8]) {
+   double mu[5] = { u[0], u[1], u[2], u[3], u[4] };
+   m_mult_factored(J, mu);                      // Jee^T u = Kd (M u)
+   const double kd[5] = { mp.kd0, mp.kd0, mp.kd2, mp.kd2, mp.kd2 };
+#pragma unroll
+   for (int j = 0; j < 5; j++) y[j] = kd[j] * (mu[j] + J.B[0][j] * u[5] + J.B[1][j] * u[6] + J.B[2][j] * u[7]);
+   double c[3]; jer_mult_T(pb, u, c);
+   double Wt[9]; wt_matrix(pb, Wt);
+#pragma unroll
+   for (int j = 0; j < 3; j++) y[5 + j] = c[j] + u[5 + j] * pb.dt_ri - (Wt[j] * u[5] + Wt[3 + j] * u[6] + Wt[6 + j] * u[7]);
+}
+
+// solve J dx = rhs by block Gauss-Seidel on the exact diagonal-block inverses (rhs_r may be identically zero: ZERO_R)
+template <bool ZERO_R>
+ECM_DI void jac_solve(const MatParams& mp, const Prob& pb, const Jac& J, const Fact& F, const double rhs[8], double dx[8]) {
+   double xr[3] = { 0, 0, 0 };
+   if (!ZERO_R) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) xr[i] = F.Ri[3 * i] * rhs[5] + F.Ri[3 * i + 1] * rhs[6] + F.Ri[3 * i + 2] * rhs[7];
+   }
+   double xe[5];
+#pragma unroll 1
+   for (int sweep = 0; sweep < 3; sweep++) {
+      double t[5]; jer_mult(pb, xr, t);
+#pragma unroll
+      for (int i = 0; i < 5; i++) xe[i] = rhs[i] - t[i];
+      jee_solve(mp, J, xe);
+      double c[3]; jre_mult(mp, J, xe, c);
+      double br[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) br[i] = (ZERO_R ? 0.0 : rhs[5 + i]) - c[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) xr[i] = F.Ri[3 * i] * br[0] + F.Ri[3 * i + 1] * br[1] + F.Ri[3 * i + 2] * br[2];
+   }
+#pragma unroll
+   for (int i = 0; i < 5; i++) dx[i] = xe[i];
+#pragma unroll
+   for (int i = 0; i < 3; i++) dx[5 + i] = xr[i];
 }
 
 ECM_DI double norm8(const double v[8]) { double s = 0; for (int i = 0; i < 8; i++) s += v[i] * v[i]; return sqrt(s); }
@@ -444,107 +556,116 @@ ECM_DI double norm8(const double v[8]) { double s = 0; for (int i = 0; i < 8; i+
 // one quadrature point: reference kernel_setup -> getResponseECM -> kernel_postprocessing, fused
 //   vgrad  : velocity gradient L(i,j) = dv_i/dx_j as L[i + 3 j]
 //   sv0/s0 : begin-of-step state (28) / Voigt stress (6)
-//   sv1/s1 : end-of-step outputs;  cmat: 6x6 tangent d sigma / d eps (engineering shear), column-major
+//   sv1/s1 : end-of-step outputs;  cmat: 6x6 tangent d sigma / d eps (engineering shear), column-major (used as a parking
+//            area for cold values until it is written at the very end)
+//   st     : per-thread stash (LDS), ST_SLOTS slots of stride ECM_STASH_STRIDE
 // returns 0 on success, 1 if the local solve failed to converge
 // ------------------------------------------------------------------------------------------------------------
 template <int KIN>
 ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const double sv0[NSTATEV], const double s0[6],
-                        double sv1[NSTATEV], double s1[6], double cmat[36]) {
-   // ---- kernel_setup (reference src/mechanics_ecmech.cpp:42-99)
-   const double w_sm[3] = { 0.5 * (L[2 + 3 * 1] - L[1 + 3 * 2]), 0.5 * (L[0 + 3 * 2] - L[2 + 3 * 0]), 0.5 * (L[1 + 3 * 0] - L[0 + 3 * 1]) };
-   const double dkk = L[0] + L[4] + L[8];
-   const double d_mean = -(1.0 / 3.0) * dkk;
-   double d_sm[5];
-   sym_to_vecd(L[0] + d_mean, L[4] + d_mean, L[8] + d_mean, 0.5 * (L[1 + 3 * 0] + L[0 + 3 * 1]), 0.5 * (L[2 + 3 * 0] + L[0 + 3 * 2]),
-               0.5 * (L[2 + 3 * 1] + L[1 + 3 * 2]), d_sm);
-   double dnorm2 = 0; for (int i = 0; i < 5; i++) dnorm2 += d_sm[i] * d_sm[i];
-   const double dnorm = sqrt(dnorm2), dEff = SQR2B3 * dnorm;
-   const double vOld = sv0[IND_VOL], vNew = vOld * exp(dkk * dt), delv = vNew - vOld;
-   const double pOld = -(1.0 / 3.0) * (s0[0] + s0[1] + s0[2]);
-   double s_old[5]; sym_to_vecd(s0[0] + pOld, s0[1] + pOld, s0[2] + pOld, s0[5], s0[4], s0[3], s_old);
-   // ---- EOS ("updateSimple", EosModelConst<false>): p = K (1/v - 1) + Gamma e
-   double eNew = sv0[IND_EINT] - delv * pOld;
-   const double tK = mp.tK0 + eNew * mp.dtde;
-   const double bulkNew = mp.bulk * vNew + mp.gamma * pOld * vNew;
-   // ---- hardness to end of step with begin-of-step slip rates
-   double shrate_o = 0; for (int a = 0; a < NSLIP; a++) shrate_o += fabs(sv0[H_GDOT + a]);
-   const double h_u = kin_update_h<KIN>(mp, sv0[H_H], dt, shrate_o);
-   // ---- point problem set-up
-   Prob pb;
-   pb.dt_ri = 1.0 / dt; pb.detV_ri = 1.0 / vNew;
-   double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += sv0[H_Q + i] * sv0[H_Q + i]; const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = sv0[H_Q + i] * ni; }
+                        double sv1[NSTATEV], double s1[6], double cmat[36], double* st) {
+   double* cold = cmat;
+   Prob pb; pb.st = st;
+   pb.dt_ri = 1.0 / dt;
    {
+      // ---- kernel_setup (reference src/mechanics_ecmech.cpp:42-99)
+      const double w_sm[3] = { 0.5 * (L[2 + 3 * 1] - L[1 + 3 * 2]), 0.5 * (L[0 + 3 * 2] - L[2 + 3 * 0]), 0.5 * (L[1 + 3 * 0] - L[0 + 3 * 1]) };
+      const double dkk = L[0] + L[4] + L[8];
+      const double d_mean = -(1.0 / 3.0) * dkk;
+      double d_sm[5];
+      sym_to_vecd(L[0] + d_mean, L[4] + d_mean, L[8] + d_mean, 0.5 * (L[1 + 3 * 0] + L[0 + 3 * 1]), 0.5 * (L[2 + 3 * 0] + L[0 + 3 * 2]),
+                  0.5 * (L[2 + 3 * 1] + L[1 + 3 * 2]), d_sm);
+      double dnorm2 = 0; for (int i = 0; i < 5; i++) dnorm2 += d_sm[i] * d_sm[i];
+      const double dnorm = sqrt(dnorm2), dEff = SQR2B3 * dnorm;
+      const double vOld = sv0[IND_VOL], vNew = vOld * exp(dkk * dt), delv = vNew - vOld;
+      const double pOld = -(1.0 / 3.0) * (s0[0] + s0[1] + s0[2]);
+      double s_old[5]; sym_to_vecd(s0[0] + pOld, s0[1] + pOld, s0[2] + pOld, s0[5], s0[4], s0[3], s_old);
+      // ---- EOS ("updateSimple", EosModelConst<false>): p = K (1/v - 1) + Gamma e
+      const double eNew = sv0[IND_EINT] - delv * pOld;
+      const double tK = mp.tK0 + eNew * mp.dtde;
+      const double bulkNew = mp.bulk * vNew + mp.gamma * pOld * vNew;
+      // ---- hardness to end of step with begin-of-step slip rates
+      double shrate_o = 0; for (int a = 0; a < NSLIP; a++) shrate_o += fabs(sv0[H_GDOT + a]);
+      const double h_u = kin_update_h<KIN>(mp, sv0[H_H], dt, shrate_o);
+      // ---- point problem set-up
+      pb.detV_ri = 1.0 / vNew;
+      double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += sv0[H_Q + i] * sv0[H_Q + i]; const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = sv0[H_Q + i] * ni; }
       double Cn[9]; quat_to_mat(qn, Cn);
-      rot_vecd_T(Cn, d_sm, pb.d_n);
-      for (int i = 0; i < 3; i++) pb.w_n[i] = Cn[i] * w_sm[0] + Cn[3 + i] * w_sm[1] + Cn[6 + i] * w_sm[2];
+      double dn[5]; rot_vecd_T(Cn, d_sm, dn);
+      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = sv0[H_E + i]; cold[CD_DSM + i] = d_sm[i]; cold[CD_SOLD + i] = s_old[i]; }
+      for (int i = 0; i < 3; i++) ECM_ST(st, ST_WN + i) = Cn[i] * w_sm[0] + Cn[3 + i] * w_sm[1] + Cn[6 + i] * w_sm[2];
+      for (int i = 0; i < 4; i++) cold[CD_QN + i] = qn[i];
+      cold[CD_VOLD] = vOld; cold[CD_VNEW] = vNew; cold[CD_ENEW] = eNew; cold[CD_DEFF] = dEff; cold[CD_BULK] = bulkNew; cold[CD_HU] = h_u;
+      double adots_ref;
+      if (KIN == KIN_KMBALD) {
+         const double sq = sqrt(h_u);
+         pb.kv.g = mp.go + mp.s * sq; pb.kv.gam_w = mp.gam_wo / sq; pb.kv.gam_r = mp.gam_ro * sq * sq; pb.kv.c_e = (mp.c_1 / tK) * mp.mu_ref;
+         adots_ref = pb.kv.gam_w;
+      } else { pb.kv.g = h_u; pb.kv.gam_w = mp.gam_w; pb.kv.gam_r = 0; pb.kv.c_e = 0; adots_ref = mp.gam_w; }
+      if (dnorm < EPS_SQRT * adots_ref) { pb.sc_i = adots_ref; pb.sc = 1.0 / adots_ref; }
+      else { pb.sc = fmin(1.0 / dnorm, 1.0e6 * dt); pb.sc_i = 1.0 / pb.sc; }
+      pb.g_i = 1.0 / pb.kv.g;
    }
-   for (int i = 0; i < 5; i++) pb.e_n[i] = sv0[H_E + i];
-   double adots_ref;
-   if (KIN == KIN_KMBALD) {
-      const double sq = sqrt(h_u);
-      pb.kv.g = mp.go + mp.s * sq; pb.kv.gam_w = mp.gam_wo / sq; pb.kv.gam_r = mp.gam_ro * sq * sq; pb.kv.c_e = (mp.c_1 / tK) * mp.mu_ref;
-      adots_ref = pb.kv.gam_w;
-   } else { pb.kv.g = h_u; pb.kv.gam_w = mp.gam_w; pb.kv.gam_r = 0; pb.kv.c_e = 0; adots_ref = mp.gam_w; }
-   pb.sc = (dnorm < EPS_SQRT * adots_ref) ? 1.0 / adots_ref : fmin(1.0 / dnorm, 1.0e6 * dt);
+   ECM_PARK_BARRIER();
 
-   // ---- trust-region dog-leg Newton (SNLS "TrDlDenseG" defaults)
+   // ---- trust-region dog-leg Newton (SNLS "TrDlDenseG" defaults).  Every evaluation leaves (r, J, slip rates, dissipation) of
+   // the point it was asked for; a rejected trial is followed by a re-evaluation at the restored point (rare), so nothing but x
+   // and a few scalars has to survive an evaluation and the converged evaluation doubles as the one the tangent needs.
    double x[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-   double r[8], gdot[NSLIP], dis_rate;
+   double r[8], dis_rate, shrate;
    Jac J; Fact F;
+   double* gdot_out = sv1 + H_GDOT;
    int nfev = 1; bool conv = false;
-   bool ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot, dis_rate);
-   double res = norm8(r), res_0 = res;
-   if (ok && res < mp.tol) conv = true;
+   bool ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);
+   double res_0 = norm8(r);
+   if (ok && res_0 < mp.tol) conv = true;
    if (ok && !conv) {
-      const double cs[8] = { E_SCALE, E_SCALE, E_SCALE, E_SCALE, E_SCALE, R_SCALE, R_SCALE, R_SCALE };
       double delta = 1.0;
-      double nr[8], grad[8];
-      double nr2norm = 0, Jg_2 = 0, norm_grad = 0, norm2_grad = 0, norm_s_sd_opt = 0, res_cauchy = 0;
-      bool reject_prev = false;
       for (int it = 0; it < 200; it++) {
-         if (!reject_prev) {
-            // grad = Js^T r, Jg = Js grad, Newton step; only vectors and scalars survive the next evaluation
-            double t[8], u[8];
-            jac_mult_T(mp, pb, J, r, t);
-            for (int i = 0; i < 8; i++) { grad[i] = pb.sc * cs[i] * t[i]; u[i] = cs[i] * grad[i]; }
-            jac_mult(mp, pb, J, u, t);
-            Jg_2 = 0; norm2_grad = 0;
-            for (int i = 0; i < 8; i++) { const double jg = pb.sc * t[i]; Jg_2 += jg * jg; norm2_grad += grad[i] * grad[i]; }
-            norm_grad = sqrt(norm2_grad);
-            const double fac = (Jg_2 > 0) ? norm2_grad / Jg_2 : 0.0;
-            norm_s_sd_opt = (Jg_2 > 0) ? fac * norm_grad : 1e300;
-            // |r + Js sd|, sd = -fac grad  (needed for the dog-leg prediction)
-            { double s2 = 0; for (int i = 0; i < 8; i++) { const double v = r[i] - fac * pb.sc * t[i]; s2 += v * v; } res_cauchy = sqrt(s2); }
-            jac_factor(mp, pb, J, F);
-            if (F.ok) {
-               double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i] / pb.sc;
-               jac_solve<false>(J, F, rhs, t);
-               for (int i = 0; i < 8; i++) nr[i] = t[i] / cs[i];
-               nr2norm = norm8(nr);
-            } else { nr2norm = 1e300; for (int i = 0; i < 8; i++) nr[i] = 0; }
-         }
+         // Newton step first; the steepest-descent data (grad = Js^T r, Jg = Js grad) only when the step leaves the trust region
+         double nr[8], t[8];
+         jac_factor(mp, pb, J, F);
+         double nr2norm;
+         if (F.ok) {
+            double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i] * pb.sc_i;
+            jac_solve<false>(mp, pb, J, F, rhs, t);
+            for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? (1.0 / E_SCALE) : (1.0 / R_SCALE));
+            nr2norm = norm8(nr);
+         } else { nr2norm = 1e300; for (int i = 0; i < 8; i++) nr[i] = 0; }
          double delx[8], pred_resid; bool use_nr = false;
          if (nr2norm <= delta) { use_nr = true; for (int i = 0; i < 8; i++) delx[i] = nr[i]; pred_resid = 0.0; }
-         else if (norm_s_sd_opt >= delta) {
-            const double f = delta / norm_grad;
-            for (int i = 0; i < 8; i++) delx[i] = -grad[i] * f;
-            pred_resid = sqrt(fmax(res_0 * res_0 - 2.0 * delta * norm_grad + delta * delta * Jg_2 / norm2_grad, 0.0));
-         } else {
-            const double fac = norm2_grad / Jg_2;
-            double qa = 0, qb = 0;
-            for (int i = 0; i < 8; i++) { const double sd = -grad[i] * fac, p = nr[i] - sd; qa += p * p; qb += p * sd; }
-            const double qc = norm_s_sd_opt * norm_s_sd_opt - delta * delta;
-            const double beta = (-qb + sqrt(fmax(qb * qb - qa * qc, 0.0))) / qa;
-            for (int i = 0; i < 8; i++) { const double sd = -grad[i] * fac; delx[i] = sd + beta * (nr[i] - sd); }
-            pred_resid = (1.0 - beta) * res_cauchy;   // the Newton point zeroes the linear model
+         else {
+            double grad[8], u[8];
+            jac_mult_T(mp, pb, J, r, t);
+            for (int i = 0; i < 8; i++) { const double cs = (i < 5) ? E_SCALE : R_SCALE; grad[i] = pb.sc * cs * t[i]; u[i] = cs * grad[i]; }
+            jac_mult(mp, pb, J, u, t);
+            double Jg_2 = 0, norm2_grad = 0;
+            for (int i = 0; i < 8; i++) { const double jg = pb.sc * t[i]; Jg_2 += jg * jg; norm2_grad += grad[i] * grad[i]; }
+            const double norm_grad = sqrt(norm2_grad);
+            const double fac = (Jg_2 > 0) ? norm2_grad / Jg_2 : 0.0;
+            const double norm_s_sd_opt = (Jg_2 > 0) ? fac * norm_grad : 1e300;
+            if (norm_s_sd_opt >= delta) {
+               const double f = delta / norm_grad;
+               for (int i = 0; i < 8; i++) delx[i] = -grad[i] * f;
+               pred_resid = sqrt(fmax(res_0 * res_0 - 2.0 * delta * norm_grad + delta * delta * Jg_2 / norm2_grad, 0.0));
+            } else {
+               // |r + Js sd|, sd = -fac grad: the Newton point zeroes the linear model, so the dog-leg point predicts (1-beta) of it
+               double s2 = 0; for (int i = 0; i < 8; i++) { const double v = r[i] - fac * pb.sc * t[i]; s2 += v * v; }
+               double qa = 0, qb = 0;
+               for (int i = 0; i < 8; i++) { const double sd = -grad[i] * fac, p = nr[i] - sd; qa += p * p; qb += p * sd; }
+               const double qc = norm_s_sd_opt * norm_s_sd_opt - delta * delta;
+               const double beta = (-qb + sqrt(fmax(qb * qb - qa * qc, 0.0))) / qa;
+               for (int i = 0; i < 8; i++) { const double sd = -grad[i] * fac; delx[i] = sd + beta * (nr[i] - sd); }
+               pred_resid = (1.0 - beta) * sqrt(s2);
+            }
          }
-         for (int i = 0; i < 8; i++) x[i] += delx[i];
-         // evaluate straight into (r, J): after a rejection only nr/grad/scalars of the accepted point are needed
-         ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot, dis_rate); nfev++;
+         for (int i = 0; i < 8; i++) { ECM_ST(st, ST_XS + i) = x[i]; x[i] += delx[i]; }
+         ECM_PARK_BARRIER();
+         ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate); nfev++;
          bool reject;
          if (!ok) { reject = true; delta = fmax(delta * 0.25, 1e-12); }
          else {
-            res = norm8(r);
+            const double res = norm8(r);
             if (res < mp.tol) { conv = true; break; }
             const double actual = res - res_0, pred = pred_resid - res_0;
             if (pred == 0.0) delta = fmin(delta * 1.5, 1e4);
@@ -554,18 +675,23 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
                else if (rho < 0.35) delta = fmax(delta * 0.25, 1e-12);
             }
             reject = (actual > 0.0);
+            if (!reject) res_0 = res;
          }
-         if (reject) { for (int i = 0; i < 8; i++) x[i] -= delx[i]; res = res_0; reject_prev = true; if (delta <= 1e-12) break; }
-         else { res_0 = res; reject_prev = false; }
+         if (reject) {
+            for (int i = 0; i < 8; i++) x[i] = ECM_ST(st, ST_XS + i);
+            ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);   // restore (r, J) of the accepted point
+            if (!ok || delta <= 1e-12) break;
+         }
       }
    }
-   // ---- converged state, by-products and tangent at the solution
-   ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot, dis_rate);
+   // ---- converged state: stress, energy, history (getResponseSngl tail + reference kernel_postprocessing src/mechanics_ecmech.cpp:116-152)
    double e_f[5], xi[3];
-   for (int i = 0; i < 5; i++) e_f[i] = pb.e_n[i] + x[i] * E_SCALE;
+   for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(st, ST_EN + i) + x[i] * E_SCALE;
    for (int i = 0; i < 3; i++) xi[i] = x[5 + i] * R_SCALE;
-   double qf[4];
+   double Cf[9];
    {
+      const double qn[4] = { cold[CD_QN], cold[CD_QN + 1], cold[CD_QN + 2], cold[CD_QN + 3] };
+      double qf[4];
       const double th2 = xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2];
       double cq, sq;   // cos(th/2), sin(th/2)/th
       if (th2 < 1.0e-4) { const double h2 = 0.25 * th2; cq = 1.0 - 0.5 * h2 * (1.0 - h2 * (1.0 / 12.0) * (1.0 - h2 * (1.0 / 30.0))); sq = 0.5 * (1.0 - h2 * (1.0 / 6.0) * (1.0 - h2 * (1.0 / 20.0) * (1.0 - h2 * (1.0 / 42.0)))); }
@@ -575,73 +701,92 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       qf[1] = qn[0] * a[1] + qn[1] * a[0] + qn[2] * a[3] - qn[3] * a[2];
       qf[2] = qn[0] * a[2] - qn[1] * a[3] + qn[2] * a[0] + qn[3] * a[1];
       qf[3] = qn[0] * a[3] + qn[1] * a[2] - qn[2] * a[1] + qn[3] * a[0];
+      quat_to_mat(qf, Cf);
+      double dq = 0; for (int i = 0; i < 4; i++) dq += qf[i] * qn[i];
+      const double sg = dq < 0 ? -1.0 : 1.0;
+      for (int i = 0; i < 4; i++) sv1[H_Q + i] = sg * qf[i];
    }
-   double Cf[9]; quat_to_mat(qf, Cf);
    const double kdj[5] = { mp.kd0 * pb.detV_ri, mp.kd0 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri };
-   double s_lat[5], s_sm[5];
+   double s_lat[5];
    for (int i = 0; i < 5; i++) s_lat[i] = kdj[i] * e_f[i];
-   rot_vecd(Cf, s_lat, s_sm);
-   // ---- tangent: lattice-frame d sigma'/d D' by implicit differentiation, rotated to the sample frame, then to Voigt
+   const double bulkNew = cold[CD_BULK];
    {
-      jac_factor(mp, pb, J, F);
-      double A[9], Tr[9]; exp_map(xi, A, Tr);
-      double Ms[5][3]; m35(s_lat, Ms);
-      double Llat[5][5];
-#pragma unroll
-      for (int c = 0; c < 5; c++) {
-         double rhs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dx[8];
-         rhs[c] = 1.0;
-         jac_solve<true>(J, F, rhs, dx);
-         double dth[3];
-         for (int i = 0; i < 3; i++) dth[i] = Tr[3 * i] * dx[5] + Tr[3 * i + 1] * dx[6] + Tr[3 * i + 2] * dx[7];
-         for (int k = 0; k < 5; k++) Llat[k][c] = kdj[k] * dx[k] - (Ms[k][0] * dth[0] + Ms[k][1] * dth[1] + Ms[k][2] * dth[2]);
-      }
-      // D55 = Q5 Llat Q5^T : rotate columns then rows with vecd(C . C^T)
-      double T1[5][5];
-#pragma unroll
-      for (int c = 0; c < 5; c++) { double col[5], out[5]; for (int k = 0; k < 5; k++) col[k] = Llat[k][c]; rot_vecd(Cf, col, out); for (int k = 0; k < 5; k++) T1[k][c] = out[k]; }
-      double D55[5][5];
-#pragma unroll
-      for (int k = 0; k < 5; k++) { double row[5], out[5]; for (int c = 0; c < 5; c++) row[c] = T1[k][c]; rot_vecd(Cf, row, out); for (int c = 0; c < 5; c++) D55[k][c] = out[c]; }
-      // Voigt: sigma_svec = V65 sigma_vecd ; d_vecd = S56 eps_svec(eng. shear) / dt
-      const double dti = pb.dt_ri * (F.ok ? 1.0 : 0.0);
-      double T2[5][6];
-#pragma unroll
-      for (int k = 0; k < 5; k++) {
-         T2[k][0] = (SQR2I * D55[k][0] - SQR6I * D55[k][1]) * dti;
-         T2[k][1] = (-SQR2I * D55[k][0] - SQR6I * D55[k][1]) * dti;
-         T2[k][2] = (2.0 * SQR6I * D55[k][1]) * dti;
-         T2[k][3] = (SQR2I * D55[k][4]) * dti;
-         T2[k][4] = (SQR2I * D55[k][3]) * dti;
-         T2[k][5] = (SQR2I * D55[k][2]) * dti;
-      }
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-         const double t1 = SQR2I * T2[0][j], t2 = SQR6I * T2[1][j];
-         const double bk = (j < 3) ? bulkNew : 0.0;
-         // column-major C(i,j) at cmat[i + 6 j]
-         cmat[0 + 6 * j] = t1 - t2 + bk; cmat[1 + 6 * j] = -t1 - t2 + bk; cmat[2 + 6 * j] = SQR2B3 * T2[1][j] + bk;
-         cmat[3 + 6 * j] = SQR2I * T2[4][j]; cmat[4 + 6 * j] = SQR2I * T2[3][j]; cmat[5 + 6 * j] = SQR2I * T2[2][j];
-      }
-   }
-   // ---- energy, history, outputs (getResponseSngl tail + reference kernel_postprocessing src/mechanics_ecmech.cpp:116-152)
-   { double wrk = 0; for (int k = 0; k < 5; k++) wrk += (s_old[k] + s_sm[k]) * d_sm[k]; eNew += 0.25 * (vOld + vNew) * dt * wrk; }
-   double shrate = 0; for (int a = 0; a < NSLIP; a++) shrate += fabs(gdot[a]);
-   sv1[H_SHRATE] = shrate;
-   sv1[H_SHR] = sv0[H_SHR] + shrate * dt;
-   sv1[H_FLOW] = ((dEff > TINY_SQRT) ? dis_rate * dt : 0.0) + sv0[H_FLOW];   // accumulated plastic work
-   sv1[H_NFEV] = (double)nfev;
-   for (int i = 0; i < 5; i++) sv1[H_E + i] = e_f[i];
-   { double dq = 0; for (int i = 0; i < 4; i++) dq += qf[i] * qn[i]; const double sg = dq < 0 ? -1.0 : 1.0; for (int i = 0; i < 4; i++) sv1[H_Q + i] = sg * qf[i]; }
-   sv1[H_H] = h_u;
-   for (int a = 0; a < NSLIP; a++) sv1[H_GDOT + a] = gdot[a];
-   sv1[IND_VOL] = vNew; sv1[IND_EINT] = eNew;
-   const double pNew = mp.bulk * (1.0 / vNew - 1.0) + mp.gamma * eNew;
-   {
+      double s_sm[5]; rot_vecd(Cf, s_lat, s_sm);
+      const double vNew = cold[CD_VNEW];
+      double eNew = cold[CD_ENEW];
+      { double wrk = 0; for (int k = 0; k < 5; k++) wrk += (cold[CD_SOLD + k] + s_sm[k]) * cold[CD_DSM + k]; eNew += 0.25 * (cold[CD_VOLD] + vNew) * dt * wrk; }
+      sv1[H_SHRATE] = shrate;
+      sv1[H_SHR] = sv0[H_SHR] + shrate * dt;
+      sv1[H_FLOW] = ((cold[CD_DEFF] > TINY_SQRT) ? dis_rate * dt : 0.0) + sv0[H_FLOW];   // accumulated plastic work
+      sv1[H_NFEV] = (double)nfev;
+      for (int i = 0; i < 5; i++) sv1[H_E + i] = e_f[i];
+      sv1[H_H] = cold[CD_HU];
+      sv1[IND_VOL] = vNew; sv1[IND_EINT] = eNew;
+      const double pNew = mp.bulk * (1.0 / vNew - 1.0) + mp.gamma * eNew;
       const double t1 = SQR2I * s_sm[0], t2 = SQR6I * s_sm[1];
       s1[0] = t1 - t2 - pNew; s1[1] = -t1 - t2 - pNew; s1[2] = SQR2B3 * s_sm[1] - pNew;
       s1[3] = SQR2I * s_sm[4]; s1[4] = SQR2I * s_sm[3]; s1[5] = SQR2I * s_sm[2];
    }
+#ifndef ECM_NO_TANGENT
+   // ---- tangent (last: it overwrites the parking area): lattice-frame d sigma'/d D' by implicit differentiation on the converged
+   // factorisation, rotated to the sample frame, then to Voigt (engineering shear) + bulk term, column-major
+   {
+      jac_factor(mp, pb, J, F);
+      double Llat[5][5];
+      {
+         double Tr[9]; load_tr(pb, Tr);
+         double Ms[5][3]; m35(s_lat, Ms);
+#pragma unroll
+         for (int c = 0; c < 5; c++) {
+            double rhs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dx[8];
+            rhs[c] = 1.0;
+            jac_solve<true>(mp, pb, J, F, rhs, dx);
+            double dth[3];
+            for (int i = 0; i < 3; i++) dth[i] = Tr[3 * i] * dx[5] + Tr[3 * i + 1] * dx[6] + Tr[3 * i + 2] * dx[7];
+            for (int k = 0; k < 5; k++) Llat[k][c] = kdj[k] * dx[k] - (Ms[k][0] * dth[0] + Ms[k][1] * dth[1] + Ms[k][2] * dth[2]);
+         }
+      }
+      // D55 = Q5 Llat Q5^T with the explicit 5x5 rotation of deviatoric 5-vectors (columns = images of the unit vectors)
+      double Q5[5][5];
+#pragma unroll
+      for (int l = 0; l < 5; l++) {
+         double e[5] = { 0, 0, 0, 0, 0 }, out[5]; e[l] = 1.0;
+         rot_vecd(Cf, e, out);
+#pragma unroll
+         for (int k = 0; k < 5; k++) Q5[k][l] = out[k];
+      }
+      double T1[5][5];
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+#pragma unroll
+         for (int c = 0; c < 5; c++) { double v = 0; for (int l = 0; l < 5; l++) v += Q5[k][l] * Llat[l][c]; T1[k][c] = v; }
+      const double dti = pb.dt_ri * (F.ok ? 1.0 : 0.0);
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+         double D[5];   // row k of D55 = T1 Q5^T
+#pragma unroll
+         for (int c = 0; c < 5; c++) { double v = 0; for (int l = 0; l < 5; l++) v += T1[k][l] * Q5[c][l]; D[c] = v; }
+         // row k of T2 = D55 S56 / dt  (d_vecd = S56 eps_svec(eng. shear) / dt), overwriting T1's row
+         T1[k][0] = (SQR2I * D[0] - SQR6I * D[1]) * dti;
+         T1[k][1] = (-SQR2I * D[0] - SQR6I * D[1]) * dti;
+         T1[k][2] = (2.0 * SQR6I * D[1]) * dti;
+         T1[k][3] = (SQR2I * D[4]) * dti;
+         T1[k][4] = (SQR2I * D[3]) * dti;
+         Llat[k][0] = (SQR2I * D[2]) * dti;   // sixth column parked in Llat's first column
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+         double T2[5];
+#pragma unroll
+         for (int k = 0; k < 5; k++) T2[k] = (j < 5) ? T1[k][j] : Llat[k][0];
+         const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
+         const double bk = (j < 3) ? bulkNew : 0.0;
+         // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[i + 6 j]
+         cmat[0 + 6 * j] = t1 - t2 + bk; cmat[1 + 6 * j] = -t1 - t2 + bk; cmat[2 + 6 * j] = SQR2B3 * T2[1] + bk;
+         cmat[3 + 6 * j] = SQR2I * T2[4]; cmat[4 + 6 * j] = SQR2I * T2[3]; cmat[5 + 6 * j] = SQR2I * T2[2];
+      }
+   }
+#endif
    return (conv && ok) ? 0 : 1;
 }
 

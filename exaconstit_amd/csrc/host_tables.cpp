@@ -130,6 +130,7 @@ bool exa_fill_mat_params(const exa_config& cfg, ecmdev::MatParams& mp, double* h
       xm = 1.0 / (2.0 * ((mp.c_1 / tK_ref) * mp.mu_ref * mp.p * mp.q));
    }
    mp.xnn = 1.0 / xm; mp.xn = mp.xnn - 1.0;
+   mp.xn_int = (mp.xn == std::floor(mp.xn) && mp.xn >= 1.0 && mp.xn <= 255.0) ? (int)mp.xn : 0;
    mp.t_min = std::pow(1.0e-60, xm); mp.t_max = std::pow(1.0e45, xm);
    mp.gamma = p[i++]; const double ecold = p[i++];
    mp.dtde = 1.0 / cvav; mp.tK0 = -ecold * mp.dtde;

@@ -8,8 +8,12 @@
 
 using namespace ecmdev;
 
+#ifndef EXA_MODEL_OCC
+#define EXA_MODEL_OCC 2   // waves per SIMD the register allocator is asked to fit (tuned on MI355X)
+#endif
+
 template <int KIN>
-__global__ __launch_bounds__(256) void k_model_setup(const MatParams mp, const int Q, const int n, const int64_t P, const double dt,
+__global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatParams mp, const int Q, const int n, const int64_t P, const double dt,
                                                      const double* __restrict__ J, const double* __restrict__ G,
                                                      const double* __restrict__ vel, const double* __restrict__ stress0,
                                                      const double* __restrict__ state0, double* __restrict__ stress1,
@@ -44,7 +48,9 @@ __global__ __launch_bounds__(256) void k_model_setup(const MatParams mp, const i
       L[3] += v0 * b1; L[4] += v1 * b1; L[5] += v2 * b1;
       L[6] += v0 * b2; L[7] += v1 * b2; L[8] += v2 * b2;
    }
-   const int rc = point_update<KIN>(mp, dt, L, state0 + NSTATEV * ip, stress0 + 6 * ip, state1 + NSTATEV * ip, stress1 + 6 * ip, cmat + 36 * ip);
+   // per-thread stash behind the shape table in LDS: slot s of this thread at stash[s * 256 + threadIdx.x]
+   double* st = sG + n * 3 * Q + threadIdx.x;
+   const int rc = point_update<KIN>(mp, dt, L, state0 + NSTATEV * ip, stress0 + 6 * ip, state1 + NSTATEV * ip, stress1 + 6 * ip, cmat + 36 * ip, st);
    if (rc) atomicAdd(fail, 1);
 }
 
@@ -83,7 +89,8 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, const double* J, const doubl
                            double* stress1, double* state1, double* cmat, hipStream_t s) {
    const int bs = 256;
    const int64_t nb = (ctx->P + bs - 1) / bs;
-   const size_t lds = sizeof(double) * ctx->n * 3 * ctx->Q;
+   const size_t lds = sizeof(double) * ((size_t)ctx->n * 3 * ctx->Q + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE);
+   static_assert(ECM_STASH_STRIDE == 256, "stash stride must equal the block size");
    EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->fail_count_dev, 0, sizeof(int), s));
    switch (ctx->mp.kin) {
       case KIN_VOCE:
