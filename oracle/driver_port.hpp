@@ -38,6 +38,7 @@ struct Config {
    std::vector<double> dts;            // one per step
    std::vector<BCSet> bcs;
    int assembly = ASM_PA, nl_solver = NL_NR, precond = PC_IDENTITY;
+   int integ = 0;                      // 0 full integration, 1 B-bar (ICExaNLFIntegrator; element assembly only, README.md:20)
    double newton_rel = 5e-5, newton_abs = 5e-10; int newton_iter = 25;
    double krylov_rel = 1e-7, krylov_abs = 1e-27; int krylov_iter = 1000;
    bool additional_avgs = false;
@@ -62,7 +63,7 @@ struct Sim {
    std::vector<double> x_ref, x_beg, x_cur, v_sol;
    std::vector<double> stress0, stress1, state0, state1, matgrad, J;
    std::vector<char> ess; std::vector<double> ess_val;
-   std::vector<double> dmat, C4, D4, emat, diag, dinv;
+   std::vector<double> dmat, C4, D4, emat, diag, dinv, eDS;
    double dt = 0;
    Result* res = nullptr;
    fem::ModelOpts mo;
@@ -136,10 +137,16 @@ inline void op_setup(Sim& s, const std::vector<double>& v, bool upd_crds) {
 }
 
 inline void residual_action(Sim& s, std::vector<double>& y) {   // Hform->Setup(); Hform->Mult
-   s.dmat.resize(9 * s.P);
-   fem::assemble_pa(s.Q, s.E, s.re.W.data(), s.J.data(), s.stress1.data(), s.dmat.data());
    std::vector<double> ye((size_t)3 * s.n * s.E, 0.0);
-   fem::add_mult_pa(s.Q, s.E, s.n, s.re.G.data(), s.dmat.data(), ye.data());
+   if (s.cfg.integ == 1) {
+      s.eDS.resize((size_t)3 * s.n * s.E);
+      fem::element_eds(s.Q, s.E, s.n, s.re.W.data(), s.re.G.data(), s.J.data(), s.eDS.data());
+      fem::add_mult_pa_bbar(s.Q, s.E, s.n, s.re.W.data(), s.re.G.data(), s.J.data(), s.eDS.data(), s.stress1.data(), ye.data());
+   } else {
+      s.dmat.resize(9 * s.P);
+      fem::assemble_pa(s.Q, s.E, s.re.W.data(), s.J.data(), s.stress1.data(), s.dmat.data());
+      fem::add_mult_pa(s.Q, s.E, s.n, s.re.G.data(), s.dmat.data(), ye.data());
+   }
    std::fill(y.begin(), y.end(), 0.0);
    fem::restrict_EtoL_add(s.mesh, ye.data(), y.data());
    for (int i = 0; i < s.ND; i++) if (s.ess[i]) y[i] = 0.0;
@@ -156,6 +163,11 @@ inline void grad_setup(Sim& s) {   // Hform->GetGradient + AssembleDiagonal
       fem::assemble_grad_diag_pa(s.Q, s.E, s.n, s.dt, s.re.W.data(), s.re.G.data(), s.J.data(), s.matgrad.data(), de.data());
    } else {
       s.emat.resize((size_t)9 * s.n * s.n * s.E);
+      if (s.cfg.integ == 1) {
+         s.eDS.resize((size_t)3 * s.n * s.E);
+         fem::element_eds(s.Q, s.E, s.n, s.re.W.data(), s.re.G.data(), s.J.data(), s.eDS.data());
+         fem::assemble_ea_bbar(s.Q, s.E, s.n, s.dt, s.re.W.data(), s.re.G.data(), s.J.data(), s.eDS.data(), s.matgrad.data(), s.emat.data());
+      } else
       fem::assemble_ea(s.Q, s.E, s.n, s.dt, s.re.W.data(), s.re.G.data(), s.J.data(), s.matgrad.data(), s.emat.data());
       fem::ea_diag(s.E, s.n, s.emat.data(), de.data());
    }

@@ -428,6 +428,102 @@ inline void element_vector(int Q, int E, int n, const double* W, const double* G
    }
 }
 
+// ---------------------------------------------------------------------------------------------
+// B-bar (Hughes) integrator: ICExaNLFIntegrator                        mechanics_integrators.hpp:78-124
+// ---------------------------------------------------------------------------------------------
+// element-average shape gradient eDS(a,t,e) = sum_q W G adj(J) / sum_q W detJ      mechanics_integrators.cpp:1895-1953
+inline void element_eds(int Q, int E, int n, const double* W, const double* G, const double* J, double* eDS /*(n,3,E)*/) {
+   for (int e = 0; e < E; e++) {
+      double vol = 0;
+      double* ed = &eDS[(size_t)3 * n * e];
+      for (int i = 0; i < 3 * n; i++) ed[i] = 0.0;
+      for (int q = 0; q < Q; q++) {
+         const double* Jq = &J[9 * (q + (size_t)Q * e)];
+         double adj[9]; adjugate3(Jq, adj);
+         vol += W[q] * det3(Jq);
+         for (int a = 0; a < n; a++) for (int t = 0; t < 3; t++) {
+            double s = 0; for (int j = 0; j < 3; j++) s += G[a + n * (j + 3 * q)] * adj[3 * j + t];
+            ed[a + n * t] += W[q] * s;
+         }
+      }
+      for (int i = 0; i < 3 * n; i++) ed[i] /= vol;
+   }
+}
+
+// B-bar^T rows of node a: physical gradient g, element-average gradient ge           mechanics_model.cpp:845-877
+inline void bbar_rows(const double* g, const double* ge, double Bt[3][6]) {
+   b_rows(g, Bt);
+   for (int c = 0; c < 3; c++) { const double v = (ge[c] - g[c]) / 3.0; for (int k = 0; k < 3; k++) Bt[c][k] += v; }
+}
+
+// PA residual with B-bar, written as the reference writes it (b4..b9)                mechanics_integrators.cpp:2011-2086
+inline void add_mult_pa_bbar(int Q, int E, int n, const double* W, const double* G, const double* J, const double* eDS, const double* S, double* Y) {
+   const double i3 = 1.0 / 3.0;
+   for (int e = 0; e < E; e++) for (int q = 0; q < Q; q++) {
+      const size_t ip = q + (size_t)Q * e;
+      const double* Jq = &J[9 * ip];
+      const double detJ = det3(Jq), idetJ = 1.0 / detJ, c_detJ = detJ * W[q];
+      double adj[9]; adjugate3(Jq, adj);
+      const double* s = &S[6 * ip];
+      for (int a = 0; a < n; a++) {
+         double b[3];
+         for (int t = 0; t < 3; t++) { double v = 0; for (int j = 0; j < 3; j++) v += G[a + n * (j + 3 * q)] * adj[3 * j + t]; b[t] = idetJ * v; }
+         const double b4 = i3 * (eDS[a + n * (0 + 3 * e)] - b[0]), b5 = b4 + b[0];
+         const double b6 = i3 * (eDS[a + n * (1 + 3 * e)] - b[1]), b7 = b6 + b[1];
+         const double b8 = i3 * (eDS[a + n * (2 + 3 * e)] - b[2]), b9 = b8 + b[2];
+         Y[a + n * (0 + 3 * e)] += c_detJ * (b4 * s[1] + b4 * s[2] + b5 * s[0] + b[1] * s[5] + b[2] * s[4]);
+         Y[a + n * (1 + 3 * e)] += c_detJ * (b6 * s[0] + b6 * s[2] + b7 * s[1] + b[0] * s[5] + b[2] * s[3]);
+         Y[a + n * (2 + 3 * e)] += c_detJ * (b8 * s[0] + b8 * s[1] + b9 * s[2] + b[0] * s[4] + b[1] * s[3]);
+      }
+   }
+}
+
+// element matrices / dense residual with B-bar rows (ICExaNLFIntegrator::AssembleEA, AssembleElementVector)
+//                                                                                     mechanics_integrators.cpp:1021-1187,1195-1604
+inline void assemble_ea_bbar(int Q, int E, int n, double dt, const double* W, const double* G, const double* J, const double* eDS, const double* K, double* emat) {
+   const int nd = 3 * n;
+   std::vector<double> Bt((size_t)nd * 6);
+   for (int e = 0; e < E; e++) {
+      double* M = &emat[(size_t)nd * nd * e];
+      for (int i = 0; i < nd * nd; i++) M[i] = 0.0;
+      for (int q = 0; q < Q; q++) {
+         const size_t ip = q + (size_t)Q * e;
+         const double* Jq = &J[9 * ip];
+         const double detJ = det3(Jq);
+         double adj[9]; adjugate3(Jq, adj);
+         const double wt = dt * W[q] * detJ;
+         const double* Kq = &K[36 * ip];
+         for (int a = 0; a < n; a++) {
+            double g[3], ge[3];
+            for (int t = 0; t < 3; t++) { double s = 0; for (int j = 0; j < 3; j++) s += G[a + n * (j + 3 * q)] * adj[3 * j + t] / detJ; g[t] = s; ge[t] = eDS[a + n * (t + 3 * e)]; }
+            double b[3][6]; bbar_rows(g, ge, b);
+            for (int c = 0; c < 3; c++) for (int v = 0; v < 6; v++) Bt[(a + n * c) * 6 + v] = b[c][v];
+         }
+         for (int cj = 0; cj < nd; cj++) {
+            double CB[6];
+            for (int u = 0; u < 6; u++) { double s = 0; for (int v = 0; v < 6; v++) s += Kq[u + 6 * v] * Bt[cj * 6 + v]; CB[u] = s; }
+            for (int ri = 0; ri < nd; ri++) { double s = 0; for (int u = 0; u < 6; u++) s += Bt[ri * 6 + u] * CB[u]; M[ri + nd * cj] += wt * s; }
+         }
+      }
+   }
+}
+
+inline void element_vector_bbar(int Q, int E, int n, const double* W, const double* G, const double* J, const double* eDS, const double* stress1, double* Y) {
+   for (int e = 0; e < E; e++) for (int q = 0; q < Q; q++) {
+      const size_t ip = q + (size_t)Q * e;
+      const double* Jq = &J[9 * ip];
+      const double detJ = det3(Jq);
+      double adj[9]; adjugate3(Jq, adj);
+      const double* S = &stress1[6 * ip];
+      for (int a = 0; a < n; a++) {
+         double g[3], ge[3];
+         for (int t = 0; t < 3; t++) { double s = 0; for (int j = 0; j < 3; j++) s += G[a + n * (j + 3 * q)] * adj[3 * j + t] / detJ; g[t] = s; ge[t] = eDS[a + n * (t + 3 * e)]; }
+         double b[3][6]; bbar_rows(g, ge, b);
+         for (int c = 0; c < 3; c++) { double s = 0; for (int v = 0; v < 6; v++) s += b[c][v] * S[v]; Y[a + n * (c + 3 * e)] += s * detJ * W[q]; }
+      }
+   }
+}
+
 // volume average: sum_q W detJ val / sum_q W detJ                        mechanics_kernels.hpp:19-134
 inline void vol_avg(int Q, int E, int vdim, const double* W, const double* J, const double* qf, double* out, bool normalise) {
    std::vector<double> acc(vdim, 0.0); double vol = 0;

@@ -11,7 +11,7 @@ struct orc_case {
    int ngrains; const int* elem_grain; const double* quats;
    int nsteps; const double* dts;
    int nbc; const int* bc_step; const int* bc_nids; const int* bc_ids; const int* bc_comps; const double* bc_vals;   // flattened
-   int assembly, nl_solver, precond;
+   int assembly, nl_solver, precond, integ;
    double newton_rel, newton_abs; int newton_iter;
    double krylov_rel, krylov_abs; int krylov_iter;
    int additional_avgs, second_order_terms, use_input_temperature, verbose;
@@ -41,7 +41,7 @@ int orc_run_case(const orc_case* c, orc_result* r) {
       off += c->bc_nids[b];
       cfg.bcs.push_back(bc);
    }
-   cfg.assembly = c->assembly; cfg.nl_solver = c->nl_solver; cfg.precond = c->precond;
+   cfg.assembly = c->assembly; cfg.nl_solver = c->nl_solver; cfg.precond = c->precond; cfg.integ = c->integ;
    cfg.newton_rel = c->newton_rel; cfg.newton_abs = c->newton_abs; cfg.newton_iter = c->newton_iter;
    cfg.krylov_rel = c->krylov_rel; cfg.krylov_abs = c->krylov_abs; cfg.krylov_iter = c->krylov_iter;
    cfg.additional_avgs = c->additional_avgs != 0; cfg.second_order_terms = c->second_order_terms != 0;
@@ -117,6 +117,10 @@ void orc_assemble_ea(int Q, int E, int n, double dt, const double* W, const doub
 void orc_ea_mult(int E, int n, const double* emat, const double* X, double* Y) { fem::ea_mult(E, n, emat, X, Y); }
 void orc_ea_diag(int E, int n, const double* emat, double* Y) { fem::ea_diag(E, n, emat, Y); }
 void orc_element_vector(int Q, int E, int n, const double* W, const double* G, const double* J, const double* stress1, double* Y) { fem::element_vector(Q, E, n, W, G, J, stress1, Y); }
+void orc_element_eds(int Q, int E, int n, const double* W, const double* G, const double* J, double* eDS) { fem::element_eds(Q, E, n, W, G, J, eDS); }
+void orc_add_mult_pa_bbar(int Q, int E, int n, const double* W, const double* G, const double* J, const double* eDS, const double* S, double* Y) { fem::add_mult_pa_bbar(Q, E, n, W, G, J, eDS, S, Y); }
+void orc_assemble_ea_bbar(int Q, int E, int n, double dt, const double* W, const double* G, const double* J, const double* eDS, const double* K, double* emat) { fem::assemble_ea_bbar(Q, E, n, dt, W, G, J, eDS, K, emat); }
+void orc_element_vector_bbar(int Q, int E, int n, const double* W, const double* G, const double* J, const double* eDS, const double* s, double* Y) { fem::element_vector_bbar(Q, E, n, W, G, J, eDS, s, Y); }
 void orc_vol_avg(int Q, int E, int vdim, const double* W, const double* J, const double* qf, double* out, int normalise) { fem::vol_avg(Q, E, vdim, W, J, qf, out, normalise != 0); }
 void orc_calc_dp_mat(int xtal, int64_t P, int nstatev, const double* state1, double* dp) {
    ecm::Model mdl; std::memset(&mdl, 0, sizeof(mdl)); mdl.xtal = xtal; ecm::slip_geom_init(mdl);

@@ -55,7 +55,7 @@ class OrcCase(C.Structure):
                 ("ngrains", C.c_int), ("elem_grain", ip), ("quats", dp),
                 ("nsteps", C.c_int), ("dts", dp),
                 ("nbc", C.c_int), ("bc_step", ip), ("bc_nids", ip), ("bc_ids", ip), ("bc_comps", ip), ("bc_vals", dp),
-                ("assembly", C.c_int), ("nl_solver", C.c_int), ("precond", C.c_int),
+                ("assembly", C.c_int), ("nl_solver", C.c_int), ("precond", C.c_int), ("integ", C.c_int),
                 ("newton_rel", C.c_double), ("newton_abs", C.c_double), ("newton_iter", C.c_int),
                 ("krylov_rel", C.c_double), ("krylov_abs", C.c_double), ("krylov_iter", C.c_int),
                 ("additional_avgs", C.c_int), ("second_order_terms", C.c_int), ("use_input_temperature", C.c_int),
@@ -121,6 +121,7 @@ def load_case(toml_name, datadir=REFDATA):
         newton_rel=sol["NR"]["rel_tol"], newton_abs=sol["NR"]["abs_tol"], newton_iter=sol["NR"]["iter"],
         krylov_rel=sol["Krylov"]["rel_tol"], krylov_abs=sol["Krylov"]["abs_tol"], krylov_iter=sol["Krylov"]["iter"],
         additional_avgs=bool(vis.get("additional_avgs", False)),
+        integ=1 if sol.get("integ_model", "FULL").lower() == "bbar" else 0,
     )
 
 
@@ -143,7 +144,7 @@ def run_case(case, nsteps=None, precond=0, second_order_terms=False, use_input_t
                 case["xtal"], case["kin"], len(props), _p(props), case["temp_k"],
                 quats.shape[0], _ip(eg), _p(quats), ns, _p(dts),
                 len(bc_step), _ip(bc_step), _ip(bc_nids), _ip(bc_ids), _ip(bc_comps), _p(bc_vals),
-                case["assembly"], case["nl_solver"], precond,
+                case["assembly"], case["nl_solver"], precond, int(case.get("integ", 0)),
                 case["newton_rel"], case["newton_abs"], case["newton_iter"],
                 case["krylov_rel"], case["krylov_abs"], case["krylov_iter"],
                 int(case["additional_avgs"]), int(second_order_terms), int(use_input_temperature), verbose)
