@@ -21,6 +21,14 @@ int exa_launch_ea_export_p1(exa_ctx*, double*, hipStream_t);
 int exa_launch_restrict(exa_ctx*, const double*, double*, hipStream_t);
 int exa_launch_restrict_T(exa_ctx*, const double*, double*, hipStream_t);
 int exa_launch_vol_avg(exa_ctx*, const double*, const double*, int, double*, int, hipStream_t);
+int exa_launch_eds(exa_ctx*, const double*, hipStream_t);
+int exa_launch_residual_bbar(exa_ctx*, const double*, const double*, double*, hipStream_t);
+int exa_launch_assemble_ea_gen(exa_ctx*, hipStream_t);
+int exa_launch_ea_apply_gen(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t);
+int exa_launch_ea_diag_gen(exa_ctx*, double*, hipStream_t);
+int exa_launch_ea_export_gen(exa_ctx*, double*, hipStream_t);
+int exa_launch_pa_apply_gen(exa_ctx*, const double*, double*, hipStream_t);
+int exa_launch_pa_diag_gen(exa_ctx*, double*, hipStream_t);
 
 namespace {
 constexpr int VOL_AVG_BLOCKS = 512;
@@ -36,7 +44,9 @@ exa_ctx* exa_create(const exa_config* cfg, int* err) {
    exa_ctx* ctx = new exa_ctx();
    ctx->cfg = *cfg; ctx->cfg.props = nullptr;
    if (!exa_fill_mat_params(*cfg, ctx->mp, ctx->hist_init, ctx->err)) { std::fprintf(stderr, "exa_create: %s\n", ctx->err.c_str()); delete ctx; set(EXA_ERR_ARG); return nullptr; }
-   if (cfg->integ != EXA_INTEG_FULL) { std::fprintf(stderr, "exa_create: B-bar integration is not built yet\n"); delete ctx; set(EXA_ERR_UNSUPPORTED); return nullptr; }
+   if (cfg->integ != EXA_INTEG_FULL && cfg->integ != EXA_INTEG_BBAR) { delete ctx; set(EXA_ERR_ARG); return nullptr; }
+   // the reference has no partial-assembly gradient for B-bar (README.md:20; ICExaNLFIntegrator does not override AddMultGradPA)
+   if (cfg->integ == EXA_INTEG_BBAR && cfg->assembly != EXA_ASSEMBLY_EA) { std::fprintf(stderr, "exa_create: integ_model BBAR requires element (or full) assembly\n"); delete ctx; set(EXA_ERR_UNSUPPORTED); return nullptr; }
    ctx->p = cfg->order; const int np = ctx->p + 1; ctx->n = np * np * np; ctx->Q = ctx->n; ctx->E = cfg->nelems; ctx->P = (int64_t)ctx->E * ctx->Q;
    ctx->nstatev = ecmdev::NSTATEV;
    if (cfg->device >= 0) { if (hipSetDevice(cfg->device) != hipSuccess) { delete ctx; set(EXA_ERR_HIP); return nullptr; } }
@@ -61,7 +71,7 @@ exa_ctx* exa_create(const exa_config* cfg, int* err) {
 void exa_destroy(exa_ctx* ctx) {
    if (!ctx) return;
    (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->scratch_dev);
-   (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat);
+   (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->tbuf);
    delete ctx;
 }
 
@@ -116,27 +126,43 @@ int exa_grad_calc(exa_ctx* ctx, const double* J, const double* fe, double* out, 
 
 int exa_residual_setup(exa_ctx* ctx, const double* J, const double* stress1, exa_stream s) {
    if (!ctx || !J || !stress1) return fail(ctx, EXA_ERR_ARG, "exa_residual_setup: null pointer");
-   if (!ctx->dmat) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->dmat, sizeof(double) * 9 * ctx->P));
    ctx->have_resid = true;
+   if (ctx->cfg.integ == EXA_INTEG_BBAR) {      // ICExaNLFIntegrator::AssemblePA: element-average gradient; J and sigma are read by AddMultPA
+      if (!ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * ctx->E));
+      ctx->resid_J = J; ctx->resid_S = stress1;
+      return exa_launch_eds(ctx, J, S(s));
+   }
+   if (!ctx->dmat) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->dmat, sizeof(double) * 9 * ctx->P));
    return exa_launch_residual_setup(ctx, J, stress1, S(s));
 }
 
 int exa_residual_apply(exa_ctx* ctx, double* y, exa_stream s) {
    if (!ctx || !y) return fail(ctx, EXA_ERR_ARG, "exa_residual_apply: null pointer");
    if (!ctx->have_resid) return fail(ctx, EXA_ERR_STATE, "exa_residual_apply called before exa_residual_setup");
+   if (ctx->cfg.integ == EXA_INTEG_BBAR) return exa_launch_residual_bbar(ctx, ctx->resid_J, ctx->resid_S, y, S(s));
    return exa_launch_residual_apply(ctx, y, S(s));
 }
 
 int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, exa_stream s) {
    if (!ctx || !J || !C) return fail(ctx, EXA_ERR_ARG, "exa_grad_setup: null pointer");
-   if (ctx->p != 1) return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_grad_setup: only p = 1 is built in this round");
    if (!ctx->pa) { EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa, pa_bytes(ctx->E, ctx->Q))); EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa, 0, pa_bytes(ctx->E, ctx->Q), S(s))); }
    int rc = exa_launch_grad_setup_pa(ctx, dt, J, C, S(s));
    if (rc) return rc;
+   const size_t nblocks = (size_t)((ctx->E + PA_BLK - 1) / PA_BLK);
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
-      const size_t bytes = (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * 576 * PA_BLK * sizeof(double);
+      const bool bbar = ctx->cfg.integ == EXA_INTEG_BBAR;
+      ctx->ea_generic = bbar || ctx->p != 1;
+      const size_t nd = 3 * (size_t)ctx->n;
+      const size_t bytes = nblocks * nd * nd * PA_BLK * sizeof(double);
       if (!ctx->emat) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->emat, bytes));
-      rc = exa_launch_assemble_ea_p1(ctx, S(s));
+      if (bbar) {
+         if (!ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * ctx->E));
+         rc = exa_launch_eds(ctx, J, S(s));
+         if (rc) return rc;
+      }
+      rc = ctx->ea_generic ? exa_launch_assemble_ea_gen(ctx, S(s)) : exa_launch_assemble_ea_p1(ctx, S(s));
+   } else if (ctx->p != 1) {
+      if (!ctx->tbuf) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tbuf, sizeof(double) * 9 * ctx->P));
    }
    ctx->have_grad = (rc == EXA_OK);
    return rc;
@@ -145,21 +171,24 @@ int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, ex
 int exa_grad_apply(exa_ctx* ctx, const double* x, double* y, exa_stream s) {
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply: null pointer");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply called before exa_grad_setup");
-   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_apply_p1(ctx, x, y, false, nullptr, nullptr, S(s));
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA)
+      return ctx->ea_generic ? exa_launch_ea_apply_gen(ctx, x, y, false, nullptr, nullptr, S(s)) : exa_launch_ea_apply_p1(ctx, x, y, false, nullptr, nullptr, S(s));
+   if (ctx->p != 1) return exa_launch_pa_apply_gen(ctx, x, y, S(s));
    return exa_launch_grad_apply_p1(ctx, x, y, false, nullptr, nullptr, S(s));
 }
 
 int exa_grad_diagonal(exa_ctx* ctx, double* d, exa_stream s) {
    if (!ctx || !d) return fail(ctx, EXA_ERR_ARG, "exa_grad_diagonal: null pointer");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_diagonal called before exa_grad_setup");
-   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_diag_p1(ctx, d, S(s));
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return ctx->ea_generic ? exa_launch_ea_diag_gen(ctx, d, S(s)) : exa_launch_ea_diag_p1(ctx, d, S(s));
+   if (ctx->p != 1) return exa_launch_pa_diag_gen(ctx, d, S(s));
    return exa_launch_grad_diag_p1(ctx, d, S(s));
 }
 
 int exa_grad_get_ea(exa_ctx* ctx, double* emat, exa_stream s) {
    if (!ctx || !emat) return fail(ctx, EXA_ERR_ARG, "exa_grad_get_ea: null pointer");
    if (!ctx->have_grad || ctx->cfg.assembly != EXA_ASSEMBLY_EA) return fail(ctx, EXA_ERR_STATE, "exa_grad_get_ea: no element matrices assembled");
-   return exa_launch_ea_export_p1(ctx, emat, S(s));
+   return ctx->ea_generic ? exa_launch_ea_export_gen(ctx, emat, S(s)) : exa_launch_ea_export_p1(ctx, emat, S(s));
 }
 
 int exa_set_connectivity(exa_ctx* ctx, const int32_t* conn, int nnodes) {
@@ -186,7 +215,9 @@ int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const ui
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec: connectivity not set");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec called before exa_grad_setup");
-   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return exa_launch_ea_apply_p1(ctx, x, y, true, mask, gate, S(s));
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA)
+      return ctx->ea_generic ? exa_launch_ea_apply_gen(ctx, x, y, true, mask, gate, S(s)) : exa_launch_ea_apply_p1(ctx, x, y, true, mask, gate, S(s));
+   if (ctx->p != 1) return fail(ctx, EXA_ERR_UNSUPPORTED, "fused L-vector partial-assembly action is built for p = 1 only; use exa_restrict + exa_grad_apply");
    return exa_launch_grad_apply_p1(ctx, x, y, true, mask, gate, S(s));
 }
 
@@ -197,7 +228,7 @@ int exa_grad_apply_lvec(exa_ctx* ctx, const double* x, double* y, const uint8_t*
 int exa_residual_lvec(exa_ctx* ctx, const double* J, const double* stress1, double* y, exa_stream s) {
    if (!ctx || !J || !stress1 || !y) return fail(ctx, EXA_ERR_ARG, "exa_residual_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_residual_lvec: connectivity not set");
-   if (ctx->p != 1) return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_residual_lvec: only p = 1 is built in this round");
+   if (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL) return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_residual_lvec: fused path is built for p = 1 full integration; use exa_residual_setup/apply + exa_restrict_transpose_add");
    return exa_launch_residual_p1(ctx, J, stress1, y, true, S(s));
 }
 

@@ -36,7 +36,11 @@ struct exa_ctx {
    // residual PA data (D of AssemblePA), gradient PA data / EA matrices
    double* dmat = nullptr;                  // (3,3,Q,E)
    double* pa = nullptr;                    // see layout above
-   double* emat = nullptr;                  // EA: [block of 64 elements][(3n)^2][64]
+   double* emat = nullptr;                  // EA: p=1 full integration [block][24][12 pairs][64][2]; otherwise [block][3n][3n][64]
+   double* eDS = nullptr;                   // B-bar: element-average shape gradient (n,3,E)
+   double* tbuf = nullptr;                  // generic PA action: per-point T (3,3,Q,E)
+   const double* resid_J = nullptr; const double* resid_S = nullptr;   // B-bar residual reads J and sigma at apply time, like the reference
+   bool ea_generic = false;
    bool have_resid = false, have_grad = false;
    // L-vector support
    const int32_t* conn = nullptr; int nnodes = 0;

@@ -1,0 +1,278 @@
+// Generic-order and B-bar integrator kernels (gfx950):
+//   ICExaNLFIntegrator::AssemblePA (element-average gradient)   reference src/mechanics_integrators.cpp:1895-1953
+//   ICExaNLFIntegrator::AddMultPA                               reference src/mechanics_integrators.cpp:2011-2086
+//   ICExaNLFIntegrator::AssembleEA / ExaNLFIntegrator::AssembleEA for any order     :756-1017, 1195-1604
+//   element mat-vec / diagonal                                   spec src/mechanics_operator_ext.cpp:246-252,303-314
+//   AddMultGradPA / AssembleGradDiagonalPA for orders other than 1                   :562-622, 625-748
+// Element matrices are kept in an element-blocked layout [block of 64 elements][column j][row i][64 lanes] so that one lane per
+// element streams them with loads that are contiguous across the wave; p = 2 (81 x 81 per element, 52 KB) is HBM-bound on exactly
+// this stream.  The p = 1 full-integration fast paths live in pa_kernels.hip.
+#include "exa_internal.hpp"
+
+namespace {
+
+__device__ __forceinline__ int64_t pa_off(int64_t blk, int Q, int q, int pair) { return (((blk * Q + q) * PA_PAIRS + pair) * PA_BLK) * 2; }
+__device__ __forceinline__ int64_t eag_off(int64_t blk, int nd, int j, int i) { return ((blk * nd + j) * nd + i) * PA_BLK; }
+
+__device__ __forceinline__ void adj_det(const double* Jq, double adj[9], double& detJ) {
+   const double J11 = Jq[0], J21 = Jq[1], J31 = Jq[2], J12 = Jq[3], J22 = Jq[4], J32 = Jq[5], J13 = Jq[6], J23 = Jq[7], J33 = Jq[8];
+   adj[0] = J22 * J33 - J23 * J32; adj[1] = J32 * J13 - J12 * J33; adj[2] = J12 * J23 - J22 * J13;
+   adj[3] = J31 * J23 - J21 * J33; adj[4] = J11 * J33 - J13 * J31; adj[5] = J21 * J13 - J11 * J23;
+   adj[6] = J21 * J32 - J31 * J22; adj[7] = J31 * J12 - J11 * J32; adj[8] = J11 * J22 - J12 * J21;
+   detJ = J11 * adj[0] + J21 * adj[1] + J31 * adj[2];
+}
+
+// Voigt row of B (or B-bar) for a dof of component c with scaled gradient b and volumetric correction v (0 for plain B)
+__device__ __forceinline__ void b_row(int c, const double b[3], double v, double row[6]) {
+   row[0] = v; row[1] = v; row[2] = v; row[3] = 0.0; row[4] = 0.0; row[5] = 0.0;
+   if (c == 0) { row[0] += b[0]; row[4] = b[2]; row[5] = b[1]; }
+   else if (c == 1) { row[1] += b[1]; row[3] = b[2]; row[5] = b[0]; }
+   else { row[2] += b[2]; row[3] = b[1]; row[4] = b[0]; }
+}
+
+// eDS(a,t,e) = sum_q W_q (G adj)(a,t) / sum_q W_q detJ ; one thread per (node, element)
+__global__ void k_eds(const int Q, const int n, const int E, const double* __restrict__ W, const double* __restrict__ G,
+                      const double* __restrict__ J, double* __restrict__ eDS) {
+   extern __shared__ double sG[];
+   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
+   __syncthreads();
+   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= (int64_t)n * E) return;
+   const int a = (int)(t % n); const int64_t e = t / n;
+   double acc[3] = { 0, 0, 0 }, vol = 0;
+   for (int q = 0; q < Q; q++) {
+      double adj[9], detJ; adj_det(J + 9 * (q + (int64_t)Q * e), adj, detJ);
+      const double w = W[q]; vol += w * detJ;
+      const double g0 = sG[a + n * (3 * q)], g1 = sG[a + n * (3 * q + 1)], g2 = sG[a + n * (3 * q + 2)];
+      for (int c = 0; c < 3; c++) acc[c] += w * (g0 * adj[c] + g1 * adj[3 + c] + g2 * adj[6 + c]);
+   }
+   for (int c = 0; c < 3; c++) eDS[a + n * (c + 3 * e)] = acc[c] / vol;
+}
+
+// Y(a,c,e) += sum_q detJ W B-bar(a,c,:) . sigma ; one thread per (node, element)
+__global__ void k_residual_bbar(const int Q, const int n, const int E, const double* __restrict__ W, const double* __restrict__ G,
+                                const double* __restrict__ J, const double* __restrict__ S, const double* __restrict__ eDS, double* __restrict__ Y) {
+   extern __shared__ double sG[];
+   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
+   __syncthreads();
+   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= (int64_t)n * E) return;
+   const int a = (int)(t % n); const int64_t e = t / n;
+   const double ge[3] = { eDS[a + n * (3 * e)], eDS[a + n * (1 + 3 * e)], eDS[a + n * (2 + 3 * e)] };
+   double y[3] = { 0, 0, 0 };
+   for (int q = 0; q < Q; q++) {
+      const int64_t ip = q + (int64_t)Q * e;
+      double adj[9], detJ; adj_det(J + 9 * ip, adj, detJ);
+      const double idet = 1.0 / detJ, cw = detJ * W[q];
+      const double g0 = sG[a + n * (3 * q)], g1 = sG[a + n * (3 * q + 1)], g2 = sG[a + n * (3 * q + 2)];
+      double b[3];
+      for (int c = 0; c < 3; c++) b[c] = idet * (g0 * adj[c] + g1 * adj[3 + c] + g2 * adj[6 + c]);
+      const double* s = S + 6 * ip;
+      for (int c = 0; c < 3; c++) {
+         double row[6]; b_row(c, b, (ge[c] - b[c]) * (1.0 / 3.0), row);
+         double v = 0; for (int k = 0; k < 6; k++) v += row[k] * s[k];
+         y[c] += cw * v;
+      }
+   }
+   for (int c = 0; c < 3; c++) Y[a + n * (c + 3 * e)] += y[c];
+}
+
+// element matrices, any order, optional B-bar; grid (blocks of 64 elements, column dof)
+template <int N, bool BBAR>
+__global__ __launch_bounds__(PA_BLK) void k_assemble_ea_gen(const int E, const double* __restrict__ pa, const double* __restrict__ G, const double* __restrict__ W,
+                                                            const double* __restrict__ eDS, double* __restrict__ emat) {
+   constexpr int Q = N, ND = 3 * N;
+   extern __shared__ double sG[];
+   for (int i = threadIdx.x; i < N * 3 * Q; i += blockDim.x) sG[i] = G[i];
+   __syncthreads();
+   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   const int cj = blockIdx.y, aj = cj % N, kj = cj / N;
+   if (e >= E) return;
+   double M[ND];
+#pragma unroll
+   for (int i = 0; i < ND; i++) M[i] = 0.0;
+   double gej[3] = { 0, 0, 0 };
+   if (BBAR) for (int c = 0; c < 3; c++) gej[c] = eDS[aj + N * (c + 3 * e)];
+   for (int q = 0; q < Q; q++) {
+      const double2* rec = reinterpret_cast<const double2*>(pa + pa_off(blk, Q, q, 0)) + lane;
+      double v[PA_SLOTS];
+#pragma unroll
+      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = rec[pr * PA_BLK]; v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
+      const double* Ct = v; const double* adj = v + 36;
+      const double detJ = v[45] / W[q];
+      const double* Gq = sG + 3 * N * q;
+      double bj[3];
+      { const double g0 = Gq[aj], g1 = Gq[aj + N], g2 = Gq[aj + 2 * N];
+        for (int t = 0; t < 3; t++) bj[t] = g0 * adj[t] + g1 * adj[3 + t] + g2 * adj[6 + t]; }
+      double epsj[6]; b_row(kj, bj, BBAR ? (detJ * gej[kj] - bj[kj]) * (1.0 / 3.0) : 0.0, epsj);
+      double cb[6];
+#pragma unroll
+      for (int u = 0; u < 6; u++) { double s = 0; for (int w = 0; w < 6; w++) s += Ct[u + 6 * w] * epsj[w]; cb[u] = s; }
+      const double cb012 = cb[0] + cb[1] + cb[2];
+#pragma unroll
+      for (int a = 0; a < N; a++) {
+         const double g0 = Gq[a], g1 = Gq[a + N], g2 = Gq[a + 2 * N];
+         const double b0 = g0 * adj[0] + g1 * adj[3] + g2 * adj[6], b1 = g0 * adj[1] + g1 * adj[4] + g2 * adj[7], b2 = g0 * adj[2] + g1 * adj[5] + g2 * adj[8];
+         double r0 = b0 * cb[0] + b2 * cb[4] + b1 * cb[5];
+         double r1 = b1 * cb[1] + b2 * cb[3] + b0 * cb[5];
+         double r2 = b2 * cb[2] + b1 * cb[3] + b0 * cb[4];
+         if (BBAR) {
+            r0 += (detJ * eDS[a + N * (0 + 3 * e)] - b0) * (1.0 / 3.0) * cb012;
+            r1 += (detJ * eDS[a + N * (1 + 3 * e)] - b1) * (1.0 / 3.0) * cb012;
+            r2 += (detJ * eDS[a + N * (2 + 3 * e)] - b2) * (1.0 / 3.0) * cb012;
+         }
+         M[a] += r0; M[a + N] += r1; M[a + 2 * N] += r2;
+      }
+   }
+#pragma unroll
+   for (int i = 0; i < ND; i++) emat[eag_off(blk, ND, cj, i) + lane] = M[i];
+}
+
+// y(j,e) += sum_i A(i,j,e) x(i,e)
+template <int N, bool LVEC>
+__global__ __launch_bounds__(PA_BLK) void k_ea_apply_gen(const int E, const double* __restrict__ emat, const double* __restrict__ x, double* __restrict__ y,
+                                                         const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
+                                                         const double* __restrict__ gate) {
+   constexpr int ND = 3 * N;
+   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   if (e >= E) return;
+   if (gate != nullptr && gate[0] != 0.0) return;
+   double X[ND];
+   if (LVEC) {
+#pragma unroll
+      for (int a = 0; a < N; a++) {
+         const int g = conn[a + N * e];
+#pragma unroll
+         for (int c = 0; c < 3; c++) { const int64_t idx = g + (int64_t)nnodes * c; X[a + N * c] = (mask != nullptr && mask[idx]) ? 0.0 : x[idx]; }
+      }
+   } else {
+#pragma unroll
+      for (int i = 0; i < ND; i++) X[i] = x[i + (int64_t)ND * e];
+   }
+   for (int j = 0; j < ND; j++) {
+      const double* col = emat + eag_off(blk, ND, j, 0) + lane;
+      double s = 0;
+#pragma unroll
+      for (int i = 0; i < ND; i++) s += col[(int64_t)i * PA_BLK] * X[i];
+      if (LVEC) atomicAdd(&y[conn[(j % N) + N * e] + (int64_t)nnodes * (j / N)], s);
+      else y[j + (int64_t)ND * e] += s;
+   }
+}
+
+__global__ __launch_bounds__(PA_BLK) void k_ea_diag_gen(const int E, const int nd, const double* __restrict__ emat, double* __restrict__ y) {
+   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   if (e >= E) return;
+   for (int j = 0; j < nd; j++) y[j + (int64_t)nd * e] += emat[eag_off(blk, nd, j, j) + lane];
+}
+
+__global__ __launch_bounds__(PA_BLK) void k_ea_export_gen(const int E, const int nd, const double* __restrict__ emat, double* __restrict__ out) {
+   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   if (e >= E) return;
+   for (int j = 0; j < nd; j++) for (int i = 0; i < nd; i++) out[i + (int64_t)nd * (j + (int64_t)nd * e)] = emat[eag_off(blk, nd, j, i) + lane];
+}
+
+// generic partial-assembly gradient action: stage 1 (one thread per point) T = adj ( Ct : sym( (G x_e) adj ) )
+__global__ void k_pa_apply_stage1(const int Q, const int n, const int64_t P, const double* __restrict__ G, const double* __restrict__ pa,
+                                  const double* __restrict__ X, double* __restrict__ Tb) {
+   extern __shared__ double sG[];
+   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
+   __syncthreads();
+   const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (ip >= P) return;
+   const int q = (int)(ip % Q); const int64_t e = ip / Q;
+   const int64_t blk = e / PA_BLK; const int lane = (int)(e % PA_BLK);
+   const double* rec = pa + pa_off(blk, Q, q, 0) + 2 * lane;
+   auto slot = [&](int s) { return rec[(int64_t)(s >> 1) * PA_BLK * 2 + (s & 1)]; };
+   double adj[9]; for (int i = 0; i < 9; i++) adj[i] = slot(36 + i);
+   const double* x = X + (int64_t)3 * n * e; const double* Gq = sG + 3 * n * q;
+   double gx[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+   for (int a = 0; a < n; a++) {
+      const double g[3] = { Gq[a], Gq[a + n], Gq[a + 2 * n] };
+      for (int c = 0; c < 3; c++) { const double xv = x[a + n * c]; for (int j = 0; j < 3; j++) gx[c][j] += g[j] * xv; }
+   }
+   double h[3][3];
+   for (int c = 0; c < 3; c++) for (int t = 0; t < 3; t++) h[c][t] = gx[c][0] * adj[t] + gx[c][1] * adj[3 + t] + gx[c][2] * adj[6 + t];
+   const double eps[6] = { h[0][0], h[1][1], h[2][2], h[1][2] + h[2][1], h[0][2] + h[2][0], h[0][1] + h[1][0] };
+   double sg[6];
+   for (int i = 0; i < 6; i++) { double s = 0; for (int j = 0; j < 6; j++) s += slot(i + 6 * j) * eps[j]; sg[i] = s; }
+   const double Sm[3][3] = { { sg[0], sg[5], sg[4] }, { sg[5], sg[1], sg[3] }, { sg[4], sg[3], sg[2] } };
+   for (int j = 0; j < 3; j++) for (int c = 0; c < 3; c++) Tb[9 * ip + j + 3 * c] = adj[3 * j] * Sm[0][c] + adj[3 * j + 1] * Sm[1][c] + adj[3 * j + 2] * Sm[2][c];
+}
+
+// diag(a,c,e) += sum_q b(a)^T Ct_c b(a) for any order (reference src/mechanics_integrators.cpp:702-743)
+__global__ void k_pa_diag_gen(const int Q, const int n, const int E, const double* __restrict__ G, const double* __restrict__ pa, double* __restrict__ Y) {
+   extern __shared__ double sG[];
+   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
+   __syncthreads();
+   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= (int64_t)n * E) return;
+   const int a = (int)(t % n); const int64_t e = t / n;
+   const int64_t blk = e / PA_BLK; const int lane = (int)(e % PA_BLK);
+   constexpr int R[3][3] = { { 0, 5, 4 }, { 5, 1, 3 }, { 4, 3, 2 } };
+   double y[3] = { 0, 0, 0 };
+   for (int q = 0; q < Q; q++) {
+      const double* rec = pa + pa_off(blk, Q, q, 0) + 2 * lane;
+      auto slot = [&](int s) { return rec[(int64_t)(s >> 1) * PA_BLK * 2 + (s & 1)]; };
+      const double g0 = sG[a + n * (3 * q)], g1 = sG[a + n * (3 * q + 1)], g2 = sG[a + n * (3 * q + 2)];
+      double b[3];
+      for (int c = 0; c < 3; c++) b[c] = g0 * slot(36 + c) + g1 * slot(39 + c) + g2 * slot(42 + c);
+      for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 3; r++) for (int u = 0; u < 3; u++) s += b[r] * slot(R[c][r] + 6 * R[c][u]) * b[u]; y[c] += s; }
+   }
+   for (int c = 0; c < 3; c++) Y[a + n * (c + 3 * e)] += y[c];
+}
+
+inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+int exa_launch_residual_apply_from(exa_ctx* ctx, const double* D, double* Y, hipStream_t s);   // pa_kernels.hip
+
+int exa_launch_eds(exa_ctx* ctx, const double* J, hipStream_t s) {
+   hipLaunchKernelGGL(k_eds, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, ctx->eDS);
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
+int exa_launch_residual_bbar(exa_ctx* ctx, const double* J, const double* S, double* Y, hipStream_t s) {
+   hipLaunchKernelGGL(k_residual_bbar, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, S, ctx->eDS, Y);
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
+int exa_launch_assemble_ea_gen(exa_ctx* ctx, hipStream_t s) {
+   const bool bbar = ctx->cfg.integ == EXA_INTEG_BBAR;
+   const dim3 grid(nblk(ctx->E, PA_BLK), 3 * ctx->n); const size_t lds = sizeof(double) * ctx->n * 3 * ctx->Q;
+   if (ctx->n == 8) {
+      if (bbar) hipLaunchKernelGGL((k_assemble_ea_gen<8, true>), grid, dim3(PA_BLK), lds, s, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
+      else hipLaunchKernelGGL((k_assemble_ea_gen<8, false>), grid, dim3(PA_BLK), lds, s, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
+   } else if (ctx->n == 27) {
+      if (bbar) hipLaunchKernelGGL((k_assemble_ea_gen<27, true>), grid, dim3(PA_BLK), lds, s, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
+      else hipLaunchKernelGGL((k_assemble_ea_gen<27, false>), grid, dim3(PA_BLK), lds, s, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
+   } else { ctx->err = "element assembly is built for p = 1 and p = 2"; return EXA_ERR_UNSUPPORTED; }
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
+int exa_launch_ea_apply_gen(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s) {
+   const unsigned nb = nblk(ctx->E, PA_BLK);
+   if (ctx->n == 8) {
+      if (lvec) hipLaunchKernelGGL((k_ea_apply_gen<8, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
+      else hipLaunchKernelGGL((k_ea_apply_gen<8, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
+   } else if (ctx->n == 27) {
+      if (lvec) hipLaunchKernelGGL((k_ea_apply_gen<27, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
+      else hipLaunchKernelGGL((k_ea_apply_gen<27, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
+   } else { ctx->err = "element assembly is built for p = 1 and p = 2"; return EXA_ERR_UNSUPPORTED; }
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
+int exa_launch_ea_diag_gen(exa_ctx* ctx, double* y, hipStream_t s) {
+   hipLaunchKernelGGL(k_ea_diag_gen, dim3(nblk(ctx->E, PA_BLK)), dim3(PA_BLK), 0, s, ctx->E, 3 * ctx->n, ctx->emat, y);
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
+int exa_launch_ea_export_gen(exa_ctx* ctx, double* out, hipStream_t s) {
+   hipLaunchKernelGGL(k_ea_export_gen, dim3(nblk(ctx->E, PA_BLK)), dim3(PA_BLK), 0, s, ctx->E, 3 * ctx->n, ctx->emat, out);
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
+// generic PA action on E-vectors: stage 1 into the (3,3,Q,E) scratch `dmat`, stage 2 = the AddMultPA contraction
+int exa_launch_pa_apply_gen(exa_ctx* ctx, const double* x, double* y, hipStream_t s) {
+   hipLaunchKernelGGL(k_pa_apply_stage1, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, ctx->pa, x, ctx->tbuf);
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   return exa_launch_residual_apply_from(ctx, ctx->tbuf, y, s);
+}
+int exa_launch_pa_diag_gen(exa_ctx* ctx, double* y, hipStream_t s) {
+   hipLaunchKernelGGL(k_pa_diag_gen, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, ctx->pa, y);
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}

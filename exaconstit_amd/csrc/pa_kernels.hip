@@ -444,6 +444,10 @@ int exa_launch_residual_apply(exa_ctx* ctx, double* Y, hipStream_t s) {
    hipLaunchKernelGGL(k_residual_apply, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, ctx->dmat, Y);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
+int exa_launch_residual_apply_from(exa_ctx* ctx, const double* D, double* Y, hipStream_t s) {
+   hipLaunchKernelGGL(k_residual_apply, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, D, Y);
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
 int exa_launch_residual_p1(exa_ctx* ctx, const double* J, const double* S, double* y, bool lvec, hipStream_t s) {
    const unsigned nb = nblk(ctx->E, PA_BLK);
    if (lvec) hipLaunchKernelGGL(k_residual_p1<true>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);

@@ -208,3 +208,109 @@ def test_integrators_match_oracle(oracle, assembly):
     ctx.check(L.exa_vol_avg(ctx.h, ptr(d_J), ptr(d_qf), 6, 1, out.ctypes.data_as(C.POINTER(C.c_double)), None))
     assert rel_l2(out[:6], ref) < 1e-12
     ctx.close()
+
+
+@pytest.mark.parametrize("p,assembly,integ", [(2, 0, 0), (2, 1, 0), (1, 1, 1), (2, 1, 1)])
+def test_generic_order_and_bbar_integrators(oracle, p, assembly, integ):
+    """p = 2 partial/element assembly and the B-bar integrator (config 5 of BASELINE.json) against the oracle."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 5 if p == 1 else 3, p=p, distort=0.2, seed=4)   # E not a multiple of 64
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    rng = np.random.default_rng(9)
+    ctx = L.Context(L.EXA_FCC_VOCE, _props(orc, "voce"), 298.0, p, E, assembly=assembly, integ=integ)
+    G, W = ctx.shape_table()
+    assert rel_l2(G, rve["G"]) < 1e-13 and rel_l2(W, rve["W"]) < 1e-13
+    xe = hipref.l_to_e(rve, rve["X"])
+    J = np.zeros(9 * P); orc.lib().orc_jacobians(p, E, orc._p(xe), orc._p(J))
+    d_xe = dev.up(xe); d_J = dev.zeros(9 * P)
+    ctx.check(L.exa_jacobians(ctx.h, ptr(d_xe), ptr(d_J), None))
+    assert rel_l2(d_J.cpu().numpy(), J) < 1e-13
+    eDS = np.zeros(3 * n * E)
+    orc.lib().orc_element_eds(Q, E, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(eDS))
+    # residual
+    sig = rng.standard_normal(6 * P)
+    y0 = rng.standard_normal(3 * n * E); y_ref = y0.copy()
+    if integ:
+        orc.lib().orc_add_mult_pa_bbar(Q, E, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(eDS), orc._p(sig), orc._p(y_ref))
+    else:
+        orc.lib().orc_element_vector(Q, E, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(sig), orc._p(y_ref))
+    d_sig = dev.up(sig); d_y = dev.up(y0)
+    ctx.check(L.exa_residual_setup(ctx.h, ptr(d_J), ptr(d_sig), None))
+    ctx.check(L.exa_residual_apply(ctx.h, ptr(d_y), None))
+    assert rel_l2(d_y.cpu().numpy(), y_ref) < 1e-12
+    # gradient
+    dt = 0.2
+    Cm = _spd_tangent(P, seed=8)
+    x_e = rng.standard_normal(3 * n * E); yg0 = rng.standard_normal(3 * n * E)
+    yg_ref = yg0.copy(); diag_ref = np.zeros(3 * n * E)
+    emat = np.zeros(9 * n * n * E)
+    if integ:
+        orc.lib().orc_assemble_ea_bbar(Q, E, n, C.c_double(dt), orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(eDS), orc._p(Cm), orc._p(emat))
+    else:
+        orc.lib().orc_assemble_ea(Q, E, n, C.c_double(dt), orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(Cm), orc._p(emat))
+    if assembly == 0:
+        C4 = np.zeros(81 * P); D4 = np.zeros(81 * P)
+        orc.lib().orc_transform_4d(C.c_int64(P), orc._p(Cm), orc._p(C4))
+        orc.lib().orc_assemble_grad_pa(Q, E, C.c_double(dt), orc._p(rve["W"]), orc._p(J), orc._p(C4), orc._p(D4))
+        orc.lib().orc_add_mult_grad_pa(Q, E, n, orc._p(rve["G"]), orc._p(D4), orc._p(x_e), orc._p(yg_ref))
+        orc.lib().orc_assemble_grad_diag_pa(Q, E, n, C.c_double(dt), orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(Cm), orc._p(diag_ref))
+    else:
+        orc.lib().orc_ea_mult(E, n, orc._p(emat), orc._p(x_e), orc._p(yg_ref))
+        orc.lib().orc_ea_diag(E, n, orc._p(emat), orc._p(diag_ref))
+    d_C = dev.up(Cm); d_x = dev.up(x_e); d_yg = dev.up(yg0); d_diag = dev.zeros(3 * n * E)
+    ctx.check(L.exa_grad_setup(ctx.h, dt, ptr(d_J), ptr(d_C), None))
+    ctx.check(L.exa_grad_apply(ctx.h, ptr(d_x), ptr(d_yg), None))
+    ctx.check(L.exa_grad_diagonal(ctx.h, ptr(d_diag), None))
+    assert rel_l2(d_yg.cpu().numpy(), yg_ref) < 1e-12
+    assert rel_l2(d_diag.cpu().numpy(), diag_ref) < 1e-12
+    if assembly == 1:
+        d_em = dev.zeros(9 * n * n * E)
+        ctx.check(L.exa_grad_get_ea(ctx.h, ptr(d_em), None))
+        assert rel_l2(d_em.cpu().numpy(), emat) < 1e-12
+        # fused L-vector element mat-vec
+        d_conn = dev.up(rve["conn"]); ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+        xL = rng.standard_normal(3 * NN); mask = (rng.uniform(size=3 * NN) < 0.1).astype(np.uint8)
+        ye = np.zeros(3 * n * E)
+        orc.lib().orc_ea_mult(E, n, orc._p(emat), orc._p(hipref.l_to_e(rve, np.where(mask, 0.0, xL))), orc._p(ye))
+        yL_ref = np.zeros(3 * NN); conn = rve["conn"].reshape(E, n)
+        for c in range(3):
+            np.add.at(yL_ref, conn + NN * c, ye.reshape(E, 3, n)[:, c, :])
+        d_xL = dev.up(xL); d_mask = dev.up(mask); d_yL = dev.zeros(3 * NN)
+        ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xL), ptr(d_yL), ptr(d_mask), None))
+        assert rel_l2(d_yL.cpu().numpy(), yL_ref) < 1e-12
+    ctx.close()
+
+
+def test_model_setup_p2_matches_oracle(oracle):
+    """the fused constitutive kernel is order-generic (27 nodes / 27 points per element at p = 2)."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 3, p=2, distort=0.1)
+    props = _props(orc, "voce")
+    E, Q, n = rve["E"], rve["Q"], rve["n"]
+    P = E * Q
+    ctx = L.Context(L.EXA_FCC_VOCE, props, 298.0, 2, E)
+    quats = hipref.random_quats(E)
+    d_state0 = dev.zeros(28 * P)
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_state0), ptr(dev.up(quats.ravel())), None))
+    sv0 = d_state0.cpu().numpy().copy(); s0 = np.zeros(6 * P)
+    v = hipref.velocity_field(rve, scale=2.0); vel_e = hipref.l_to_e(rve, v); x = rve["X"].copy()
+    for dt in (0.2, 0.3, 0.5):
+        x = x + v * dt
+        xe = hipref.l_to_e(rve, x)
+        J = np.zeros(9 * P); orc.lib().orc_jacobians(2, E, orc._p(xe), orc._p(J))
+        s1 = np.zeros(6 * P); sv1 = np.zeros(28 * P); cm = np.zeros(36 * P)
+        nf = orc.lib().orc_model_setup(0, 0, orc._p(props), len(props), Q, E, n, 28, C.c_double(dt), C.c_double(298.0), orc._p(J), orc._p(rve["G"]),
+                                       orc._p(vel_e), orc._p(s0), orc._p(sv0), orc._p(s1), orc._p(sv1), orc._p(cm), None, 1, 0, 0)
+        assert nf == 0
+        d = [dev.up(a) for a in (J, vel_e, s0, sv0)]; o = [dev.zeros(6 * P), dev.zeros(28 * P), dev.zeros(36 * P)]
+        ctx.check(L.exa_model_setup(ctx.h, dt, *[ptr(t) for t in d], *[ptr(t) for t in o], None))
+        assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+        assert rel_l2(o[0].cpu().numpy(), s1) < 1e-9
+        assert rel_l2(o[2].cpu().numpy(), cm) < 1e-7
+        s0, sv0 = s1, sv1
+    ctx.close()
