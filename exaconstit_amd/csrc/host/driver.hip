@@ -125,19 +125,22 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
                                              const std::vector<double>& quats_per_elem)
    : opt_(opt), part_(part), comm_(comm) {
    EXA_HC(hipStreamCreate(&stream_)); EXA_HC(hipEventCreate(&ev0_)); EXA_HC(hipEventCreate(&ev1_));
-   exa_config cfg; cfg.model = model_id(opt); cfg.nprops = (int)props.size(); cfg.props = props.data(); cfg.temp_k = opt.temp_k; cfg.order = 1;
-   cfg.nelems = part.E; cfg.assembly = opt.assembly == Assembly::PA ? EXA_ASSEMBLY_PA : EXA_ASSEMBLY_EA; cfg.integ = EXA_INTEG_FULL; cfg.device = -1;
+   const bool bbar = ExaOptions::lower(opt.integ_model) == "bbar";
+   exa_config cfg; cfg.model = model_id(opt); cfg.nprops = (int)props.size(); cfg.props = props.data(); cfg.temp_k = opt.temp_k; cfg.order = part.p;
+   cfg.nelems = part.E; cfg.assembly = opt.assembly == Assembly::PA ? EXA_ASSEMBLY_PA : EXA_ASSEMBLY_EA; cfg.integ = bbar ? EXA_INTEG_BBAR : EXA_INTEG_FULL; cfg.device = -1;
    int err = 0; ctx_ = exa_create(&cfg, &err);
    if (!ctx_) throw std::runtime_error("exa_create failed (" + std::to_string(err) + ")");
-   nn_ = part.NN; nd_ = 3 * nn_; E_ = part.E;
-   const size_t P = (size_t)E_ * 8;
+   nn_ = part.NN; nd_ = 3 * nn_; E_ = part.E; npe_ = part.n;
+   fast_p1_ = (part.p == 1 && !bbar);          // fused L-vector kernels exist for p = 1 full integration
+   lvec_grad_ = fast_p1_ || opt.assembly == Assembly::EA;
+   const size_t P = (size_t)E_ * npe_;
    conn.upload(part.conn); abi_check(ctx_, exa_set_connectivity(ctx_, conn.p, nn_), "exa_set_connectivity");
    x_ref.upload(part.X); x_beg.upload(part.X); x_cur.upload(part.X);
    weight.upload(part.weight);
-   el_x.alloc(24 * (size_t)E_); el_v.alloc(24 * (size_t)E_); el_y_.alloc(24 * (size_t)E_); el_jac.alloc(9 * P);
+   el_x.alloc(3 * (size_t)npe_ * E_); el_v.alloc(3 * (size_t)npe_ * E_); el_y_.alloc(3 * (size_t)npe_ * E_); el_jac.alloc(9 * P);
    stress0.alloc(6 * P); stress1.alloc(6 * P); matVars0.alloc(28 * P); matVars1.alloc(28 * P); matGrad.alloc(36 * P);
    stress0.zero(); stress1.zero(); matVars1.zero(); matGrad.zero();
-   diag.alloc(nd_); dinv.alloc(nd_); tmp_l_.alloc(nd_); ess_mask.alloc(nd_); ess_mask.zero();
+   diag.alloc(nd_); dinv.alloc(nd_); tmp_l_.alloc(nd_); tmp_r_.alloc(nd_); el_x2_.alloc(3 * (size_t)npe_ * E_); ess_mask.alloc(nd_); ess_mask.zero();
    partial.alloc(DOT_BLOCKS * 4); scal.alloc(16); scal.zero();
    { DevBuf<double> q; q.upload(quats_per_elem); abi_check(ctx_, exa_init_state(ctx_, matVars0.p, q.p, stream_), "exa_init_state"); EXA_HC(hipStreamSynchronize(stream_)); }
    model_.reset(new ExaCMechModel(ctx_, &stress0, &stress1, &matGrad, &matVars0, &matVars1));
@@ -159,14 +162,20 @@ void NonlinearMechOperator::Setup(const double* k) {
    EXA_HC(hipEventRecord(ev1_, stream_));
    EXA_HC(hipEventSynchronize(ev1_));
    float ms = 0; EXA_HC(hipEventElapsedTime(&ms, ev0_, ev1_));
-   timers.t_model_ms += ms; timers.qpt_updates += (int64_t)E_ * 8; model_calls++;
+   timers.t_model_ms += ms; timers.qpt_updates += (int64_t)E_ * npe_; model_calls++;
 }
 template void NonlinearMechOperator::Setup<true>(const double*);
 template void NonlinearMechOperator::Setup<false>(const double*);
 
 void NonlinearMechOperator::ResidualAction(double* y) {
    EXA_HC(hipMemsetAsync(y, 0, sizeof(double) * nd_, stream_));
-   abi_check(ctx_, exa_residual_lvec(ctx_, el_jac.p, stress1.p, y, stream_), "exa_residual_lvec");
+   if (fast_p1_) abi_check(ctx_, exa_residual_lvec(ctx_, el_jac.p, stress1.p, y, stream_), "exa_residual_lvec");
+   else {   // Hform->Setup() = AssemblePA, Hform->Mult = L->E, AddMultPA, E->L
+      abi_check(ctx_, exa_residual_setup(ctx_, el_jac.p, stress1.p, stream_), "exa_residual_setup");
+      el_y_.zero(stream_);
+      abi_check(ctx_, exa_residual_apply(ctx_, el_y_.p, stream_), "exa_residual_apply");
+      abi_check(ctx_, exa_restrict_transpose_add(ctx_, el_y_.p, y, stream_), "exa_restrict_transpose_add");
+   }
    comm_.halo_sum(part_, y, stream_);
    vk_mask_zero(nd_, ess_mask.p, y, stream_);
 }
@@ -186,7 +195,15 @@ void NonlinearMechOperator::GetGradient() {
 
 void NonlinearMechOperator::GradMult(const double* x, double* y, bool constrained, const double* done_flag) {
    vk_fill_if(nd_, done_flag, 0.0, y, stream_);
-   abi_check(ctx_, exa_grad_apply_lvec_gated(ctx_, x, y, constrained ? ess_mask.p : nullptr, done_flag, stream_), "exa_grad_apply_lvec");
+   if (lvec_grad_) abi_check(ctx_, exa_grad_apply_lvec_gated(ctx_, x, y, constrained ? ess_mask.p : nullptr, done_flag, stream_), "exa_grad_apply_lvec");
+   else {   // generic-order partial assembly: mask, L->E, AddMultGradPA, E->L (spec reference src/mechanics_operator_ext.cpp:143-157)
+      EXA_HC(hipMemcpyAsync(tmp_l_.p, x, sizeof(double) * nd_, hipMemcpyDeviceToDevice, stream_));
+      if (constrained) vk_mask_zero(nd_, ess_mask.p, tmp_l_.p, stream_);
+      abi_check(ctx_, exa_restrict(ctx_, tmp_l_.p, el_x2_.p, stream_), "exa_restrict");
+      el_y_.zero(stream_);
+      abi_check(ctx_, exa_grad_apply(ctx_, el_x2_.p, el_y_.p, stream_), "exa_grad_apply");
+      abi_check(ctx_, exa_restrict_transpose_add(ctx_, el_y_.p, y, stream_), "exa_restrict_transpose_add");
+   }
    comm_.halo_sum(part_, y, stream_);
    if (constrained) vk_mask_zero(nd_, ess_mask.p, y, stream_);
 }
@@ -195,9 +212,9 @@ void NonlinearMechOperator::GetUpdateBCsAction(const double* k, const double* x,
    Setup<false>(k);
    GetGradient();                              // Hform->Setup + gradient data
    GradMult(x, y, false);                      // local action without essential constraints
-   ResidualAction(tmp_l_.p);                   // Hform->Mult(k, resid), essential rows zeroed
+   ResidualAction(tmp_r_.p);                   // Hform->Mult(k, resid), essential rows zeroed
    vk_mask_zero(nd_, ess_mask.p, y, stream_);
-   vk_axpby(nd_, 1.0, tmp_l_.p, 1.0, y, stream_);
+   vk_axpby(nd_, 1.0, tmp_r_.p, 1.0, y, stream_);
 }
 
 double NonlinearMechOperator::dot(const double* a, const double* b) {
@@ -235,7 +252,7 @@ static void load_case_data(const ExaOptions& opt, const Partition& part, std::ve
 SystemDriver::SystemDriver(const ExaOptions& opt, int rank, int nranks, const void* uid) : opt_(opt) {
    comm.init(rank, nranks, uid);
    const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
-   part.build(N, opt.length, rank, nranks);
+   part.build(N, opt.length, rank, nranks, opt.order);
    std::vector<double> props, quats; load_case_data(opt, part, props, quats);
    init(props, quats);
 }
@@ -243,7 +260,7 @@ SystemDriver::SystemDriver(const ExaOptions& opt, int rank, int nranks, const vo
 SystemDriver::SystemDriver(const ExaOptions& opt, const std::vector<double>& props, const std::vector<double>& quats_global, int rank, int nranks, const void* uid) : opt_(opt) {
    comm.init(rank, nranks, uid);
    const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
-   part.build(N, opt.length, rank, nranks);
+   part.build(N, opt.length, rank, nranks, opt.order);
    std::vector<double> quats((size_t)4 * part.E);
    for (int e = 0; e < part.E; e++) for (int q = 0; q < 4; q++) quats[4 * (size_t)e + q] = quats_global[4 * (size_t)part.elem_gid[e] + q];
    init(props, quats);
@@ -418,8 +435,8 @@ void SystemDriver::UpdateModel() {
       avg_pl_work.push_back(a[2]);
       if (root) append_row(out_dir + "/" + opt_.avg_pl_work_fname, a + 2, 1);
       // CalculateDeformationGradient: gradient of the current coordinates on the reference configuration
-      const size_t P = (size_t)part.E * 8;
-      DevBuf<double> jref(9 * P), F(9 * P), xe(24 * (size_t)part.E);
+      const size_t P = (size_t)part.E * part.n;
+      DevBuf<double> jref(9 * P), F(9 * P), xe(3 * (size_t)part.n * part.E);
       abi_check(ctx, exa_restrict(ctx, op.x_ref.p, xe.p, s), "exa_restrict");
       abi_check(ctx, exa_jacobians(ctx, xe.p, jref.p, s), "exa_jacobians");
       abi_check(ctx, exa_grad_calc(ctx, jref.p, op.el_x.p, F.p, s), "exa_grad_calc");

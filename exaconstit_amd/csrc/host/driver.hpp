@@ -104,8 +104,9 @@ class NonlinearMechOperator {
    ExaOptions opt_; const Partition& part_; Comm& comm_;
    exa_ctx* ctx_ = nullptr; std::unique_ptr<ExaCMechModel> model_;
    hipStream_t stream_ = nullptr; hipEvent_t ev0_, ev1_;
-   int nn_, nd_, E_; double dt_ = 1.0;
-   DevBuf<double> tmp_l_, el_y_;
+   int nn_, nd_, E_, npe_ = 8; double dt_ = 1.0;
+   bool fast_p1_ = true, lvec_grad_ = true;
+   DevBuf<double> tmp_l_, tmp_r_, el_y_, el_x2_;
 };
 
 class SystemDriver {

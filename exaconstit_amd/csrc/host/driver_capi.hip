@@ -43,6 +43,7 @@ exa_driver* exa_driver_create_synthetic(const exa_synth_config* c, int rank, int
       opt.slip = c->slip == 0 ? SlipType::POWERVOCE : (c->slip == 1 ? SlipType::POWERVOCENL : SlipType::MTSDD);
       for (int i = 0; i < 3; i++) { opt.ncuts[i] = c->N; opt.length[i] = 1.0; }
       opt.assembly = c->assembly == 0 ? Assembly::PA : Assembly::EA;
+      opt.order = c->order > 0 ? c->order : 1; opt.integ_model = c->bbar ? "BBAR" : "FULL";
       opt.nl_solver = c->nrls ? NLSolver::NRLS : NLSolver::NR;
       opt.newton_iter = c->newton_iter; opt.newton_rel = c->newton_rel; opt.newton_abs = c->newton_abs;
       opt.krylov_iter = c->krylov_iter; opt.krylov_rel = c->krylov_rel; opt.krylov_abs = c->krylov_abs;
@@ -64,7 +65,7 @@ exa_driver* exa_driver_create_synthetic(const exa_synth_config* c, int rank, int
 void exa_driver_destroy(exa_driver* d) { delete d; }
 
 int exa_driver_num_steps(exa_driver* d) { return d->sd->options().nsteps; }
-int64_t exa_driver_local_qpts(exa_driver* d) { return (int64_t)d->sd->part.E * 8; }
+int64_t exa_driver_local_qpts(exa_driver* d) { return (int64_t)d->sd->part.E * d->sd->part.n; }
 int64_t exa_driver_local_dofs(exa_driver* d) { return (int64_t)d->sd->part.NN * 3; }
 
 int exa_driver_step(exa_driver* d, int ti, char* err, int errlen) {
@@ -186,7 +187,7 @@ int exa_options_query(const char* toml_path, double* out, char* err, int errlen)
 int exa_partition_query(const int* N, int rank, int nranks, int64_t* info, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
                         int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs) {
    Partition p; const double L[3] = { 1.0, 1.0, 1.0 };
-   p.build(N, L, rank, nranks);
+   p.build(N, L, rank, nranks, 1);
    int64_t shared = 0; for (auto& nb : p.nbrs) shared += (int64_t)nb.dofs.size();
    info[0] = p.E; info[1] = p.NN; info[2] = (int64_t)p.nbrs.size(); info[3] = p.pg[0]; info[4] = p.pg[1]; info[5] = p.pg[2]; info[6] = shared; info[7] = 0;
    if (conn) std::memcpy(conn, p.conn.data(), sizeof(int32_t) * p.conn.size());

@@ -18,8 +18,9 @@ struct Partition {
    int N[3] = { 1, 1, 1 }; double len[3] = { 1, 1, 1 };
    int pg[3] = { 1, 1, 1 }, rank = 0, nranks = 1, rc[3] = { 0, 0, 0 };
    int e0[3], ne[3], nn[3];
+   int p = 1, n = 8;                 // H1 order, nodes per element (p+1)^3
    int E = 0, NN = 0;
-   std::vector<int32_t> conn;        // (8, E)
+   std::vector<int32_t> conn;        // (n, E), native node order
    std::vector<double> X;            // byNODES (NN, 3)
    std::vector<int64_t> elem_gid;    // global element index, x fastest
    std::vector<double> weight;       // 1 / (number of ranks holding the node)
@@ -38,24 +39,50 @@ struct Partition {
       return g;
    }
 
-   void build(const int Nn[3], const double L[3], int rank_, int nranks_) {
+   // lexicographic (i,j,k) -> native index of the order-p hexahedron (vertices, edge, face, volume interiors)
+   static std::vector<int> native_order(int p) {
+      const int np = p + 1;
+      std::vector<int> m((size_t)np * np * np, -1);
+      auto Lx = [&](int i, int j, int k) { return i + np * (j + np * k); };
+      int c = 0;
+      static const int V[8][3] = { { 0, 0, 0 }, { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 0, 0, 1 }, { 1, 0, 1 }, { 1, 1, 1 }, { 0, 1, 1 } };
+      for (auto& v : V) m[Lx(v[0] * p, v[1] * p, v[2] * p)] = c++;
+      static const int Ed[12][2] = { { 0, 1 }, { 1, 2 }, { 3, 2 }, { 0, 3 }, { 4, 5 }, { 5, 6 }, { 7, 6 }, { 4, 7 }, { 0, 4 }, { 1, 5 }, { 2, 6 }, { 3, 7 } };
+      for (auto& ed : Ed) for (int t = 1; t < p; t++) {
+         int ijk[3]; for (int d = 0; d < 3; d++) ijk[d] = V[ed[0]][d] * p + (V[ed[1]][d] - V[ed[0]][d]) * t;
+         m[Lx(ijk[0], ijk[1], ijk[2])] = c++;
+      }
+      for (int f = 0; f < 6; f++) for (int t2 = 1; t2 < p; t2++) for (int t1 = 1; t1 < p; t1++) {
+         int i = t1, j = t2, k = 0;
+         if (f == 1) { i = t1; j = 0; k = t2; } else if (f == 2) { i = p; j = t1; k = t2; } else if (f == 3) { i = t1; j = p; k = t2; }
+         else if (f == 4) { i = 0; j = t1; k = t2; } else if (f == 5) { i = t1; j = t2; k = p; }
+         m[Lx(i, j, k)] = c++;
+      }
+      for (int k = 1; k < p; k++) for (int j = 1; j < p; j++) for (int i = 1; i < p; i++) m[Lx(i, j, k)] = c++;
+      return m;
+   }
+
+   void build(const int Nn[3], const double L[3], int rank_, int nranks_, int order = 1) {
+      p = order; n = (p + 1) * (p + 1) * (p + 1);
       for (int d = 0; d < 3; d++) { N[d] = Nn[d]; len[d] = L[d]; }
       rank = rank_; nranks = nranks_;
       auto g = grid_for(nranks); for (int d = 0; d < 3; d++) pg[d] = g[d];
       rc[0] = rank % pg[0]; rc[1] = (rank / pg[0]) % pg[1]; rc[2] = rank / (pg[0] * pg[1]);
-      for (int d = 0; d < 3; d++) { split(N[d], pg[d], rc[d], e0[d], ne[d]); nn[d] = ne[d] + 1; }
+      for (int d = 0; d < 3; d++) { split(N[d], pg[d], rc[d], e0[d], ne[d]); nn[d] = ne[d] * p + 1; }
       E = ne[0] * ne[1] * ne[2]; NN = nn[0] * nn[1] * nn[2];
-      conn.resize((size_t)8 * E); X.resize((size_t)3 * NN); elem_gid.resize(E); weight.resize(NN);
-      static const int V[8][3] = { { 0, 0, 0 }, { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 0, 0, 1 }, { 1, 0, 1 }, { 1, 1, 1 }, { 0, 1, 1 } };
+      conn.resize((size_t)n * E); X.resize((size_t)3 * NN); elem_gid.resize(E); weight.resize(NN);
+      const std::vector<int> nat = native_order(p);
+      const int np = p + 1;
       for (int k = 0; k < ne[2]; k++) for (int j = 0; j < ne[1]; j++) for (int i = 0; i < ne[0]; i++) {
          const int e = i + ne[0] * (j + ne[1] * k);
          elem_gid[e] = (int64_t)(e0[0] + i) + (int64_t)N[0] * ((e0[1] + j) + (int64_t)N[1] * (e0[2] + k));
-         for (int a = 0; a < 8; a++) conn[a + 8 * (size_t)e] = (i + V[a][0]) + nn[0] * ((j + V[a][1]) + nn[1] * (k + V[a][2]));
+         for (int c = 0; c < np; c++) for (int b = 0; b < np; b++) for (int a = 0; a < np; a++)
+            conn[nat[a + np * (b + np * c)] + (size_t)n * e] = (i * p + a) + nn[0] * ((j * p + b) + nn[1] * (k * p + c));
       }
       for (int k = 0; k < nn[2]; k++) for (int j = 0; j < nn[1]; j++) for (int i = 0; i < nn[0]; i++) {
          const int g = i + nn[0] * (j + nn[1] * k);
-         const int gi[3] = { e0[0] + i, e0[1] + j, e0[2] + k };
-         for (int d = 0; d < 3; d++) X[g + (size_t)NN * d] = len[d] * gi[d] / N[d];
+         const int gi[3] = { e0[0] * p + i, e0[1] * p + j, e0[2] * p + k };   // equispaced nodes (p <= 2: identical to Gauss-Lobatto)
+         for (int d = 0; d < 3; d++) X[g + (size_t)NN * d] = len[d] * gi[d] / (N[d] * p);
          int mult = 1;
          for (int d = 0; d < 3; d++) {
             const int li = (d == 0 ? i : (d == 1 ? j : k));
@@ -81,8 +108,8 @@ struct Partition {
 
    // is local node g on global boundary face id?
    bool on_face(int g, int id) const {
-      const int i = g % nn[0] + e0[0], j = (g / nn[0]) % nn[1] + e0[1], k = g / (nn[0] * nn[1]) + e0[2];
-      switch (id) { case 1: return k == 0; case 2: return i == 0; case 3: return j == 0; case 4: return k == N[2]; case 5: return i == N[0]; default: return j == N[1]; }
+      const int i = g % nn[0] + e0[0] * p, j = (g / nn[0]) % nn[1] + e0[1] * p, k = g / (nn[0] * nn[1]) + e0[2] * p;
+      switch (id) { case 1: return k == 0; case 2: return i == 0; case 3: return j == 0; case 4: return k == N[2] * p; case 5: return i == N[0] * p; default: return j == N[1] * p; }
    }
 };
 

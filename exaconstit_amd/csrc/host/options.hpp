@@ -160,7 +160,8 @@ struct ExaOptions {
       const std::string as = lower(d.str("Solvers.assembly", "FULL"));
       if (as == "pa") assembly = Assembly::PA; else if (as == "ea" || as == "full") assembly = Assembly::EA; else throw std::runtime_error("Unknown assembly: " + as);
       integ_model = d.str("Solvers.integ_model", "FULL");
-      if (lower(integ_model) != "full") throw std::runtime_error("integ_model = \"BBAR\" is not built yet");
+      if (lower(integ_model) != "full" && lower(integ_model) != "bbar") throw std::runtime_error("Solvers.integ_model was not provided a valid type.");
+      if (lower(integ_model) == "bbar" && assembly == Assembly::PA) throw std::runtime_error("integ_model = \"BBAR\" has no partial-assembly gradient (use EA or FULL), as in the reference");
       newton_iter = (int)d.num("Solvers.NR.iter", 25); newton_rel = d.num("Solvers.NR.rel_tol", 1e-5); newton_abs = d.num("Solvers.NR.abs_tol", 1e-10);
       nl_solver = lower(d.str("Solvers.NR.nl_solver", "NR")) == "nrls" ? NLSolver::NRLS : NLSolver::NR;
       krylov_iter = (int)d.num("Solvers.Krylov.iter", 200); krylov_rel = d.num("Solvers.Krylov.rel_tol", 1e-10); krylov_abs = d.num("Solvers.Krylov.abs_tol", 1e-30);
@@ -171,7 +172,7 @@ struct ExaOptions {
       const TomlValue* nc = d.get("Mesh.Auto.ncuts"); const TomlValue* ln = d.get("Mesh.Auto.length");
       if (!nc || !ln || nc->arr.size() != 3 || ln->arr.size() != 3) throw std::runtime_error("Must input mesh geometry/discretization for hex_mesh_gen");
       for (int i = 0; i < 3; i++) { ncuts[i] = (int)nc->arr[i].num; length[i] = ln->arr[i].num; }
-      if (order != 1) throw std::runtime_error("Only p_refinement = 1 is built in this round");
+      if (order != 1 && order != 2) throw std::runtime_error("Only p_refinement = 1 or 2 is built");
    }
 };
 

@@ -25,6 +25,8 @@ typedef struct {
    int krylov_iter; double krylov_rel, krylov_abs;
    int nsteps; const double* dts;
    double vz;                  /* z-velocity of the top face */
+   int order;                  /* H1 order p (1 or 2; 0 = 1) */
+   int bbar;                   /* 1: B-bar integrator (element assembly only) */
 } exa_synth_config;
 
 int exa_rccl_unique_id(void* out128);

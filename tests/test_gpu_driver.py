@@ -70,3 +70,42 @@ def test_cyclic_bc_change(oracle, tmp_path):
     s = d.avgs(0, 6)
     # after the reversal the answer is only defined to the Newton tolerance of the case (rel 5e-5 of a large initial residual)
     assert np.max(np.abs(s[:, 2] - g[:, 2])) < 5e-5 * np.abs(g[:, 2]).max()
+
+
+def _variant_toml(tmp_path, base, edits, tag):
+    """Write a variant of one of the reference option files (absolute data paths) into tmp_path."""
+    import orc
+    txt = open(os.path.join(orc.REFDATA, base)).read()
+    for fl in ("props_cp_voce.txt", "state_cp_voce.txt", "voce_quats.ori", "grains.txt", "custom_dt.txt"):
+        txt = txt.replace('"%s"' % fl, '"%s"' % os.path.join(orc.REFDATA, fl))
+    for a, b in edits:
+        assert a in txt, a
+        txt = txt.replace(a, b)
+    path = os.path.join(str(tmp_path), tag + ".toml")
+    with open(path, "w") as f:
+        f.write(txt)
+    return path
+
+
+@pytest.mark.parametrize("p,assembly,integ,nrls,ref_ser", [(2, "PA", "FULL", False, 0), (2, "EA", "FULL", False, 0),
+                                                           (1, "EA", "BBAR", True, 1), (2, "EA", "BBAR", True, 0)])
+def test_gpu_driver_order2_bbar_matches_oracle(oracle, tmp_path, p, assembly, integ, nrls, ref_ser):
+    """BASELINE config 5 ingredients (p = 2, B-bar, EA, NRLS) on the small regression mesh: GPU driver vs CPU oracle."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    n = 4
+    edits = [('assembly = "PA"', 'assembly = "%s"\n    integ_model = "%s"' % (assembly, integ)),
+             ("prefinement = 1", "p_refinement = %d" % p), ("ref_ser = 1", "ref_ser = %d" % ref_ser)]
+    if nrls:
+        edits.append(("[Solvers.NR]", '[Solvers.NR]\n        nl_solver = "NRLS"'))
+    path = _variant_toml(tmp_path, "voce_pa.toml", edits, "variant")
+    case = orc.load_case(path)
+    assert case["p"] == p and case["integ"] == (1 if integ == "BBAR" else 0) and case["nl_solver"] == (1 if nrls else 0)
+    ref = orc.run_case(case, nsteps=n)
+    d = L.Driver.from_toml(path, out_dir=str(tmp_path))
+    for ti in range(1, n + 1):
+        assert d.step(ti), f"Newton failed at step {ti}"
+    s = d.avgs(0, 6)
+    assert np.linalg.norm(s[:, 2:] - ref["avg_stress"][:, 2:]) / np.linalg.norm(ref["avg_stress"][:, 2:]) < 1e-6
+    newton, krylov, calls = d.stats()
+    assert list(newton) == list(ref["newton_iters"])
