@@ -279,17 +279,37 @@ void SystemDriver::init(const std::vector<double>& props, const std::vector<doub
 void SystemDriver::UpdateEssBdr(const BCEntry& bc) {
    const int nn = part.NN;
    std::fill(ess_host_.begin(), ess_host_.end(), 0); std::fill(ess_val_host_.begin(), ess_val_host_.end(), 0.0);
+   std::vector<uint8_t> vel(ess_host_.size(), 0), vg(ess_host_.size(), 0);
+   have_vel_ = have_vgrad_ = false;
+   for (int k = 0; k < 9; k++) vgrad_[k] = bc.vgrad[k];
    for (size_t b = 0; b < bc.ids.size(); b++) {
       bool c[3] = { false, false, false };
-      switch (bc.comps[b]) { case 1: c[0] = true; break; case 2: c[1] = true; break; case 3: c[2] = true; break; case 4: c[0] = c[1] = true; break;
-                             case 5: c[1] = c[2] = true; break; case 6: c[0] = c[2] = true; break; case 7: c[0] = c[1] = c[2] = true; break; default: break; }
-      for (int g = 0; g < nn; g++) if (part.on_face(g, bc.ids[b])) for (int k = 0; k < 3; k++) if (c[k]) { ess_host_[g + nn * k] = 1; ess_val_host_[g + nn * k] = bc.vals[3 * b + k]; }
+      const bool is_vg = bc.comps[b] < 0;
+      switch (std::abs(bc.comps[b])) { case 1: c[0] = true; break; case 2: c[1] = true; break; case 3: c[2] = true; break; case 4: c[0] = c[1] = true; break;
+                                       case 5: c[1] = c[2] = true; break; case 6: c[0] = c[2] = true; break; case 7: c[0] = c[1] = c[2] = true; break; default: break; }
+      for (int g = 0; g < nn; g++) if (part.on_face(g, bc.ids[b])) for (int k = 0; k < 3; k++) if (c[k]) {
+         ess_host_[g + nn * k] = 1;
+         if (is_vg) { vg[g + nn * k] = 1; vel[g + nn * k] = 0; have_vgrad_ = true; }
+         else { vel[g + nn * k] = 1; vg[g + nn * k] = 0; ess_val_host_[g + nn * k] = bc.vals[3 * b + k]; have_vel_ = true; }
+      }
    }
    oper_->UpdateEssTDofs(ess_host_);
-   ess_val_.upload(ess_val_host_);
+   ess_val_.upload(ess_val_host_); vel_mask_.upload(vel); vg_mask_.upload(vg);
 }
 
-void SystemDriver::UpdateVelocity(double* v) { vk_mask_set(oper_->Height(), oper_->ess_mask.p, ess_val_.p, v, oper_->stream()); }
+// SystemDriver::UpdateVelocity (reference src/system_driver.cpp:326-426): velocity conditions, then the velocity-gradient
+// conditions v = L (x - x_min) evaluated on the current mesh nodes (end of the previous step) for their own essential dofs.
+void SystemDriver::UpdateVelocity(double* v) {
+   NonlinearMechOperator& op = *oper_;
+   hipStream_t s = op.stream();
+   if (have_vel_) vk_mask_set(op.Height(), vel_mask_.p, ess_val_.p, v, s);
+   if (have_vgrad_) {
+      double* org = op.scal.p + 12;
+      if (opt_.vgrad_origin_flag) EXA_HC(hipMemcpyAsync(org, opt_.vgrad_origin, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+      else { vk_min3(part.NN, op.x_cur.p, op.partial.p, org, s); comm.allreduce_min(org, 3, s); }
+      vk_vgrad_velocity(part.NN, vg_mask_.p, op.x_cur.p, org, vgrad_, v, s);
+   }
+}
 
 // device PCG (MFEM CGSolver::Mult with iterative_mode = false); all scalars stay on the device, the host only polls the
 // done-flag every cg_check_every iterations.

@@ -141,6 +141,7 @@ class SystemDriver {
    std::unique_ptr<NonlinearMechOperator> oper_;
    DevBuf<double> r_, c_, xt_, cg_r_, cg_z_, cg_d_, ess_val_;
    std::vector<uint8_t> ess_host_; std::vector<double> ess_val_host_;
+   DevBuf<uint8_t> vel_mask_, vg_mask_; bool have_vel_ = false, have_vgrad_ = false; double vgrad_[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
    double last_dt_ = 0.0;
 };
 

@@ -187,9 +187,10 @@ int exa_options_query(const char* toml_path, double* out, char* err, int errlen)
 int exa_partition_query(const int* N, int rank, int nranks, int64_t* info, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
                         int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs) {
    Partition p; const double L[3] = { 1.0, 1.0, 1.0 };
-   p.build(N, L, rank, nranks, 1);
+   const int order = (info[7] == 2) ? 2 : 1;   // info[7] is in/out: H1 order on input (0/1 -> 1), nodes per element on output
+   p.build(N, L, rank, nranks, order);
    int64_t shared = 0; for (auto& nb : p.nbrs) shared += (int64_t)nb.dofs.size();
-   info[0] = p.E; info[1] = p.NN; info[2] = (int64_t)p.nbrs.size(); info[3] = p.pg[0]; info[4] = p.pg[1]; info[5] = p.pg[2]; info[6] = shared; info[7] = 0;
+   info[0] = p.E; info[1] = p.NN; info[2] = (int64_t)p.nbrs.size(); info[3] = p.pg[0]; info[4] = p.pg[1]; info[5] = p.pg[2]; info[6] = shared; info[7] = p.n;
    if (conn) std::memcpy(conn, p.conn.data(), sizeof(int32_t) * p.conn.size());
    if (X) std::memcpy(X, p.X.data(), sizeof(double) * p.X.size());
    if (elem_gid) std::memcpy(elem_gid, p.elem_gid.data(), sizeof(int64_t) * p.elem_gid.size());

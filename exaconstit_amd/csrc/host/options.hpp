@@ -84,14 +84,15 @@ enum class NLSolver { NR, NRLS };
 enum class XtalType { FCC, BCC };
 enum class SlipType { POWERVOCE, POWERVOCENL, MTSDD };
 
-struct BCEntry { int step; std::vector<int> ids, comps; std::vector<double> vals; };
+// comps < 0: velocity-gradient condition on components |comp| (reference src/option_parser.cpp:178-195)
+struct BCEntry { int step; std::vector<int> ids, comps; std::vector<double> vals; double vgrad[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; };
 
 struct ExaOptions {
    std::string basedir;
    double temp_k = 298.0;
    std::string props_file; int nprops = 0;
    std::string ori_file, grain_file; int num_grains = 0; std::string ori_type = "quat";
-   std::vector<BCEntry> bcs;
+   std::vector<BCEntry> bcs; bool vgrad_origin_flag = false; double vgrad_origin[3] = { 0, 0, 0 };
    XtalType xtal = XtalType::FCC; SlipType slip = SlipType::POWERVOCE;
    bool dt_cust = false, dt_auto = false; std::vector<double> cust_dt; double dt = 1.0, t_final = 1.0;
    double dt_min = 1.0, dt_scale = 0.25; int nsteps = 1;
@@ -121,24 +122,46 @@ struct ExaOptions {
       // BCs (reference src/option_parser.cpp get_bcs): either flat arrays or arrays-of-arrays keyed by update_steps
       const bool changing = d.boolean("BCs.changing_ess_bcs", false);
       const TomlValue* ids = d.get("BCs.essential_ids"); const TomlValue* comps = d.get("BCs.essential_comps"); const TomlValue* vals = d.get("BCs.essential_vals");
-      if (d.has("BCs.essential_vel_grad") || d.boolean("BCs.constant_strain_rate", false)) throw std::runtime_error("Velocity-gradient BCs (essential_vel_grad / negative essential_comps) are not built yet");
-      if (!ids || !comps || !vals) throw std::runtime_error("BCs.essential_ids / essential_comps / essential_vals are required");
+      const TomlValue* vgr = d.get("BCs.essential_vel_grad");
+      if (!ids || !comps) throw std::runtime_error("BCs.essential_ids / essential_comps are required");
+      if (const TomlValue* vo = d.get("BCs.vgrad_origin")) {
+         if (!vo->arr.empty()) { if (vo->arr.size() != 3) throw std::runtime_error("BCs.vgrad_origin when provided must contain 3 components."); vgrad_origin_flag = true; for (int k = 0; k < 3; k++) vgrad_origin[k] = vo->arr[k].num; }
+      }
       auto flat = [](const TomlValue& a) { std::vector<double> o; for (auto& e : a.arr) o.push_back(e.num); return o; };
+      auto fill_vgrad = [](const TomlValue* m, BCEntry& e) {   // [[a,b,c],[d,e,f],[g,h,i]] flattened row by row
+         if (!m) return; int k = 0;
+         for (auto& row : m->arr) for (auto& x : row.arr) { if (k < 9) e.vgrad[k] = x.num; k++; }
+         if (k != 0 && k != 9) throw std::runtime_error("BCs.essential_vel_grad must be a 3 x 3 array");
+      };
       if (changing) {
-         const TomlValue* us = d.get("BCs.update_steps"); if (!us) throw std::runtime_error("BCs.update_steps is required with changing_ess_bcs");
+         const TomlValue* us = d.get("BCs.update_steps"); if (!us) throw std::runtime_error("BCs.update_steps was not provided any values.");
+         bool has1 = false; for (auto& u : us->arr) has1 = has1 || (int)u.num == 1;
+         if (!has1) throw std::runtime_error("BCs.update_steps must contain 1 in the array");
+         if (ids->arr.size() != us->arr.size()) throw std::runtime_error("BCs.essential_ids did not contain the same number of arrays as number of update steps");
+         if (comps->arr.size() != us->arr.size()) throw std::runtime_error("BCs.essential_comps did not contain the same number of arrays as number of update steps");
          for (size_t b = 0; b < us->arr.size(); b++) {
             BCEntry e; e.step = (int)us->arr[b].num;
             for (double v : flat(ids->arr[b])) e.ids.push_back((int)v);
             for (double v : flat(comps->arr[b])) e.comps.push_back((int)v);
-            e.vals = flat(vals->arr[b]); bcs.push_back(e);
+            if (vals && b < vals->arr.size()) e.vals = flat(vals->arr[b]);
+            if (vgr && b < vgr->arr.size()) fill_vgrad(&vgr->arr[b], e);
+            bcs.push_back(e);
          }
       } else {
          BCEntry e; e.step = 1;
          for (double v : flat(*ids)) e.ids.push_back((int)v);
          for (double v : flat(*comps)) e.comps.push_back((int)v);
-         e.vals = flat(*vals); bcs.push_back(e);
+         if (vals) e.vals = flat(*vals);
+         fill_vgrad(vgr, e); bcs.push_back(e);
       }
-      for (auto& e : bcs) { if (e.vals.size() != 3 * e.ids.size() || e.comps.size() != e.ids.size()) throw std::runtime_error("BCs: essential_vals must hold 3 values per essential id"); for (int c : e.comps) if (c < 0) throw std::runtime_error("Velocity-gradient BCs (negative essential_comps) are not built yet"); }
+      for (auto& e : bcs) {
+         if (e.comps.size() != e.ids.size()) throw std::runtime_error("BCs: essential_comps must hold one entry per essential id");
+         bool need_vel = false, need_vg = false; for (int c : e.comps) { if (c > 0) need_vel = true; if (c < 0) need_vg = true; }
+         if (e.vals.empty() && need_vel) throw std::runtime_error("BCs.essential_vals was not provided any values  but a boundary requires this.");
+         if (!vgr && need_vg) throw std::runtime_error("BCs.essential_vel_grad was not provided any values but a boundary requires this.");
+         if (e.vals.empty()) e.vals.assign(3 * e.ids.size(), 0.0);
+         if (e.vals.size() != 3 * e.ids.size()) throw std::runtime_error("BCs: essential_vals must hold 3 values per essential id");
+      }
       if (lower(d.str("Model.mech_type", "")) != "exacmech") throw std::runtime_error("Only mech_type = \"exacmech\" is supported (UMAT is CPU-only in the reference)");
       const std::string xt = lower(d.str("Model.ExaCMech.xtal_type", "")), st = lower(d.str("Model.ExaCMech.slip_type", ""));
       if (xt == "fcc") xtal = XtalType::FCC; else if (xt == "bcc") xtal = XtalType::BCC; else throw std::runtime_error("Unknown xtal_type: " + xt);

@@ -142,6 +142,39 @@ __global__ void k_unpack_add(int64_t n, const int32_t* __restrict__ idx, const d
 }
 
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// coordinate minima for the velocity-gradient BC origin (reference src/system_driver.cpp:355-396): out[d] = min_g x(g,d)
+struct double9 { double a[9]; };
+__global__ void __launch_bounds__(RBLK) k_min3_partial(int64_t nn, const double* __restrict__ x, double* __restrict__ partial) {
+   __shared__ double sm[RBLK];
+   for (int d = 0; d < 3; d++) {
+      double m = 1.7976931348623157e308;
+      for (int64_t i = (int64_t)blockIdx.x * RBLK + threadIdx.x; i < nn; i += (int64_t)gridDim.x * RBLK) m = fmin(m, x[i + nn * d]);
+      sm[threadIdx.x] = m; __syncthreads();
+      for (int st = RBLK / 2; st > 0; st >>= 1) { if ((int)threadIdx.x < st) sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + st]); __syncthreads(); }
+      if (threadIdx.x == 0) partial[blockIdx.x + (int64_t)gridDim.x * d] = sm[0];
+      __syncthreads();
+   }
+}
+__global__ void __launch_bounds__(RBLK) k_min3_final(int nb, const double* __restrict__ partial, double* __restrict__ out) {
+   __shared__ double sm[RBLK];
+   for (int d = 0; d < 3; d++) {
+      double m = 1.7976931348623157e308;
+      for (int i = threadIdx.x; i < nb; i += RBLK) m = fmin(m, partial[i + (int64_t)nb * d]);
+      sm[threadIdx.x] = m; __syncthreads();
+      for (int st = RBLK / 2; st > 0; st >>= 1) { if ((int)threadIdx.x < st) sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + st]); __syncthreads(); }
+      if (threadIdx.x == 0) out[d] = sm[0];
+      __syncthreads();
+   }
+}
+// v(g,i) = sum_j L(i,j) (x(g,j) - x0(j)) on the dofs flagged in m (reference src/system_driver.cpp:400-424)
+__global__ void k_vgrad_velocity(int64_t nn, const uint8_t* __restrict__ m, const double* __restrict__ x, const double* __restrict__ org, double9 L, double* __restrict__ v) {
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= nn) return;
+   const double d0 = x[g] - org[0], d1 = x[g + nn] - org[1], d2 = x[g + 2 * nn] - org[2];
+   for (int i = 0; i < 3; i++) if (m[g + nn * i]) v[g + nn * i] = L.a[3 * i] * d0 + L.a[3 * i + 1] * d1 + L.a[3 * i + 2] * d2;
+}
+
 inline unsigned gblk(int64_t n) { const int64_t b = (n + RBLK - 1) / RBLK; return (unsigned)(b < exa_host::DOT_BLOCKS ? (b > 0 ? b : 1) : exa_host::DOT_BLOCKS); }
 
 }  // namespace
@@ -161,6 +194,15 @@ void vk_dot(int64_t n, int64_t nn, const double* w, const double* a, const doubl
    const unsigned nb = gblk(n);
    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(RBLK), 0, s, n, nn, w, a, b, flag, partial);
    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out);
+}
+void vk_min3(int64_t nn, const double* x, double* partial, double* out3, hipStream_t s) {
+   const unsigned nb = gblk(nn) < (unsigned)(DOT_BLOCKS / 3) ? gblk(nn) : (unsigned)(DOT_BLOCKS / 3);
+   hipLaunchKernelGGL(k_min3_partial, dim3(nb), dim3(RBLK), 0, s, nn, x, partial);
+   hipLaunchKernelGGL(k_min3_final, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, out3);
+}
+void vk_vgrad_velocity(int64_t nn, const uint8_t* m, const double* x, const double* org, const double* L9, double* v, hipStream_t s) {
+   double9 L; for (int i = 0; i < 9; i++) L.a[i] = L9[i];
+   hipLaunchKernelGGL(k_vgrad_velocity, dim3(nblk(nn)), dim3(256), 0, s, nn, m, x, org, L, v);
 }
 void vk_cg_init(double* S, double rel, double abs_, hipStream_t s) { hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1), 0, s, S, rel, abs_); }
 void vk_cg_den(double* S, hipStream_t s) { hipLaunchKernelGGL(k_cg_den, dim3(1), dim3(1), 0, s, S); }

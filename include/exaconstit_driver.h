@@ -52,8 +52,9 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out3, char* err, int 
  *  newton_abs, krylov_iter, krylov_rel, krylov_abs, ref_ser, ncuts0, additional_avgs, number of BC change steps}; returns 0 or -1 (err) */
 int exa_options_query(const char* toml_path, double* out20, char* err, int errlen);
 /* block decomposition of an N0 x N1 x N2 element grid (reference: ParMesh/METIS, src/mechanics_driver.cpp:312): sizes first
- * (info[0..7] = {E, NN, nneighbors, pg0, pg1, pg2, total shared dofs, 0}), then the arrays when the pointers are non-null:
- * conn (8,E), X (NN,3 byNODES), elem_gid (E), weight (NN), nbr_rank (nneighbors), nbr_count (nneighbors), nbr_dofs (concatenated) */
+ * (info[0..7] = {E, NN, nneighbors, pg0, pg1, pg2, total shared dofs, n}; info[7] is in/out: H1 order p on input (0 or 1 -> 1, 2 -> 2),
+ * nodes per element n = (p+1)^3 on output), then the arrays when the pointers are non-null:
+ * conn (n,E) native node order, X (NN,3 byNODES), elem_gid (E), weight (NN), nbr_rank (nneighbors), nbr_count (nneighbors), nbr_dofs (concatenated) */
 int exa_partition_query(const int* N, int rank, int nranks, int64_t* info8, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
                         int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs);
 #ifdef __cplusplus

@@ -13,6 +13,8 @@
 // MFEM's CGSolver (not in /root/reference) is restated from its published algorithm.
 #pragma once
 #include <vector>
+#include <limits>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <chrono>
@@ -26,8 +28,10 @@ enum Precond { PC_IDENTITY = 0, PC_JACOBI = 1 };   // IDENTITY reproduces the re
 
 struct BCSet {            // one entry per step at which the essential BCs change (BCManager)
    int step;              // 1-based
-   std::vector<int> ids, comps;
+   std::vector<int> ids, comps;   // comps < 0: velocity-gradient condition on components |comp| (option_parser.cpp:178-195)
    std::vector<double> vals;   // 3 per id
+   double vgrad[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // essential_vel_grad, row-major as written in the option file
+   bool has_origin = false; double origin[3] = { 0, 0, 0 };   // BCs.vgrad_origin
 };
 
 struct Config {
@@ -62,7 +66,7 @@ struct Sim {
    int nstatev, E, Q, n, NN, ND; size_t P;
    std::vector<double> x_ref, x_beg, x_cur, v_sol;
    std::vector<double> stress0, stress1, state0, state1, matgrad, J;
-   std::vector<char> ess; std::vector<double> ess_val;
+   std::vector<char> ess, ess_vg; std::vector<double> ess_val; double vgrad[9]; bool vg_has_origin = false; double vg_origin[3];
    std::vector<double> dmat, C4, D4, emat, diag, dinv, eDS;
    double dt = 0;
    Result* res = nullptr;
@@ -83,7 +87,7 @@ inline void sim_init(Sim& s, const Config& cfg) {
    s.stress0.assign(6 * s.P, 0.0); s.stress1.assign(6 * s.P, 0.0);
    s.state0.assign(s.nstatev * s.P, 0.0); s.state1.assign(s.nstatev * s.P, 0.0);
    s.matgrad.assign(36 * s.P, 0.0); s.J.assign(9 * s.P, 0.0);
-   s.ess.assign(s.ND, 0); s.ess_val.assign(s.ND, 0.0);
+   s.ess.assign(s.ND, 0); s.ess_vg.assign(s.ND, 0); s.ess_val.assign(s.ND, 0.0);
    s.diag.assign(s.ND, 1.0); s.dinv.assign(s.ND, 1.0);
    s.mo.po.second_order_terms = cfg.second_order_terms; s.mo.po.use_input_temperature = cfg.use_input_temperature;
    // initial state: library history defaults, grain quaternion spliced at offset 9, rel. volume 1, e_int 0
@@ -111,16 +115,39 @@ inline void comp_mask(int code, bool c[3]) {
 }
 
 inline void update_ess_bdr(Sim& s, const BCSet& bc) {
-   std::fill(s.ess.begin(), s.ess.end(), 0); std::fill(s.ess_val.begin(), s.ess_val.end(), 0.0);
+   std::fill(s.ess.begin(), s.ess.end(), 0); std::fill(s.ess_vg.begin(), s.ess_vg.end(), 0); std::fill(s.ess_val.begin(), s.ess_val.end(), 0.0);
+   for (int i = 0; i < 9; i++) s.vgrad[i] = bc.vgrad[i];
+   s.vg_has_origin = bc.has_origin; for (int i = 0; i < 3; i++) s.vg_origin[i] = bc.origin[i];
    for (size_t b = 0; b < bc.ids.size(); b++) {
-      bool c[3]; comp_mask(bc.comps[b], c);
+      bool c[3]; comp_mask(std::abs(bc.comps[b]), c);
+      const bool vg = bc.comps[b] < 0;
       for (int g = 0; g < s.NN; g++) if (node_on_face(s.mesh, g, bc.ids[b])) for (int k = 0; k < 3; k++) if (c[k]) {
-         s.ess[g + s.NN * k] = 1; s.ess_val[g + s.NN * k] = bc.vals[3 * b + k];
+         s.ess[g + s.NN * k] = 1;
+         if (vg) s.ess_vg[g + s.NN * k] = 1; else s.ess_val[g + s.NN * k] = bc.vals[3 * b + k];
       }
    }
 }
 
-inline void update_velocity(Sim& s, std::vector<double>& v) { for (int i = 0; i < s.ND; i++) if (s.ess[i]) v[i] = s.ess_val[i]; }
+// SystemDriver::UpdateVelocity (system_driver.cpp:326-426): velocity conditions first, then the velocity-gradient
+// conditions v = L (x - x_min) evaluated on the mesh nodes of the moment (= end-of-previous-step coordinates,
+// mechanics_driver.cpp:829-832) overwrite their own essential dofs.
+inline void update_velocity(Sim& s, std::vector<double>& v) {
+   for (int i = 0; i < s.ND; i++) if (s.ess[i] && !s.ess_vg[i]) v[i] = s.ess_val[i];
+   bool any = false; for (int i = 0; i < s.ND && !any; i++) any = s.ess_vg[i];
+   if (!any) return;
+   double xmin[3];
+   for (int d = 0; d < 3; d++) {
+      if (s.vg_has_origin) { xmin[d] = s.vg_origin[d]; continue; }
+      double m = std::numeric_limits<double>::max();
+      for (int g = 0; g < s.NN; g++) m = std::min(m, s.x_cur[g + s.NN * d]);
+      xmin[d] = m;
+   }
+   for (int g = 0; g < s.NN; g++) for (int ii = 0; ii < 3; ii++) if (s.ess_vg[g + s.NN * ii]) {
+      double a = 0;
+      for (int jj = 0; jj < 3; jj++) a += s.vgrad[3 * ii + jj] * (s.x_cur[g + s.NN * jj] - xmin[jj]);
+      v[g + s.NN * ii] = a;
+   }
+}
 
 // NonlinearMechOperator::Setup<upd_crds>
 inline void op_setup(Sim& s, const std::vector<double>& v, bool upd_crds) {

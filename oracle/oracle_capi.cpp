@@ -11,6 +11,7 @@ struct orc_case {
    int ngrains; const int* elem_grain; const double* quats;
    int nsteps; const double* dts;
    int nbc; const int* bc_step; const int* bc_nids; const int* bc_ids; const int* bc_comps; const double* bc_vals;   // flattened
+   const double* bc_vgrad;   // 9 per BC set (row-major essential_vel_grad), may be null
    int assembly, nl_solver, precond, integ;
    double newton_rel, newton_abs; int newton_iter;
    double krylov_rel, krylov_abs; int krylov_iter;
@@ -39,6 +40,7 @@ int orc_run_case(const orc_case* c, orc_result* r) {
          for (int k = 0; k < 3; k++) bc.vals.push_back(c->bc_vals[3 * (off + i) + k]);
       }
       off += c->bc_nids[b];
+      if (c->bc_vgrad) for (int k = 0; k < 9; k++) bc.vgrad[k] = c->bc_vgrad[9 * b + k];
       cfg.bcs.push_back(bc);
    }
    cfg.assembly = c->assembly; cfg.nl_solver = c->nl_solver; cfg.precond = c->precond; cfg.integ = c->integ;

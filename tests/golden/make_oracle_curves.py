@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import orc  # noqa: E402
 
-CASES = {"voce_pa": None, "voce_bcc": None, "voce_ea": None, "voce_nl_full": None, "mtsdd_full": None, "mtsdd_bcc": None, "voce_full_cyclic": None}
+CASES = {"voce_pa": None, "voce_bcc": None, "voce_ea": None, "voce_nl_full": None, "mtsdd_full": None, "mtsdd_bcc": None, "voce_full_cyclic": None,
+         "voce_ea_cs": None, "voce_full_cyclic_cs": None, "voce_full_cyclic_csm": None}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(CASES)

@@ -54,7 +54,7 @@ class OrcCase(C.Structure):
                 ("xtal", C.c_int), ("kin", C.c_int), ("nprops", C.c_int), ("props", dp), ("temp_k", C.c_double),
                 ("ngrains", C.c_int), ("elem_grain", ip), ("quats", dp),
                 ("nsteps", C.c_int), ("dts", dp),
-                ("nbc", C.c_int), ("bc_step", ip), ("bc_nids", ip), ("bc_ids", ip), ("bc_comps", ip), ("bc_vals", dp),
+                ("nbc", C.c_int), ("bc_step", ip), ("bc_nids", ip), ("bc_ids", ip), ("bc_comps", ip), ("bc_vals", dp), ("bc_vgrad", dp),
                 ("assembly", C.c_int), ("nl_solver", C.c_int), ("precond", C.c_int), ("integ", C.c_int),
                 ("newton_rel", C.c_double), ("newton_abs", C.c_double), ("newton_iter", C.c_int),
                 ("krylov_rel", C.c_double), ("krylov_abs", C.c_double), ("krylov_iter", C.c_int),
@@ -105,10 +105,15 @@ def load_case(toml_name, datadir=REFDATA):
     bcs = t["BCs"]
     if bcs.get("changing_ess_bcs", False):
         steps = bcs["update_steps"]
-        ids, comps, vals = bcs["essential_ids"], bcs["essential_comps"], bcs["essential_vals"]
+        ids, comps = bcs["essential_ids"], bcs["essential_comps"]
+        vals = bcs.get("essential_vals", [[0.0] * (3 * len(i)) for i in ids])
+        vgrad = bcs.get("essential_vel_grad", [[[0.0] * 3] * 3 for _ in steps])
     else:
         steps = [1]
-        ids, comps, vals = [bcs["essential_ids"]], [bcs["essential_comps"]], [bcs["essential_vals"]]
+        ids, comps = [bcs["essential_ids"]], [bcs["essential_comps"]]
+        vals = [bcs.get("essential_vals", [0.0] * (3 * len(ids[0])))]
+        vgrad = [bcs.get("essential_vel_grad", [[0.0] * 3] * 3)]
+    vgrad = [[float(x) for row in m for x in row] for m in vgrad]
     sol = t["Solvers"]
     ecm = t["Model"]["ExaCMech"]
     vis = t.get("Visualizations", {})
@@ -116,7 +121,7 @@ def load_case(toml_name, datadir=REFDATA):
         nx=nx, ny=ny, nz=nz, p=int(mesh.get("p_refinement", 1)), length=[float(x) for x in length],
         xtal=XTAL[ecm["xtal_type"].lower()], kin=KIN[ecm["slip_type"].lower()], props=props,
         temp_k=float(t["Properties"]["temperature"]), elem_grain=eg, quats=np.ascontiguousarray(quats, dtype=np.float64),
-        dts=dts, auto=auto, bc_steps=steps, bc_ids=ids, bc_comps=comps, bc_vals=vals,
+        dts=dts, auto=auto, bc_steps=steps, bc_ids=ids, bc_comps=comps, bc_vals=vals, bc_vgrad=vgrad,
         assembly=ASM[sol.get("assembly", "FULL").lower()], nl_solver=NLS[sol.get("NR", {}).get("nl_solver", "NR").lower()],
         newton_rel=sol["NR"]["rel_tol"], newton_abs=sol["NR"]["abs_tol"], newton_iter=sol["NR"]["iter"],
         krylov_rel=sol["Krylov"]["rel_tol"], krylov_abs=sol["Krylov"]["abs_tol"], krylov_iter=sol["Krylov"]["iter"],
@@ -140,10 +145,11 @@ def run_case(case, nsteps=None, precond=0, second_order_terms=False, use_input_t
     bc_ids = np.array([i for x in case["bc_ids"] for i in x], dtype=np.int32)
     bc_comps = np.array([i for x in case["bc_comps"] for i in x], dtype=np.int32)
     bc_vals = np.array([v for x in case["bc_vals"] for v in x], dtype=np.float64)
+    bc_vgrad = np.array([v for x in case.get("bc_vgrad", [[0.0] * 9] * len(bc_step)) for v in x], dtype=np.float64)
     c = OrcCase(case["nx"], case["ny"], case["nz"], case["p"], *case["length"],
                 case["xtal"], case["kin"], len(props), _p(props), case["temp_k"],
                 quats.shape[0], _ip(eg), _p(quats), ns, _p(dts),
-                len(bc_step), _ip(bc_step), _ip(bc_nids), _ip(bc_ids), _ip(bc_comps), _p(bc_vals),
+                len(bc_step), _ip(bc_step), _ip(bc_nids), _ip(bc_ids), _ip(bc_comps), _p(bc_vals), _p(bc_vgrad),
                 case["assembly"], case["nl_solver"], precond, int(case.get("integ", 0)),
                 case["newton_rel"], case["newton_abs"], case["newton_iter"],
                 case["krylov_rel"], case["krylov_abs"], case["krylov_iter"],

@@ -4,26 +4,29 @@ import ctypes as C
 import numpy as np
 
 
-def query(N, rank, nranks):
+def query(N, rank, nranks, order=1):
     import exaconstit_amd.lib as L
     Nc = (C.c_int * 3)(*N)
     info = (C.c_int64 * 8)()
+    info[7] = order
     L.exa_partition_query(Nc, rank, nranks, info, None, None, None, None, None, None, None)
-    E, NN, nnb, shared = info[0], info[1], info[2], info[6]
-    conn = np.zeros(8 * E, np.int32); X = np.zeros(3 * NN); gid = np.zeros(E, np.int64); w = np.zeros(NN)
+    E, NN, nnb, shared, n = info[0], info[1], info[2], info[6], info[7]
+    conn = np.zeros(n * E, np.int32); X = np.zeros(3 * NN); gid = np.zeros(E, np.int64); w = np.zeros(NN)
     nr = np.zeros(max(nnb, 1), np.int32); nc = np.zeros(max(nnb, 1), np.int32); nd = np.zeros(max(shared, 1), np.int32)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    info[7] = order
     L.exa_partition_query(Nc, rank, nranks, info, vp(conn), vp(X), vp(gid), vp(w), vp(nr), vp(nc), vp(nd))
     nbrs = []
     off = 0
     for i in range(nnb):
         nbrs.append((int(nr[i]), nd[off:off + nc[i]].copy()))
         off += nc[i]
-    return dict(E=E, NN=NN, pg=(info[3], info[4], info[5]), conn=conn.reshape(E, 8), X=X.reshape(3, NN), gid=gid, weight=w, nbrs=nbrs)
+    return dict(E=E, NN=NN, pg=(info[3], info[4], info[5]), conn=conn.reshape(E, n), order=order, X=X.reshape(3, NN), gid=gid, weight=w, nbrs=nbrs)
 
 
 def global_node_ids(part, N):
     """global lexicographic node id of every local node, from its coordinates on the unit cube"""
     X = part["X"]
-    i = np.rint(X[0] * N[0]).astype(np.int64); j = np.rint(X[1] * N[1]).astype(np.int64); k = np.rint(X[2] * N[2]).astype(np.int64)
-    return i + (N[0] + 1) * (j + (N[1] + 1) * k)
+    p = part.get("order", 1)
+    i = np.rint(X[0] * N[0] * p).astype(np.int64); j = np.rint(X[1] * N[1] * p).astype(np.int64); k = np.rint(X[2] * N[2] * p).astype(np.int64)
+    return i + (N[0] * p + 1) * (j + (N[1] * p + 1) * k)

@@ -109,3 +109,26 @@ def test_gpu_driver_order2_bbar_matches_oracle(oracle, tmp_path, p, assembly, in
     assert np.linalg.norm(s[:, 2:] - ref["avg_stress"][:, 2:]) / np.linalg.norm(ref["avg_stress"][:, 2:]) < 1e-6
     newton, krylov, calls = d.stats()
     assert list(newton) == list(ref["newton_iters"])
+
+
+def test_velocity_gradient_bcs_match_golden(oracle, tmp_path):
+    """voce_ea_cs: constant true strain rate via essential_vel_grad (reference src/system_driver.cpp:338-426)."""
+    orc = oracle
+    n = 12
+    d = _run("voce_ea_cs", n, tmp_path)
+    g = orc.golden("voce_ea_cs_stress.txt")[:n]
+    s = d.avgs(0, 6)
+    assert np.max(np.abs(s[:, 2] / g[:, 2] - 1.0)) < 3e-6
+    gF = orc.golden("voce_ea_cs_def_grad.txt")[:n]
+    assert np.max(np.abs(d.avgs(1, 9) - gF)) < 6e-6
+
+
+@pytest.mark.parametrize("name", ["voce_full_cyclic_cs", "voce_full_cyclic_csm"])
+def test_cyclic_velocity_gradient_bcs(oracle, tmp_path, name):
+    orc = oracle
+    n = 14
+    d = _run(name, n, tmp_path)
+    g = orc.golden(name + "_stress.txt")[:n]
+    s = d.avgs(0, 6)
+    assert np.max(np.abs(s[:10, 2] / g[:10, 2] - 1.0)) < 6e-6
+    assert np.max(np.abs(s[:, 2] - g[:, 2])) < 5e-5 * np.abs(g[:, 2]).max()

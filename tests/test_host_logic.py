@@ -37,22 +37,33 @@ def test_options_reader_matches_reference_schema():
 
 def test_options_reader_rejects_unsupported(tmp_path):
     txt = open(os.path.join(REF, "voce_ea_cs.toml")).read()
-    rc, _, msg = _q("voce_ea_cs.toml")
-    assert rc == -1 and "Velocity-gradient" in msg          # negative essential_comps: not built yet, must fail loudly
-    bad = tmp_path / "bad.toml"
-    bad.write_text(txt.replace('mech_type = "exacmech"', 'mech_type = "umat"'))
     import exaconstit_amd.lib as L
-    out = np.zeros(20); err = C.create_string_buffer(512)
-    assert L.exa_options_query(str(bad).encode(), out.ctypes.data_as(C.POINTER(C.c_double)), err, 512) == -1
+
+    def q(text):
+        for fl in ("props_cp_voce.txt", "state_cp_voce.txt", "voce_quats.ori", "grains.txt", "custom_dt.txt"):
+            text = text.replace('"%s"' % fl, '"%s"' % os.path.join(REF, fl))
+        bad = tmp_path / "bad.toml"
+        bad.write_text(text)
+        out = np.zeros(20); err = C.create_string_buffer(512)
+        return L.exa_options_query(str(bad).encode(), out.ctypes.data_as(C.POINTER(C.c_double)), err, 512), err.value.decode()
+
+    rc, _, msg = _q("voce_ea_cs.toml")
+    assert rc == 0                                           # velocity-gradient BCs (negative essential_comps) parse
+    rc, msg = q(txt.replace("essential_vel_grad", "unused_key"))
+    assert rc == -1 and "essential_vel_grad was not provided" in msg      # reference src/option_parser.cpp:217-219
+    rc, msg = q(txt.replace('mech_type = "exacmech"', 'mech_type = "umat"'))
+    assert rc == -1 and "exacmech" in msg
+    rc, msg = q(txt.replace('assembly = "EA"', 'assembly = "PA"\n    integ_model = "BBAR"'))
+    assert rc == -1 and "BBAR" in msg                        # no partial-assembly gradient for B-bar (reference README.md:20)
 
 
-@pytest.mark.parametrize("nranks", [1, 2, 3, 4, 8])
-def test_block_decomposition_is_a_partition(nranks):
+@pytest.mark.parametrize("nranks,order", [(1, 1), (2, 1), (3, 1), (4, 1), (8, 1), (1, 2), (4, 2)])
+def test_block_decomposition_is_a_partition(nranks, order):
     N = (6, 5, 4)
-    parts = [pu.query(N, r, nranks) for r in range(nranks)]
+    parts = [pu.query(N, r, nranks, order) for r in range(nranks)]
     gids = np.concatenate([p["gid"] for p in parts])
     assert sorted(gids.tolist()) == list(range(N[0] * N[1] * N[2]))            # every element exactly once
-    nn_glob = (N[0] + 1) * (N[1] + 1) * (N[2] + 1)
+    nn_glob = (N[0] * order + 1) * (N[1] * order + 1) * (N[2] * order + 1)
     wsum = np.zeros(nn_glob)
     for p in parts:
         g = pu.global_node_ids(p, N)
@@ -62,6 +73,10 @@ def test_block_decomposition_is_a_partition(nranks):
         X = p["X"]; c = p["conn"]
         d = X[:, c[:, 6]] - X[:, c[:, 0]]
         assert np.allclose(d, np.array([[1 / N[0]], [1 / N[1]], [1 / N[2]]]))
+        if order == 2:      # native order: the volume-interior node (index 26) is the cell centre, edge 0-1 midpoint is node 8
+            assert np.allclose(X[:, c[:, 26]], 0.5 * (X[:, c[:, 0]] + X[:, c[:, 6]]))
+            assert np.allclose(X[:, c[:, 8]], 0.5 * (X[:, c[:, 0]] + X[:, c[:, 1]]))
+            assert np.allclose(X[:, c[:, 20]], 0.25 * (X[:, c[:, 0]] + X[:, c[:, 1]] + X[:, c[:, 2]] + X[:, c[:, 3]]))
     assert np.allclose(wsum, 1.0)                                               # duplicated nodes count once in dot products
     # neighbour lists are symmetric and enumerate the same global dofs in the same order on both sides
     for r, p in enumerate(parts):

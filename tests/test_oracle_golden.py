@@ -15,7 +15,7 @@ import pytest
 
 CURVES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_curves")
 
-LIVE = [("voce_pa", "voce_pa", 4, 3e-6), ("voce_bcc", "voce_bcc", 3, 3e-6), ("voce_nl_full", "voce_full", 3, 3e-6),
+LIVE = [("voce_pa", "voce_pa", 4, 3e-6), ("voce_ea_cs", "voce_ea_cs", 3, 3e-6), ("voce_bcc", "voce_bcc", 3, 3e-6), ("voce_nl_full", "voce_full", 3, 3e-6),
         ("mtsdd_full", "mtsdd_full", 5, 2e-5), ("mtsdd_bcc", "mtsdd_bcc", 5, 2e-5)]
 
 
@@ -34,7 +34,7 @@ def test_live_steps_match_golden(oracle, name, gold, nsteps, tol):
         assert np.allclose(s, st, rtol=1e-9, atol=1e-16)
 
 
-STORED = [("voce_pa", "voce_pa", 3e-6), ("voce_bcc", "voce_bcc", 3e-6), ("voce_nl_full", "voce_full", 3e-6), ("voce_ea", "voce_ea", 3e-6),
+STORED = [("voce_pa", "voce_pa", 3e-6), ("voce_bcc", "voce_bcc", 3e-6), ("voce_nl_full", "voce_full", 3e-6), ("voce_ea", "voce_ea", 3e-6), ("voce_ea_cs", "voce_ea_cs", 3e-6),
           ("mtsdd_full", "mtsdd_full", 2e-5), ("mtsdd_bcc", "mtsdd_bcc", 2e-5)]
 
 
@@ -77,3 +77,31 @@ def test_stored_cyclic_curve(oracle):
     assert s.shape == g.shape
     assert np.max(np.abs(s[:, 2] - g[:, 2])) < 5e-5 * np.abs(g[:, 2]).max()
     assert np.max(np.abs(s[:10, 2] / g[:10, 2] - 1.0)) < 6e-6
+
+
+@pytest.mark.parametrize("name", ["voce_full_cyclic_cs", "voce_full_cyclic_csm"])
+def test_stored_cyclic_velocity_gradient_curves(oracle, name):
+    """Constant-true-strain-rate (velocity-gradient) boundary conditions with load reversals
+    (reference src/system_driver.cpp:338-426); same Newton-tolerance caveat as the velocity-driven cyclic case."""
+    orc = oracle
+    f = os.path.join(CURVES, name + ".npz")
+    if not os.path.exists(f):
+        pytest.skip("stored curve not generated")
+    s = np.load(f)["avg_stress"]
+    g = orc.golden(name + "_stress.txt")
+    assert s.shape == g.shape
+    assert np.max(np.abs(s[:, 2] - g[:, 2])) < 5e-5 * np.abs(g[:, 2]).max()
+    assert np.max(np.abs(s[:10, 2] / g[:10, 2] - 1.0)) < 6e-6
+
+
+def test_stored_voce_ea_cs_extra_outputs(oracle):
+    orc = oracle
+    f = os.path.join(CURVES, "voce_ea_cs.npz")
+    if not os.path.exists(f):
+        pytest.skip("stored curve not generated")
+    z = np.load(f)
+    assert np.max(np.abs(z["avg_def_grad"] - orc.golden("voce_ea_cs_def_grad.txt"))) < 6e-6
+    gw = orc.golden("voce_ea_cs_pl_work.txt").ravel()
+    assert np.max(np.abs(z["avg_pl_work"][1:] / gw[1:] - 1.0)) < 5e-5
+    gd = orc.golden("voce_ea_cs_dp_tensor.txt")
+    assert np.max(np.abs(z["avg_dp_tensor"] - gd)) < 5e-5 * np.abs(gd).max()
