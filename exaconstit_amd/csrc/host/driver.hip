@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 
 extern "C" int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, exa_stream s);
@@ -422,6 +423,7 @@ bool SystemDriver::Solve(double* x) {
    }
    if (iter > 0) time = time - dt_old + dt_class;
    last_dt_ = dt_class;
+   if (ok && write_files && comm.rank == 0) { std::ofstream f(out_dir + "/" + opt_.auto_dt_fname, std::ios_base::app); f << std::setprecision(12) << dt_class << std::endl; }
    const double niter_scale = (double)opt_.newton_iter * opt_.dt_scale;
    const double nr_iter = std::max(1, st.newton_iters);
    dt_class *= niter_scale / nr_iter; if (dt_class < opt_.dt_min) dt_class = opt_.dt_min;

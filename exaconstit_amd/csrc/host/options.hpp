@@ -5,6 +5,7 @@
 // with the reference's wording where one exists.
 #pragma once
 #include <cctype>
+#include <cmath>
 #include <cstdlib>
 #include <fstream>
 #include <map>
@@ -95,7 +96,7 @@ struct ExaOptions {
    std::vector<BCEntry> bcs; bool vgrad_origin_flag = false; double vgrad_origin[3] = { 0, 0, 0 };
    XtalType xtal = XtalType::FCC; SlipType slip = SlipType::POWERVOCE;
    bool dt_cust = false, dt_auto = false; std::vector<double> cust_dt; double dt = 1.0, t_final = 1.0;
-   double dt_min = 1.0, dt_scale = 0.25; int nsteps = 1;
+   double dt_min = 1.0, dt_scale = 0.25; int nsteps = 1; std::string auto_dt_fname = "auto_dt_out.txt";
    std::string avg_stress_fname = "avg_stress.txt", avg_def_grad_fname = "avg_def_grad.txt", avg_pl_work_fname = "avg_pl_work.txt", avg_dp_tensor_fname = "avg_dp_tensor.txt";
    bool additional_avgs = false;
    Assembly assembly = Assembly::EA; NLSolver nl_solver = NLSolver::NR; std::string integ_model = "FULL";
@@ -173,7 +174,9 @@ struct ExaOptions {
          if ((int)cust_dt.size() < nsteps) throw std::runtime_error("Custom dt file has fewer entries than nsteps");
       } else if (d.has_table("Time.Auto")) {
          dt_auto = true; dt = d.num("Time.Auto.dt_start", 1.0); dt_min = d.num("Time.Auto.dt_min", 1.0); dt_scale = d.num("Time.Auto.dt_scale", 0.25); t_final = d.num("Time.Auto.t_final", 1.0);
-         nsteps = 1000000;
+         auto_dt_fname = d.str("Time.Auto.auto_dt_file", "auto_dt_out.txt");
+         if (dt_scale < 0.0 || dt_scale > 1.0) throw std::runtime_error("dt_scale for auto time stepping needs to be between 0 and 1.");
+         nsteps = (int)std::ceil(t_final / dt_min);   // reference src/mechanics_driver.cpp:212
       } else { dt = d.num("Time.Fixed.dt", 1.0); t_final = d.num("Time.Fixed.t_final", 1.0); nsteps = (int)std::ceil(t_final / dt - 1e-9); }
       avg_stress_fname = d.str("Visualizations.avg_stress_fname", "avg_stress.txt");
       additional_avgs = d.boolean("Visualizations.additional_avgs", false);

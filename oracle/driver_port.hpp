@@ -42,6 +42,7 @@ struct Config {
    std::vector<double> dts;            // one per step
    std::vector<BCSet> bcs;
    int assembly = ASM_PA, nl_solver = NL_NR, precond = PC_IDENTITY;
+   bool dt_auto = false; double dt_start = 1.0, dt_min = 1.0, dt_scale = 0.25, t_final = 1.0; int max_steps = 0;   // Time.Auto (system_driver.cpp:43-48,225-275)
    int integ = 0;                      // 0 full integration, 1 B-bar (ICExaNLFIntegrator; element assembly only, README.md:20)
    double newton_rel = 5e-5, newton_abs = 5e-10; int newton_iter = 25;
    double krylov_rel = 1e-7, krylov_abs = 1e-27; int krylov_iter = 1000;
@@ -57,6 +58,7 @@ struct Result {
    std::vector<double> avg_pl_work;    // 1 per step
    std::vector<double> avg_dp_tensor;  // 6 per step
    std::vector<int> newton_iters, krylov_iters, model_calls;
+   std::vector<double> dts_used;       // dt of every completed step (auto time stepping: the reference's auto_dt_out.txt)
    long qpt_updates = 0; double t_model = 0, t_krylov = 0, t_total = 0;
    int failed = 0;
 };
@@ -335,10 +337,13 @@ inline void update_model(Sim& s, Result& res) {
 
 inline void run_case(const Config& cfg, Result& res) {
    Sim s; sim_init(s, cfg); s.res = &res;
-   const int nsteps = (int)cfg.dts.size();
+   const int nsteps = cfg.dt_auto ? cfg.max_steps : (int)cfg.dts.size();
    double t_start = now();
+   double t = 0.0, dt_class = cfg.dt_start;
    for (int ti = 1; ti <= nsteps; ti++) {
-      s.dt = cfg.dts[ti - 1];
+      // mechanics_driver.cpp:842-855
+      s.dt = cfg.dt_auto ? std::min(dt_class, cfg.t_final - t) : cfg.dts[ti - 1];
+      t += s.dt; if (cfg.dt_auto) dt_class = s.dt;
       s.model_calls = 0; s.krylov_total = 0;
       if (cfg.verbose) std::printf("step %d dt %g\n", ti, s.dt);
       for (const BCSet& bc : cfg.bcs) if (bc.step == ti) {
@@ -349,11 +354,30 @@ inline void run_case(const Config& cfg, Result& res) {
       }
       update_velocity(s, s.v_sol);
       int iters = 0;
-      bool ok = newton_solve(s, s.v_sol, iters);
+      bool ok;
+      if (!cfg.dt_auto) ok = newton_solve(s, s.v_sol, iters);
+      else {   // SystemDriver::Solve, auto_time branch (system_driver.cpp:225-275)
+         const double dt_old = dt_class;
+         const std::vector<double> xprev(s.v_sol);
+         ok = newton_solve(s, s.v_sol, iters);
+         int retry = 0;
+         while (!ok && retry < 2) {
+            s.v_sol = xprev;
+            dt_class *= cfg.dt_scale; if (dt_class < cfg.dt_min) dt_class = cfg.dt_min;
+            s.dt = dt_class;
+            ok = newton_solve(s, s.v_sol, iters); retry++;
+         }
+         if (retry > 0) t = t - dt_old + dt_class;
+         res.dts_used.push_back(dt_class);
+         const double niter_scale = (double)cfg.newton_iter * cfg.dt_scale;
+         dt_class *= niter_scale / (double)std::max(1, iters); if (dt_class < cfg.dt_min) dt_class = cfg.dt_min;
+      }
       if (!ok) { res.failed += 1000000; if (cfg.verbose) std::printf("Newton failed at step %d\n", ti); }
       res.newton_iters.push_back(iters); res.krylov_iters.push_back((int)s.krylov_total); res.model_calls.push_back(s.model_calls);
+      if (cfg.dt_auto && !ok) break;
       update_model(s, res);
       s.x_beg = s.x_cur;
+      if (cfg.dt_auto && std::fabs(t - cfg.t_final) <= std::fabs(1e-3 * s.dt)) break;   // last_step (mechanics_driver.cpp:856)
    }
    res.t_total = now() - t_start;
 }

@@ -16,12 +16,14 @@ struct orc_case {
    double newton_rel, newton_abs; int newton_iter;
    double krylov_rel, krylov_abs; int krylov_iter;
    int additional_avgs, second_order_terms, use_input_temperature, verbose;
+   int dt_auto; double dt_start, dt_min, dt_scale, t_final;   // Time.Auto; nsteps is then the row capacity of the result arrays
 };
 
 struct orc_result {
    double* avg_stress; double* avg_def_grad; double* avg_pl_work; double* avg_dp_tensor;   // caller-allocated, nsteps rows
    int* newton_iters; int* krylov_iters; int* model_calls;
    int64_t qpt_updates; double t_model, t_krylov, t_total; int failed;
+   int steps_done; double* dts_used;   // auto time stepping: rows actually produced, dt per row (may be null)
 };
 
 int orc_run_case(const orc_case* c, orc_result* r) {
@@ -31,7 +33,8 @@ int orc_run_case(const orc_case* c, orc_result* r) {
    const int E = c->nx * c->ny * c->nz;
    cfg.elem_grain.assign(c->elem_grain, c->elem_grain + E);
    cfg.quats.assign(c->quats, c->quats + 4 * c->ngrains);
-   cfg.dts.assign(c->dts, c->dts + c->nsteps);
+   if (c->dt_auto) { cfg.dt_auto = true; cfg.dt_start = c->dt_start; cfg.dt_min = c->dt_min; cfg.dt_scale = c->dt_scale; cfg.t_final = c->t_final; cfg.max_steps = c->nsteps; }
+   else cfg.dts.assign(c->dts, c->dts + c->nsteps);
    int off = 0;
    for (int b = 0; b < c->nbc; b++) {
       drv::BCSet bc; bc.step = c->bc_step[b];
@@ -50,14 +53,16 @@ int orc_run_case(const orc_case* c, orc_result* r) {
    cfg.use_input_temperature = c->use_input_temperature != 0; cfg.verbose = c->verbose;
    drv::Result res;
    drv::run_case(cfg, res);
-   const int ns = c->nsteps;
+   const int ns = (int)(res.avg_stress.size() / 6);   // completed steps (== c->nsteps unless auto time stepping stopped early)
+   r->steps_done = ns;
+   if (r->dts_used) for (size_t i = 0; i < res.dts_used.size() && (int)i < c->nsteps; i++) r->dts_used[i] = res.dts_used[i];
    for (int i = 0; i < 6 * ns; i++) r->avg_stress[i] = res.avg_stress[i];
    if (cfg.additional_avgs) {
       for (int i = 0; i < 9 * ns; i++) r->avg_def_grad[i] = res.avg_def_grad[i];
       for (int i = 0; i < ns; i++) r->avg_pl_work[i] = res.avg_pl_work[i];
       for (int i = 0; i < 6 * ns; i++) r->avg_dp_tensor[i] = res.avg_dp_tensor[i];
    }
-   for (int i = 0; i < ns; i++) { r->newton_iters[i] = res.newton_iters[i]; r->krylov_iters[i] = res.krylov_iters[i]; r->model_calls[i] = res.model_calls[i]; }
+   for (int i = 0; i < ns && i < (int)res.newton_iters.size(); i++) { r->newton_iters[i] = res.newton_iters[i]; r->krylov_iters[i] = res.krylov_iters[i]; r->model_calls[i] = res.model_calls[i]; }
    r->qpt_updates = res.qpt_updates; r->t_model = res.t_model; r->t_krylov = res.t_krylov; r->t_total = res.t_total; r->failed = res.failed;
    return res.failed;
 }

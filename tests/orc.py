@@ -59,14 +59,15 @@ class OrcCase(C.Structure):
                 ("newton_rel", C.c_double), ("newton_abs", C.c_double), ("newton_iter", C.c_int),
                 ("krylov_rel", C.c_double), ("krylov_abs", C.c_double), ("krylov_iter", C.c_int),
                 ("additional_avgs", C.c_int), ("second_order_terms", C.c_int), ("use_input_temperature", C.c_int),
-                ("verbose", C.c_int)]
+                ("verbose", C.c_int),
+                ("dt_auto", C.c_int), ("dt_start", C.c_double), ("dt_min", C.c_double), ("dt_scale", C.c_double), ("t_final", C.c_double)]
 
 
 class OrcResult(C.Structure):
     _fields_ = [("avg_stress", dp), ("avg_def_grad", dp), ("avg_pl_work", dp), ("avg_dp_tensor", dp),
                 ("newton_iters", ip), ("krylov_iters", ip), ("model_calls", ip),
                 ("qpt_updates", C.c_int64), ("t_model", C.c_double), ("t_krylov", C.c_double), ("t_total", C.c_double),
-                ("failed", C.c_int)]
+                ("failed", C.c_int), ("steps_done", C.c_int), ("dts_used", dp)]
 
 
 def load_case(toml_name, datadir=REFDATA):
@@ -133,10 +134,15 @@ def load_case(toml_name, datadir=REFDATA):
 def run_case(case, nsteps=None, precond=0, second_order_terms=False, use_input_temperature=False, verbose=0):
     """Run a regression case on the oracle; returns dict of arrays."""
     L = lib()
-    dts = np.ascontiguousarray(case["dts"], dtype=np.float64)
-    if nsteps is not None:
-        dts = dts[:nsteps]
-    ns = len(dts)
+    auto = case.get("auto") if case.get("dts") is None else None
+    if auto is not None:      # Time.Auto: nsteps = row capacity (reference: ceil(t_final / dt_min), src/mechanics_driver.cpp:212)
+        ns = int(nsteps) if nsteps is not None else int(np.ceil(auto["t_final"] / auto["dt_min"]))
+        dts = np.zeros(ns)
+    else:
+        dts = np.ascontiguousarray(case["dts"], dtype=np.float64)
+        if nsteps is not None:
+            dts = dts[:nsteps]
+        ns = len(dts)
     props = np.ascontiguousarray(case["props"], dtype=np.float64)
     eg = np.ascontiguousarray(case["elem_grain"], dtype=np.int32)
     quats = np.ascontiguousarray(case["quats"], dtype=np.float64)
@@ -153,13 +159,19 @@ def run_case(case, nsteps=None, precond=0, second_order_terms=False, use_input_t
                 case["assembly"], case["nl_solver"], precond, int(case.get("integ", 0)),
                 case["newton_rel"], case["newton_abs"], case["newton_iter"],
                 case["krylov_rel"], case["krylov_abs"], case["krylov_iter"],
-                int(case["additional_avgs"]), int(second_order_terms), int(use_input_temperature), verbose)
+                int(case["additional_avgs"]), int(second_order_terms), int(use_input_temperature), verbose,
+                int(auto is not None), *([float(auto.get(k, d)) for k, d in (("dt_start", 1.0), ("dt_min", 1.0), ("dt_scale", 0.25), ("t_final", 1.0))] if auto is not None else [0.0] * 4))
     out = dict(avg_stress=np.zeros((ns, 6)), avg_def_grad=np.zeros((ns, 9)), avg_pl_work=np.zeros(ns),
                avg_dp_tensor=np.zeros((ns, 6)), newton_iters=np.zeros(ns, np.int32), krylov_iters=np.zeros(ns, np.int32),
                model_calls=np.zeros(ns, np.int32))
+    dts_used = np.zeros(ns)
     r = OrcResult(_p(out["avg_stress"]), _p(out["avg_def_grad"]), _p(out["avg_pl_work"]), _p(out["avg_dp_tensor"]),
-                  _ip(out["newton_iters"]), _ip(out["krylov_iters"]), _ip(out["model_calls"]), 0, 0, 0, 0, 0)
+                  _ip(out["newton_iters"]), _ip(out["krylov_iters"]), _ip(out["model_calls"]), 0, 0, 0, 0, 0, 0, _p(dts_used))
     L.orc_run_case(C.byref(c), C.byref(r))
+    if auto is not None:
+        for k in list(out):
+            out[k] = out[k][: r.steps_done]
+        out["dts"] = dts_used[: r.steps_done]
     out.update(qpt_updates=r.qpt_updates, t_model=r.t_model, t_krylov=r.t_krylov, t_total=r.t_total, failed=r.failed)
     return out
 

@@ -132,3 +132,21 @@ def test_cyclic_velocity_gradient_bcs(oracle, tmp_path, name):
     s = d.avgs(0, 6)
     assert np.max(np.abs(s[:10, 2] / g[:10, 2] - 1.0)) < 6e-6
     assert np.max(np.abs(s[:, 2] - g[:, 2])) < 5e-5 * np.abs(g[:, 2]).max()
+
+
+def test_auto_time_stepping_matches_oracle(oracle, tmp_path):
+    """Time.Auto (reference src/system_driver.cpp:225-275): dt grows/shrinks with the Newton iteration count; the GPU driver
+    and the oracle must take the same step sequence.  (The reference's own golden curve for this case cannot be used: its
+    step sequence depends on the iteration counts of the reference's AMG-preconditioned FULL-assembly solve.)"""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    ref = orc.run_case(orc.load_case("mtsdd_full_auto.toml"))
+    d = L.Driver.from_toml(os.path.join(orc.REFDATA, "mtsdd_full_auto.toml"), out_dir=str(tmp_path))
+    n = d.run()
+    assert n == len(ref["dts"])
+    newton, krylov, calls = d.stats()
+    assert list(newton) == list(ref["newton_iters"])
+    s = d.avgs(0, 6)
+    assert np.linalg.norm(s[:, 2] - ref["avg_stress"][:, 2]) / np.linalg.norm(ref["avg_stress"][:, 2]) < 1e-6
+    dts = np.loadtxt(os.path.join(str(tmp_path), "auto_dt_out.txt"))
+    assert np.allclose(dts, ref["dts"], rtol=1e-10)
