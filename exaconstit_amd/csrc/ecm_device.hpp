@@ -48,6 +48,27 @@ __device__ constexpr double Q_TAB[3][NSLIP] = {
    { -2 * PB, PB, PB, -PB, 2 * PB, -PB, 2 * PB, -PB, -PB, PB, -2 * PB, PB },
    { PB, -2 * PB, PB, -2 * PB, PB, PB, -PB, 2 * PB, -PB, 2 * PB, -PB, -PB },
    { PB, PB, -2 * PB, PB, PB, -2 * PB, PB, PB, -2 * PB, PB, PB, -2 * PB } };
+// The same tables as small integers: P_TAB[c][a] = PSC[c] * SP[c][a], Q_TAB[c][a] = PB * SQ[c][a].  With the slip loop fully
+// unrolled every product with +-1 / +-2 is an add or an FMA with an inline constant and the zeros disappear at compile time.
+__device__ constexpr int SP[5][NSLIP] = {
+   { -1, -1, 2, 1, 1, -2, -1, -1, 2, 1, 1, -2 },
+   { -1, 1, 0, -1, 1, 0, -1, 1, 0, -1, 1, 0 },
+   { 1, -1, 0, -1, 1, 0, 1, -1, 0, -1, 1, 0 },
+   { -1, 0, 1, 0, -1, 1, 1, 0, -1, 0, 1, -1 },
+   { 0, 1, -1, -1, 0, 1, 0, -1, 1, 1, 0, -1 } };
+__device__ constexpr int SQ[3][NSLIP] = {
+   { -2, 1, 1, -1, 2, -1, 2, -1, -1, 1, -2, 1 },
+   { 1, -2, 1, -2, 1, 1, -1, 2, -1, 2, -1, -1 },
+   { 1, 1, -2, 1, 1, -2, 1, 1, -2, 1, 1, -2 } };
+__device__ constexpr double PSC[5] = { PA, 0.5, PA, PA, PA };
+constexpr bool slip_tables_agree() {
+   for (int a = 0; a < NSLIP; a++) {
+      for (int c = 0; c < 5; c++) if (P_TAB[c][a] != PSC[c] * SP[c][a]) return false;
+      for (int c = 0; c < 3; c++) if (Q_TAB[c][a] != PB * SQ[c][a]) return false;
+   }
+   return true;
+}
+static_assert(slip_tables_agree(), "integer slip tables must reproduce P_TAB / Q_TAB");
 // the same numbers, one row of 8 per slip system (P0..P4, Q0..Q2): the slip-system loop of the point problem is kept ROLLED
 // (uniform index -> scalar loads), which more than halves the register footprint of the fused kernel
 __device__ const double PQ_TAB[NSLIP][8] = {
@@ -165,6 +186,44 @@ ECM_DI void voce_gdot(const MatParams& mp, double g_i, double tau, double& gdot,
          const double temp = mp.gam_w * pow_xn(mp, at);
          gdot = temp * t_frac; dg = temp * mp.xnn * g_i;
       }
+   }
+}
+
+// Voce power law for all 12 systems at once (independent chains -> the FP64 pipeline stays full).  WITHD: also d gdot / d tau.
+template <bool WITHD>
+ECM_DI void voce_gdot12(const MatParams& mp, double g_i, const double tau[NSLIP], double gd[NSLIP], double dg[NSLIP]) {
+   double tf[NSLIP], pw[NSLIP];
+#pragma unroll
+   for (int a = 0; a < NSLIP; a++) tf[a] = tau[a] * g_i;
+   if (mp.xn_int > 0) {
+      double b[NSLIP];
+#pragma unroll
+      for (int a = 0; a < NSLIP; a++) { pw[a] = 1.0; b[a] = fabs(tf[a]); }
+      for (int e = mp.xn_int; e; e >>= 1) {   // uniform trip count
+         if (e & 1) {
+#pragma unroll
+            for (int a = 0; a < NSLIP; a++) pw[a] *= b[a];
+         }
+#pragma unroll
+         for (int a = 0; a < NSLIP; a++) b[a] *= b[a];
+      }
+   } else {
+#pragma unroll
+      for (int a = 0; a < NSLIP; a++) pw[a] = exp(mp.xn * log(fabs(tf[a])));
+   }
+   const double dfac = mp.xnn * g_i;
+#pragma unroll
+   for (int a = 0; a < NSLIP; a++) {
+      const double at = fabs(tf[a]);
+      const double temp = mp.gam_w * pw[a];
+      double g = temp * tf[a], d = temp * dfac;
+      if (at > mp.t_max) {   // rare: rate overflow guard
+         g = copysign(mp.gam_w * GAM_RATIO_OVF, tf[a]);
+         d = fabs(g) * mp.xnn / fabs(tau[a]);
+      }
+      const bool on = at > mp.t_min;
+      gd[a] = on ? g : 0.0;
+      if (WITHD) dg[a] = on ? d : 0.0;
    }
 }
 
@@ -301,6 +360,58 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
    const double g_i = pb.g_i;
    double dis = 0.0, shr = 0.0;
    double dp[5] = { 0, 0, 0, 0, 0 }, wp[3] = { 0, 0, 0 };
+   bool ok = true;
+   if constexpr (KIN != KIN_KMBALD) {
+      // fully unrolled, integer-coefficient form (see SP/SQ): resolved shear stresses, batched kinetics, then the Jacobian blocks
+      double ks[5];
+#pragma unroll
+      for (int c = 0; c < 5; c++) ks[c] = PSC[c] * k[c];
+      double tau[NSLIP], gd[NSLIP], dg[NSLIP];
+#pragma unroll
+      for (int a = 0; a < NSLIP; a++) {
+         double t = 0.0;
+#pragma unroll
+         for (int c = 0; c < 5; c++) if (SP[c][a] != 0) t += (double)SP[c][a] * ks[c];
+         tau[a] = t;
+      }
+      voce_gdot12<WITHJ>(mp, g_i, tau, gd, dg);
+#pragma unroll
+      for (int a = 0; a < NSLIP; a++) { dis += tau[a] * gd[a]; shr += fabs(gd[a]); ok = ok && isfinite(gd[a]); }
+#pragma unroll
+      for (int c = 0; c < 5; c++) {
+         double t = 0.0;
+#pragma unroll
+         for (int a = 0; a < NSLIP; a++) if (SP[c][a] != 0) t += (double)SP[c][a] * gd[a];
+         dp[c] = PSC[c] * t;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+         double t = 0.0;
+#pragma unroll
+         for (int a = 0; a < NSLIP; a++) t += (double)SQ[c][a] * gd[a];
+         wp[c] = PB * t;
+      }
+      if (WITHJ) {
+#pragma unroll
+         for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = i; j < 5; j++) {
+               double t = 0.0;
+#pragma unroll
+               for (int a = 0; a < NSLIP; a++) if (SP[i][a] * SP[j][a] != 0) t += (double)(SP[i][a] * SP[j][a]) * dg[a];
+               jac.A[sidx(i, j)] = (PSC[i] * PSC[j]) * t;
+            }
+#pragma unroll
+         for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+               double t = 0.0;
+#pragma unroll
+               for (int a = 0; a < NSLIP; a++) if (SQ[i][a] * SP[j][a] != 0) t += (double)(SQ[i][a] * SP[j][a]) * dg[a];
+               jac.B[i][j] = (PB * PSC[j]) * t;
+            }
+      }
+   } else {
    if (WITHJ) {
 #pragma unroll
       for (int i = 0; i < 15; i++) jac.A[i] = 0.0;
@@ -309,7 +420,6 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 #pragma unroll
          for (int j = 0; j < 5; j++) jac.B[i][j] = 0.0;
    }
-   bool ok = true;
 #pragma unroll kSlipUnroll
    for (int a = 0; a < NSLIP; a++) {
       double pq[8];
@@ -317,8 +427,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       for (int c = 0; c < 8; c++) pq[c] = PQ_TAB[a][c];
       const double tau = pq[0] * k[0] + pq[1] * k[1] + pq[2] * k[2] + pq[3] * k[3] + pq[4] * k[4];
       double gd, dg;
-      if (KIN == KIN_KMBALD) kmbald_gdot(mp, pb.kv, tau, gd, dg);
-      else voce_gdot(mp, g_i, tau, gd, dg);
+      kmbald_gdot(mp, pb.kv, tau, gd, dg);
       if (gdot_out) gdot_out[a] = gd;
       dis += tau * gd; shr += fabs(gd);
       ok = ok && isfinite(gd);
@@ -339,6 +448,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 #pragma unroll
             for (int j = 0; j < 5; j++) jac.B[i][j] += pq[5 + i] * gp[j];
       }
+   }
    }
    dis_rate = dis * pb.detV_ri; shrate = shr;
    if (WITHJ && mp.qsign < 0.0) {
@@ -378,6 +488,22 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
    }
    ECM_PARK_BARRIER();
    return ok;
+}
+
+// slip rates at the converged point (Voce family): written once, instead of one global store per system and evaluation
+ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out) {
+   const double ks[5] = { PSC[0] * mp.kd0 * e_f[0], PSC[1] * mp.kd0 * e_f[1], PSC[2] * mp.kd2 * e_f[2], PSC[3] * mp.kd2 * e_f[3], PSC[4] * mp.kd2 * e_f[4] };
+   double tau[NSLIP], gd[NSLIP];
+#pragma unroll
+   for (int a = 0; a < NSLIP; a++) {
+      double t = 0.0;
+#pragma unroll
+      for (int c = 0; c < 5; c++) if (SP[c][a] != 0) t += (double)SP[c][a] * ks[c];
+      tau[a] = t;
+   }
+   voce_gdot12<false>(mp, pb.g_i, tau, gd, nullptr);
+#pragma unroll
+   for (int a = 0; a < NSLIP; a++) gdot_out[a] = gd[a];
 }
 
 // ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
@@ -614,7 +740,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    double x[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
    double r[8], dis_rate, shrate;
    Jac J; Fact F;
-   double* gdot_out = sv1 + H_GDOT;
+   double* gdot_out = (KIN == KIN_KMBALD) ? sv1 + H_GDOT : nullptr;
    int nfev = 1; bool conv = false;
    bool ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);
    double res_0 = norm8(r);
@@ -720,6 +846,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       sv1[H_FLOW] = ((cold[CD_DEFF] > TINY_SQRT) ? dis_rate * dt : 0.0) + sv0[H_FLOW];   // accumulated plastic work
       sv1[H_NFEV] = (double)nfev;
       for (int i = 0; i < 5; i++) sv1[H_E + i] = e_f[i];
+      if constexpr (KIN != KIN_KMBALD) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT);
       sv1[H_H] = cold[CD_HU];
       sv1[IND_VOL] = vNew; sv1[IND_EINT] = eNew;
       const double pNew = mp.bulk * (1.0 / vNew - 1.0) + mp.gamma * eNew;

@@ -122,7 +122,7 @@ int exa_driver_bench_prepare(exa_driver* d, int nsteps, const double* dts, doubl
          op.Setup<true>(sd.v_sol.p);
          op.UpdateModel(); op.SwapCoords();
       }
-      op.SetDt(dts[nsteps - 1]);
+      op.SetDt(dts[nsteps > 0 ? nsteps - 1 : 0]);   // nsteps == 0: keep the virgin state, passes are then the elastic first step with dt = dts[0]
       EXA_HC(hipStreamSynchronize(op.stream()));
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }

@@ -209,10 +209,11 @@ class Driver:
         exa_driver_get_timers(self.h, t.ctypes.data_as(C.POINTER(C.c_double)))
         return dict(model_ms=t[0], krylov_ms=t[1], solve_ms=t[2], qpt_updates=int(t[3]), krylov_iters=int(t[4]))
 
-    def bench_prepare(self, dts, perturb=1.0):
+    def bench_prepare(self, dts, perturb=1.0, advance=True):
+        """Kinematic drive to the state the timed passes start from; advance=False keeps the virgin state (elastic first step, dt = dts[0])."""
         import numpy as np
         dts = np.ascontiguousarray(dts, dtype=np.float64)
-        self._chk(exa_driver_bench_prepare(self.h, len(dts), dts.ctypes.data_as(C.POINTER(C.c_double)), perturb, self._err, 512))
+        self._chk(exa_driver_bench_prepare(self.h, len(dts) if advance else 0, dts.ctypes.data_as(C.POINTER(C.c_double)), perturb, self._err, 512))
 
     def bench_model(self, steps):
         import numpy as np

@@ -212,6 +212,7 @@ inline void grad_calc(int Q, int E, int n, const double* J, const double* G, con
 // ExaCMechModel::ModelSetup  (K2..K9)
 // ---------------------------------------------------------------------------------------------
 struct ModelOpts { bool transpose_tangent = true; ecm::PointOpts po; };
+inline int& model_threads() { static int n = 1; return n; }
 
 // returns number of points whose local solve failed
 inline int model_setup(const ecm::Model& mdl, int Q, int E, int n, int nstatev, double dt, double temp_k,
@@ -228,6 +229,8 @@ inline int model_setup(const ecm::Model& mdl, int Q, int E, int n, int nstatev, 
    if (vgrad_out) std::memcpy(vgrad_out, vgrad.data(), sizeof(double) * 9 * P);
    const int ind_int_eng = nstatev - 1, ind_vols = ind_int_eng - 1, ind_pl_work = ecm::iHistA_flowStr;
    int nfail = 0;
+   // serial like the reference's rtmodel=CPU path unless orc_set_threads(n > 1) asked for the rtmodel=OPENMP analogue
+#pragma omp parallel for reduction(+ : nfail) schedule(dynamic, 64) num_threads(model_threads()) if (model_threads() > 1)
    for (size_t ip = 0; ip < P; ip++) {
       const double* L = &vgrad[9 * ip];               // L(i,j) = L[i + 3 j]
       double* sv = &state1[nstatev * ip];

@@ -67,6 +67,9 @@ int orc_run_case(const orc_case* c, orc_result* r) {
    return res.failed;
 }
 
+// number of OpenMP threads of the constitutive loop (1 = the reference's serial CPU path); returns the value in effect
+int orc_set_threads(int n) { fem::model_threads() = n < 1 ? 1 : n; return fem::model_threads(); }
+
 // ---- reference element / mesh helpers ------------------------------------------------------
 int orc_ref_elem(int p, double* G /*(n,3,Q)*/, double* W /*(Q)*/) {
    fem::RefElem re; fem::ref_elem_init(re, p);
