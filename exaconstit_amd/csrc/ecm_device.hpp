@@ -96,6 +96,15 @@ struct MatParams {
 // ------------------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------------------
+// reciprocal of a well-scaled, non-zero double: v_rcp_f64 seed + two Newton steps (5 instructions instead of the ~15 of an IEEE
+// division; relative error ~1e-16).  Only used for pivots / determinants that are checked for sign or finiteness afterwards.
+ECM_DI double frcp(double x) {
+   double y = __builtin_amdgcn_rcp(x);
+   y = fma(fma(-x, y, 1.0), y, y);
+   y = fma(fma(-x, y, 1.0), y, y);
+   return y;
+}
+
 ECM_DI void vecd_to_sym(const double v[5], double& t00, double& t11, double& t22, double& t01, double& t02, double& t12) {
    const double t1 = SQR2I * v[0], t2 = SQR6I * v[1];
    t00 = t1 - t2; t11 = -t1 - t2; t22 = SQR2B3 * v[1]; t01 = SQR2I * v[2]; t02 = SQR2I * v[3]; t12 = SQR2I * v[4];
@@ -190,7 +199,7 @@ ECM_DI void voce_gdot(const MatParams& mp, double g_i, double tau, double& gdot,
 }
 
 // Voce power law for all 12 systems at once (independent chains -> the FP64 pipeline stays full).  WITHD: also d gdot / d tau.
-template <bool WITHD>
+template <bool WITHD, bool CUT>
 ECM_DI void voce_gdot12(const MatParams& mp, double g_i, const double tau[NSLIP], double gd[NSLIP], double dg[NSLIP]) {
    double tf[NSLIP], pw[NSLIP];
 #pragma unroll
@@ -199,11 +208,13 @@ ECM_DI void voce_gdot12(const MatParams& mp, double g_i, const double tau[NSLIP]
       double b[NSLIP];
 #pragma unroll
       for (int a = 0; a < NSLIP; a++) { pw[a] = 1.0; b[a] = fabs(tf[a]); }
-      for (int e = mp.xn_int; e; e >>= 1) {   // uniform trip count
+      for (int e = mp.xn_int;;) {   // uniform trip count
          if (e & 1) {
 #pragma unroll
             for (int a = 0; a < NSLIP; a++) pw[a] *= b[a];
          }
+         e >>= 1;
+         if (!e) break;
 #pragma unroll
          for (int a = 0; a < NSLIP; a++) b[a] *= b[a];
       }
@@ -212,18 +223,24 @@ ECM_DI void voce_gdot12(const MatParams& mp, double g_i, const double tau[NSLIP]
       for (int a = 0; a < NSLIP; a++) pw[a] = exp(mp.xn * log(fabs(tf[a])));
    }
    const double dfac = mp.xnn * g_i;
+   double amax = 0.0;
 #pragma unroll
    for (int a = 0; a < NSLIP; a++) {
       const double at = fabs(tf[a]);
+      amax = fmax(amax, at);
       const double temp = mp.gam_w * pw[a];
-      double g = temp * tf[a], d = temp * dfac;
-      if (at > mp.t_max) {   // rare: rate overflow guard
-         g = copysign(mp.gam_w * GAM_RATIO_OVF, tf[a]);
-         d = fabs(g) * mp.xnn / fabs(tau[a]);
+      // below t_min = (1e-60)^m the reference returns exactly 0; the power law itself is < 1e-60 there, so the cut only matters
+      // for the slip rates that are written to the state (CUT), not for the sums of an evaluation
+      const bool on = !CUT || at > mp.t_min;
+      gd[a] = on ? temp * tf[a] : 0.0;
+      if (WITHD) dg[a] = on ? temp * dfac : 0.0;
+   }
+   if (amax > mp.t_max) {   // rare: rate overflow guard of the reference, one branch for all systems
+#pragma unroll
+      for (int a = 0; a < NSLIP; a++) if (fabs(tf[a]) > mp.t_max) {
+         gd[a] = copysign(mp.gam_w * GAM_RATIO_OVF, tf[a]);
+         if (WITHD) dg[a] = fabs(gd[a]) * mp.xnn / fabs(tau[a]);
       }
-      const bool on = at > mp.t_min;
-      gd[a] = on ? g : 0.0;
-      if (WITHD) dg[a] = on ? d : 0.0;
    }
 }
 
@@ -374,9 +391,10 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
          for (int c = 0; c < 5; c++) if (SP[c][a] != 0) t += (double)SP[c][a] * ks[c];
          tau[a] = t;
       }
-      voce_gdot12<WITHJ>(mp, g_i, tau, gd, dg);
+      voce_gdot12<WITHJ, false>(mp, g_i, tau, gd, dg);
 #pragma unroll
-      for (int a = 0; a < NSLIP; a++) { dis += tau[a] * gd[a]; shr += fabs(gd[a]); ok = ok && isfinite(gd[a]); }
+      for (int a = 0; a < NSLIP; a++) { dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
+      ok = isfinite(shr);   // any non-finite rate poisons the sum
 #pragma unroll
       for (int c = 0; c < 5; c++) {
          double t = 0.0;
@@ -501,7 +519,7 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
       for (int c = 0; c < 5; c++) if (SP[c][a] != 0) t += (double)SP[c][a] * ks[c];
       tau[a] = t;
    }
-   voce_gdot12<false>(mp, pb.g_i, tau, gd, nullptr);
+   voce_gdot12<false, true>(mp, pb.g_i, tau, gd, nullptr);
 #pragma unroll
    for (int a = 0; a < NSLIP; a++) gdot_out[a] = gd[a];
 }
@@ -545,8 +563,26 @@ ECM_DI void wt_matrix(const Prob& pb, double Wt[9]) {
 
 // Factorisation.  In place: J.A <- LDL^T of M = diag(1/(kd dt)) + A (unit lower L stored in the strict upper slots, 1/D on the
 // diagonal); Ri = Jrr^-1.  The coupling blocks are O(|D| dt) ~ 1e-4 relative, so J dx = rhs is solved by block Gauss-Seidel
-// sweeps on (e, r) with these two exact diagonal-block inverses: contraction ~1e-4 per sweep, 3 sweeps reach round-off.
+// sweeps on (e, r) with these two exact diagonal-block inverses: contraction ~1e-4 per sweep; the Newton step uses 2 sweeps
+// (step error ~1e-8 relative, immaterial for the iteration), the tangent eliminates the rotation block exactly instead.
 struct Fact { double Ri[9]; bool ok; };
+
+// Ri = Jrr^-1 = (I/dt - hat(w_lat) Tr)^-1, row-major; returns false if singular
+ECM_DI bool rot_block_inverse(const Prob& pb, double Ri[9]) {
+   double Wt[9]; wt_matrix(pb, Wt);
+   double R[3][3];
+#pragma unroll
+   for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) R[i][j] = (i == j ? pb.dt_ri : 0.0) - Wt[3 * i + j];
+   const double c00 = R[1][1] * R[2][2] - R[1][2] * R[2][1], c01 = R[1][2] * R[2][0] - R[1][0] * R[2][2], c02 = R[1][0] * R[2][1] - R[1][1] * R[2][0];
+   const double det = R[0][0] * c00 + R[0][1] * c01 + R[0][2] * c02;
+   const double di = frcp(det);
+   Ri[0] = c00 * di; Ri[3] = c01 * di; Ri[6] = c02 * di;
+   Ri[1] = (R[0][2] * R[2][1] - R[0][1] * R[2][2]) * di; Ri[4] = (R[0][0] * R[2][2] - R[0][2] * R[2][0]) * di; Ri[7] = (R[0][1] * R[2][0] - R[0][0] * R[2][1]) * di;
+   Ri[2] = (R[0][1] * R[1][2] - R[0][2] * R[1][1]) * di; Ri[5] = (R[0][2] * R[1][0] - R[0][0] * R[1][2]) * di; Ri[8] = (R[0][0] * R[1][1] - R[0][1] * R[1][0]) * di;
+   return isfinite(di);
+}
 
 ECM_DI void jac_factor(const MatParams& mp, const Prob& pb, Jac& J, Fact& F) {
    const double kdi0 = pb.dt_ri / mp.kd0, kdi2 = pb.dt_ri / mp.kd2;
@@ -556,7 +592,7 @@ ECM_DI void jac_factor(const MatParams& mp, const Prob& pb, Jac& J, Fact& F) {
    for (int k = 0; k < 5; k++) {
       const double d = J.A[sidx(k, k)];
       ok = ok && (d > 0.0);
-      const double inv = 1.0 / d;
+      const double inv = frcp(d);
       double li[5];
 #pragma unroll
       for (int i = k + 1; i < 5; i++) li[i] = J.A[sidx(k, i)] * inv;
@@ -568,19 +604,8 @@ ECM_DI void jac_factor(const MatParams& mp, const Prob& pb, Jac& J, Fact& F) {
       for (int i = k + 1; i < 5; i++) J.A[sidx(k, i)] = li[i];
       J.A[sidx(k, k)] = inv;
    }
-   double Wt[9]; wt_matrix(pb, Wt);
-   double R[3][3];
-#pragma unroll
-   for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) R[i][j] = (i == j ? pb.dt_ri : 0.0) - Wt[3 * i + j];
-   const double c00 = R[1][1] * R[2][2] - R[1][2] * R[2][1], c01 = R[1][2] * R[2][0] - R[1][0] * R[2][2], c02 = R[1][0] * R[2][1] - R[1][1] * R[2][0];
-   const double det = R[0][0] * c00 + R[0][1] * c01 + R[0][2] * c02;
-   const double di = 1.0 / det;
-   F.Ri[0] = c00 * di; F.Ri[3] = c01 * di; F.Ri[6] = c02 * di;
-   F.Ri[1] = (R[0][2] * R[2][1] - R[0][1] * R[2][2]) * di; F.Ri[4] = (R[0][0] * R[2][2] - R[0][2] * R[2][0]) * di; F.Ri[7] = (R[0][1] * R[2][0] - R[0][0] * R[2][1]) * di;
-   F.Ri[2] = (R[0][1] * R[1][2] - R[0][2] * R[1][1]) * di; F.Ri[5] = (R[0][2] * R[1][0] - R[0][0] * R[1][2]) * di; F.Ri[8] = (R[0][0] * R[1][1] - R[0][1] * R[1][0]) * di;
-   F.ok = ok && isfinite(di);
+   const bool okr = rot_block_inverse(pb, F.Ri);
+   F.ok = ok && okr;
 }
 
 // b <- Jee^-1 b  using the in-place factor:  Jee = M Kd  =>  x = Kd^-1 M^-1 b
@@ -649,7 +674,7 @@ ECM_DI void jac_mult_T(const MatParams& mp, const Prob& pb, const Jac& J, const 
 }
 
 // solve J dx = rhs by block Gauss-Seidel on the exact diagonal-block inverses (rhs_r may be identically zero: ZERO_R)
-template <bool ZERO_R>
+template <bool ZERO_R, int NSWEEP>
 ECM_DI void jac_solve(const MatParams& mp, const Prob& pb, const Jac& J, const Fact& F, const double rhs[8], double dx[8]) {
    double xr[3] = { 0, 0, 0 };
    if (!ZERO_R) {
@@ -658,7 +683,7 @@ ECM_DI void jac_solve(const MatParams& mp, const Prob& pb, const Jac& J, const F
    }
    double xe[5];
 #pragma unroll 1
-   for (int sweep = 0; sweep < 3; sweep++) {
+   for (int sweep = 0; sweep < NSWEEP; sweep++) {
       double t[5]; jer_mult(pb, xr, t);
 #pragma unroll
       for (int i = 0; i < 5; i++) xe[i] = rhs[i] - t[i];
@@ -754,7 +779,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          double nr2norm;
          if (F.ok) {
             double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i] * pb.sc_i;
-            jac_solve<false>(mp, pb, J, F, rhs, t);
+            jac_solve<false, 2>(mp, pb, J, F, rhs, t);
             for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? (1.0 / E_SCALE) : (1.0 / R_SCALE));
             nr2norm = norm8(nr);
          } else { nr2norm = 1e300; for (int i = 0; i < 8; i++) nr[i] = 0; }
@@ -858,19 +883,76 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    // ---- tangent (last: it overwrites the parking area): lattice-frame d sigma'/d D' by implicit differentiation on the converged
    // factorisation, rotated to the sample frame, then to Voigt (engineering shear) + bulk term, column-major
    {
-      jac_factor(mp, pb, J, F);
+      // J [xe; xr] = [e_c; 0] with Jee = M Kd, Jre = B Kd, Jer = -E (E = M35(d_lat) Tr), xr eliminated exactly:
+      //   y = Kd xe,  (M + E G) y = e_c,  G = Jrr^-1 B,  xr = -G y   =>   Llat = (I/J + M35(s') Tr G) (M + E G)^-1
       double Llat[5][5];
+      bool okT;
       {
+         double Ri[9]; okT = rot_block_inverse(pb, Ri);
+         double G[3][5];
+#pragma unroll
+         for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 5; j++) G[i][j] = Ri[3 * i] * J.B[0][j] + Ri[3 * i + 1] * J.B[1][j] + Ri[3 * i + 2] * J.B[2][j];
          double Tr[9]; load_tr(pb, Tr);
-         double Ms[5][3]; m35(s_lat, Ms);
+         double S[5][5];
+         {
+            double dl[5]; load_dl(pb, dl);
+            double Md[5][3]; m35(dl, Md);
+            const double kdi0 = pb.dt_ri / mp.kd0, kdi2 = pb.dt_ri / mp.kd2;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+               double E[3];
+#pragma unroll
+               for (int j = 0; j < 3; j++) E[j] = Md[k][0] * Tr[j] + Md[k][1] * Tr[3 + j] + Md[k][2] * Tr[6 + j];
+#pragma unroll
+               for (int j = 0; j < 5; j++) S[k][j] = J.A[sidx(k, j)] + ((k == j) ? (k < 2 ? kdi0 : kdi2) : 0.0) + E[0] * G[0][j] + E[1] * G[1][j] + E[2] * G[2][j];
+            }
+         }
+         // un-pivoted LU of S (M is SPD and dominates the O(|D| dt) coupling), then Y = S^-1 column by column
+#pragma unroll
+         for (int k = 0; k < 5; k++) {
+            okT = okT && (S[k][k] > 0.0);
+            const double inv = frcp(S[k][k]);
+            S[k][k] = inv;
+#pragma unroll
+            for (int i = k + 1; i < 5; i++) {
+               const double l = S[i][k] * inv; S[i][k] = l;
+#pragma unroll
+               for (int j = k + 1; j < 5; j++) S[i][j] -= l * S[k][j];
+            }
+         }
+         double Kt[5][5];   // detV_ri I + M35(s_lat) Tr G
+         {
+            double Ms[5][3]; m35(s_lat, Ms);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+               double H[3];
+#pragma unroll
+               for (int j = 0; j < 3; j++) H[j] = Ms[k][0] * Tr[j] + Ms[k][1] * Tr[3 + j] + Ms[k][2] * Tr[6 + j];
+#pragma unroll
+               for (int j = 0; j < 5; j++) Kt[k][j] = ((k == j) ? pb.detV_ri : 0.0) + H[0] * G[0][j] + H[1] * G[1][j] + H[2] * G[2][j];
+            }
+         }
 #pragma unroll
          for (int c = 0; c < 5; c++) {
-            double rhs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dx[8];
-            rhs[c] = 1.0;
-            jac_solve<true>(mp, pb, J, F, rhs, dx);
-            double dth[3];
-            for (int i = 0; i < 3; i++) dth[i] = Tr[3 * i] * dx[5] + Tr[3 * i + 1] * dx[6] + Tr[3 * i + 2] * dx[7];
-            for (int k = 0; k < 5; k++) Llat[k][c] = kdj[k] * dx[k] - (Ms[k][0] * dth[0] + Ms[k][1] * dth[1] + Ms[k][2] * dth[2]);
+            double y[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) {       // forward: L y = e_c (entries above c stay zero)
+               double t = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+               for (int j = c; j < i; j++) t -= S[i][j] * y[j];
+               y[i] = (i < c) ? 0.0 : t;
+            }
+#pragma unroll
+            for (int i = 4; i >= 0; i--) {      // backward: U y = y
+               double t = y[i];
+#pragma unroll
+               for (int j = i + 1; j < 5; j++) t -= S[i][j] * y[j];
+               y[i] = t * S[i][i];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) Llat[k][c] = Kt[k][0] * y[0] + Kt[k][1] * y[1] + Kt[k][2] * y[2] + Kt[k][3] * y[3] + Kt[k][4] * y[4];
          }
       }
       // D55 = Q5 Llat Q5^T with the explicit 5x5 rotation of deviatoric 5-vectors (columns = images of the unit vectors)
@@ -887,7 +969,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       for (int k = 0; k < 5; k++)
 #pragma unroll
          for (int c = 0; c < 5; c++) { double v = 0; for (int l = 0; l < 5; l++) v += Q5[k][l] * Llat[l][c]; T1[k][c] = v; }
-      const double dti = pb.dt_ri * (F.ok ? 1.0 : 0.0);
+      const double dti = pb.dt_ri * (okT ? 1.0 : 0.0);
 #pragma unroll
       for (int k = 0; k < 5; k++) {
          double D[5];   // row k of D55 = T1 Q5^T
