@@ -3,7 +3,7 @@
 #include <cstring>
 #include <cstdio>
 
-int exa_launch_model_setup(exa_ctx*, double, const double*, const double*, const double*, const double*, double*, double*, double*, hipStream_t);
+int exa_launch_model_setup(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, hipStream_t);
 int exa_launch_init_state(exa_ctx*, double*, const double*, const double*, hipStream_t);
 int exa_launch_calc_dp(exa_ctx*, const double*, double*, hipStream_t);
 int exa_launch_jacobians(exa_ctx*, const double*, double*, hipStream_t);
@@ -98,7 +98,15 @@ int exa_model_setup(exa_ctx* ctx, double dt, const double* J, const double* vel,
                     double* stress1, double* state1, double* ddsdde, exa_stream s) {
    if (!ctx || !J || !vel || !stress0 || !state0 || !stress1 || !state1 || !ddsdde) return fail(ctx, EXA_ERR_ARG, "exa_model_setup: null pointer");
    if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup: dt must be positive");
-   return exa_launch_model_setup(ctx, dt, J, vel, stress0, state0, stress1, state1, ddsdde, S(s));
+   return exa_launch_model_setup(ctx, dt, const_cast<double*>(J), vel, nullptr, stress0, state0, stress1, state1, ddsdde, S(s));
+}
+
+int exa_model_setup_lvec(exa_ctx* ctx, double dt, const double* x_lvec, const double* v_lvec, const double* stress0, const double* state0,
+                         double* stress1, double* state1, double* ddsdde, double* J_out, exa_stream s) {
+   if (!ctx || !x_lvec || !v_lvec || !stress0 || !state0 || !stress1 || !state1 || !ddsdde || !J_out) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec: null pointer");
+   if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec: call exa_set_connectivity first");
+   if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec: dt must be positive");
+   return exa_launch_model_setup(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, ddsdde, S(s));
 }
 
 int exa_model_status(exa_ctx* ctx, exa_stream s) {

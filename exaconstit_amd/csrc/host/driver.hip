@@ -108,6 +108,9 @@ static void abi_check(exa_ctx* ctx, int rc, const char* what) { if (rc < 0) thro
 void ExaCMechModel::ModelSetup(const double* jacobian, const double* vel_evec, hipStream_t s) {
    abi_check(ctx_, exa_model_setup(ctx_, dt_, jacobian, vel_evec, stress0_->p, matVars0_->p, stress1_->p, matVars1_->p, matGrad_->p, s), "exa_model_setup");
 }
+void ExaCMechModel::ModelSetupLVec(const double* x_lvec, const double* v_lvec, double* jacobian_out, hipStream_t s) {
+   abi_check(ctx_, exa_model_setup_lvec(ctx_, dt_, x_lvec, v_lvec, stress0_->p, matVars0_->p, stress1_->p, matVars1_->p, matGrad_->p, jacobian_out, s), "exa_model_setup_lvec");
+}
 void ExaCMechModel::calcDpMat(double* dp, hipStream_t s) const { abi_check(ctx_, exa_calc_dp(ctx_, matVars1_->p, dp, s), "exa_calc_dp"); }
 
 // =====================================================================================================================
@@ -134,6 +137,7 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    nn_ = part.NN; nd_ = 3 * nn_; E_ = part.E; npe_ = part.n;
    fast_p1_ = (part.p == 1 && !bbar);          // fused L-vector kernels exist for p = 1 full integration
    lvec_grad_ = fast_p1_ || opt.assembly == Assembly::EA;
+   fused_setup_ = std::getenv("EXA_UNFUSED_SETUP") == nullptr;   // A/B switch for measurements; the fused launch is the product path
    const size_t P = (size_t)E_ * npe_;
    conn.upload(part.conn); abi_check(ctx_, exa_set_connectivity(ctx_, conn.p, nn_), "exa_set_connectivity");
    x_ref.upload(part.X); x_beg.upload(part.X); x_cur.upload(part.X);
@@ -155,11 +159,14 @@ void NonlinearMechOperator::UpdateEssTDofs(const std::vector<uint8_t>& mask) { e
 template <bool upd_crds>
 void NonlinearMechOperator::Setup(const double* k) {
    if (upd_crds) vk_update_coords(nd_, x_beg.p, k, dt_, x_cur.p, stream_);   // ExaModel::UpdateEndCoords (halo copies stay consistent)
-   abi_check(ctx_, exa_restrict(ctx_, x_cur.p, el_x.p, stream_), "exa_restrict");
-   abi_check(ctx_, exa_jacobians(ctx_, el_x.p, el_jac.p, stream_), "exa_jacobians");   // SetupJacobianTerms
-   abi_check(ctx_, exa_restrict(ctx_, k, el_v.p, stream_), "exa_restrict");
    EXA_HC(hipEventRecord(ev0_, stream_));
-   model_->ModelSetup(el_jac.p, el_v.p, stream_);
+   if (fused_setup_) model_->ModelSetupLVec(x_cur.p, k, el_jac.p, stream_);   // L->E of x and v + SetupJacobianTerms inside the constitutive launch
+   else {
+      abi_check(ctx_, exa_restrict(ctx_, x_cur.p, el_x.p, stream_), "exa_restrict");
+      abi_check(ctx_, exa_jacobians(ctx_, el_x.p, el_jac.p, stream_), "exa_jacobians");   // SetupJacobianTerms
+      abi_check(ctx_, exa_restrict(ctx_, k, el_v.p, stream_), "exa_restrict");
+      model_->ModelSetup(el_jac.p, el_v.p, stream_);
+   }
    EXA_HC(hipEventRecord(ev1_, stream_));
    EXA_HC(hipEventSynchronize(ev1_));
    float ms = 0; EXA_HC(hipEventElapsedTime(&ms, ev0_, ev1_));
@@ -461,6 +468,7 @@ void SystemDriver::UpdateModel() {
       DevBuf<double> jref(9 * P), F(9 * P), xe(3 * (size_t)part.n * part.E);
       abi_check(ctx, exa_restrict(ctx, op.x_ref.p, xe.p, s), "exa_restrict");
       abi_check(ctx, exa_jacobians(ctx, xe.p, jref.p, s), "exa_jacobians");
+      abi_check(ctx, exa_restrict(ctx, op.x_cur.p, op.el_x.p, s), "exa_restrict");   // x_true -> E-vector (reference src/mechanics_operator.cpp:411-414)
       abi_check(ctx, exa_grad_calc(ctx, jref.p, op.el_x.p, F.p, s), "exa_grad_calc");
       vol_avg(F.p, 9, true, a);
       avg_def_grad.insert(avg_def_grad.end(), a, a + 9);

@@ -55,6 +55,8 @@ class ExaCMechModel {
    double GetModelDt() const { return dt_; }
    // ExaCMechModel::ModelSetup (reference src/mechanics_ecmech.cpp:192-258)
    void ModelSetup(const double* jacobian, const double* vel_evec, hipStream_t s);
+   // the same with the operator's L->E restrictions and Jacobian refresh fused in (writes the Jacobians)
+   void ModelSetupLVec(const double* x_lvec, const double* v_lvec, double* jacobian_out, hipStream_t s);
    void UpdateModelVars() {}
    void UpdateStress() { stress0_->swap(*stress1_); }        // reference src/mechanics_model.cpp:435-438
    void UpdateStateVars() { matVars0_->swap(*matVars1_); }   // reference src/mechanics_model.cpp:440-443
@@ -105,7 +107,7 @@ class NonlinearMechOperator {
    exa_ctx* ctx_ = nullptr; std::unique_ptr<ExaCMechModel> model_;
    hipStream_t stream_ = nullptr; hipEvent_t ev0_, ev1_;
    int nn_, nd_, E_, npe_ = 8; double dt_ = 1.0;
-   bool fast_p1_ = true, lvec_grad_ = true;
+   bool fast_p1_ = true, lvec_grad_ = true, fused_setup_ = true;
    DevBuf<double> tmp_l_, tmp_r_, el_y_, el_x2_;
 };
 

@@ -12,12 +12,20 @@ using namespace ecmdev;
 #define EXA_MODEL_OCC 2   // waves per SIMD the register allocator is asked to fit (tuned on MI355X)
 #endif
 
-template <int KIN>
-__global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatParams mp, const int Q, const int n, const int64_t P, const double dt,
-                                                     const double* __restrict__ J, const double* __restrict__ G,
-                                                     const double* __restrict__ vel, const double* __restrict__ stress0,
+// LVEC = false: J (3,3,Q,E) and the velocity E-vector (n,3,E) are inputs (the reference's ModelSetup signature).
+// LVEC = true : the kernel gathers nodal coordinates and velocities from the L-vectors through the connectivity, computes J itself
+//               and WRITES it to Jio for the integrator kernels: NonlinearMechOperator::Setup's L->E restrictions and
+//               SetupJacobianTerms (reference src/mechanics_operator.cpp:310-391) ride inside this VALU-bound kernel for free.
+// NFIX = 8: trilinear elements, node loops fully unrolled so that all gathers of a point are in flight together (two memory round
+// trips instead of one dependent index->value chain per node); NFIX = 0: run-time n.
+template <int KIN, bool LVEC, int NFIX>
+__global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatParams mp, const int Q, const int n_rt, const int64_t P, const double dt,
+                                                     double* __restrict__ Jio, const double* __restrict__ G,
+                                                     const double* __restrict__ vel, const double* __restrict__ xl, const int32_t* __restrict__ conn, const int nnodes,
+                                                     const double* __restrict__ stress0,
                                                      const double* __restrict__ state0, double* __restrict__ stress1,
                                                      double* __restrict__ state1, double* __restrict__ cmat, int* __restrict__ fail) {
+   const int n = NFIX ? NFIX : n_rt;
    extern __shared__ double sG[];   // (n,3,Q)
    for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
    __syncthreads();
@@ -25,9 +33,28 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    if (ip >= P) return;
    const int q = (int)(ip % Q);
    const int64_t e = ip / Q;
+   const double* Gq = sG + 3 * n * q;
+   double J11, J21, J31, J12, J22, J32, J13, J23, J33;
+   if (LVEC) {
+      // J(i,j) = sum_r x_r,i dN_r/dxi_j   (column-major 3x3 per point, like MFEM's geometric factors after the re-layout)
+      J11 = J21 = J31 = J12 = J22 = J32 = J13 = J23 = J33 = 0.0;
+      const int32_t* ce = conn + (int64_t)n * e;
+#pragma unroll
+      for (int r = 0; r < n; r++) {
+         const int g = ce[r];
+         const double x0 = xl[g], x1 = xl[g + nnodes], x2 = xl[g + 2 * (int64_t)nnodes];
+         const double g0 = Gq[r], g1 = Gq[r + n], g2 = Gq[r + 2 * n];
+         J11 += x0 * g0; J21 += x1 * g0; J31 += x2 * g0;
+         J12 += x0 * g1; J22 += x1 * g1; J32 += x2 * g1;
+         J13 += x0 * g2; J23 += x1 * g2; J33 += x2 * g2;
+      }
+      double* Jo = Jio + 9 * ip;
+      Jo[0] = J11; Jo[1] = J21; Jo[2] = J31; Jo[3] = J12; Jo[4] = J22; Jo[5] = J32; Jo[6] = J13; Jo[7] = J23; Jo[8] = J33;
+   } else {
+      const double* Jq = Jio + 9 * ip;
+      J11 = Jq[0]; J21 = Jq[1]; J31 = Jq[2]; J12 = Jq[3]; J22 = Jq[4]; J32 = Jq[5]; J13 = Jq[6]; J23 = Jq[7]; J33 = Jq[8];
+   }
    // inverse Jacobian (reference src/mechanics_kernels.cpp:38-61)
-   const double* Jq = J + 9 * ip;
-   const double J11 = Jq[0], J21 = Jq[1], J31 = Jq[2], J12 = Jq[3], J22 = Jq[4], J32 = Jq[5], J13 = Jq[6], J23 = Jq[7], J33 = Jq[8];
    const double detJ = J11 * (J22 * J33 - J32 * J23) - J21 * (J12 * J33 - J32 * J13) + J31 * (J12 * J23 - J22 * J13);
    const double di = 1.0 / detJ;
    // Ji[s][t] = dxi_s/dx_t
@@ -37,13 +64,16 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    // velocity gradient L(c,t) = sum_r v(r,c) dN_r/dx_t
    double L[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
    const double* ve = vel + (int64_t)3 * n * e;
-   const double* Gq = sG + 3 * n * q;
+   const int32_t* ce = conn + (int64_t)n * e;
+#pragma unroll
    for (int r = 0; r < n; r++) {
       const double g0 = Gq[r], g1 = Gq[r + n], g2 = Gq[r + 2 * n];
       const double b0 = g0 * Ji[0][0] + g1 * Ji[1][0] + g2 * Ji[2][0];
       const double b1 = g0 * Ji[0][1] + g1 * Ji[1][1] + g2 * Ji[2][1];
       const double b2 = g0 * Ji[0][2] + g1 * Ji[1][2] + g2 * Ji[2][2];
-      const double v0 = ve[r], v1 = ve[r + n], v2 = ve[r + 2 * n];
+      double v0, v1, v2;
+      if (LVEC) { const int g = ce[r]; v0 = vel[g]; v1 = vel[g + nnodes]; v2 = vel[g + 2 * (int64_t)nnodes]; }
+      else { v0 = ve[r]; v1 = ve[r + n]; v2 = ve[r + 2 * n]; }
       L[0] += v0 * b0; L[1] += v1 * b0; L[2] += v2 * b0;
       L[3] += v0 * b1; L[4] += v1 * b1; L[5] += v2 * b1;
       L[6] += v0 * b2; L[7] += v1 * b2; L[8] += v2 * b2;
@@ -85,22 +115,41 @@ __global__ void k_calc_dp(const double qsign, const int64_t P, const double* __r
    o[0] = t00; o[1] = t01; o[2] = t02; o[3] = t01; o[4] = t11; o[5] = t12; o[6] = t02; o[7] = t12; o[8] = t22;
 }
 
-int exa_launch_model_setup(exa_ctx* ctx, double dt, const double* J, const double* vel, const double* stress0, const double* state0,
-                           double* stress1, double* state1, double* cmat, hipStream_t s) {
+template <int KIN, bool LVEC, int NFIX>
+static void launch_model_n(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
+                         double* stress1, double* state1, double* cmat, hipStream_t s) {
    const int bs = 256;
    const int64_t nb = (ctx->P + bs - 1) / bs;
    const size_t lds = sizeof(double) * ((size_t)ctx->n * 3 * ctx->Q + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE);
    static_assert(ECM_STASH_STRIDE == 256, "stash stride must equal the block size");
+   hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX>), dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+                      ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
+}
+
+template <int KIN, bool LVEC>
+static void launch_model(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
+                         double* stress1, double* state1, double* cmat, hipStream_t s) {
+   if (LVEC && ctx->n == 8) launch_model_n<KIN, LVEC, 8>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+   else launch_model_n<KIN, LVEC, 0>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+}
+
+// xl == nullptr: J is an input and vel an E-vector; otherwise xl / vel are L-vectors (byNODES) and J is written
+int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
+                           double* stress1, double* state1, double* cmat, hipStream_t s) {
    EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->fail_count_dev, 0, sizeof(int), s));
+   const bool lv = xl != nullptr;
    switch (ctx->mp.kin) {
       case KIN_VOCE:
-         hipLaunchKernelGGL(k_model_setup<KIN_VOCE>, dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
+         if (lv) launch_model<KIN_VOCE, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         else launch_model<KIN_VOCE, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
       case KIN_VOCE_NL:
-         hipLaunchKernelGGL(k_model_setup<KIN_VOCE_NL>, dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
+         if (lv) launch_model<KIN_VOCE_NL, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         else launch_model<KIN_VOCE_NL, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
       default:
-         hipLaunchKernelGGL(k_model_setup<KIN_KMBALD>, dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
+         if (lv) launch_model<KIN_KMBALD, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         else launch_model<KIN_KMBALD, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
    }
    EXA_HIP_CHECK(ctx, hipGetLastError());

@@ -53,6 +53,7 @@ exa_qpts_per_elem = _sig("exa_qpts_per_elem", C.c_int, C.c_void_p)
 exa_shape_table = _sig("exa_shape_table", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 exa_init_state = _sig("exa_init_state", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_model_setup = _sig("exa_model_setup", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
+exa_model_setup_lvec = _sig("exa_model_setup_lvec", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_status = _sig("exa_model_status", C.c_int, C.c_void_p, C.c_void_p)
 exa_calc_dp = _sig("exa_calc_dp", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_jacobians = _sig("exa_jacobians", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)

@@ -72,6 +72,12 @@ int exa_init_state(exa_ctx* ctx, double* state0_dev, const double* quats_per_ele
 int exa_model_setup(exa_ctx* ctx, double dt, const double* jacobian_dev /*(3,3,Q,E)*/, const double* vel_evec_dev /*(n,3,E)*/,
                     const double* stress0_dev, const double* state0_dev,
                     double* stress1_dev, double* state1_dev, double* ddsdde_dev, exa_stream s);
+/* Same update driven from L-vectors (needs exa_set_connectivity): gathers nodal coordinates / velocities itself and also
+ * WRITES the Jacobians (3,3,Q,E) the integrator calls need, i.e. NonlinearMechOperator::Setup's two L->E restrictions and
+ * SetupJacobianTerms (src/mechanics_operator.cpp:310-391) fused into the constitutive launch. */
+int exa_model_setup_lvec(exa_ctx* ctx, double dt, const double* coords_lvec_dev /*(nnodes,3) byNODES*/, const double* vel_lvec_dev,
+                         const double* stress0_dev, const double* state0_dev,
+                         double* stress1_dev, double* state1_dev, double* ddsdde_dev, double* jacobian_out_dev, exa_stream s);
 /* synchronises the stream; returns the number of non-converged points of the last exa_model_setup (>= 0) */
 int exa_model_status(exa_ctx* ctx, exa_stream s);
 

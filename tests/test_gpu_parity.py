@@ -94,6 +94,18 @@ def test_model_setup_matches_oracle(oracle, name, xtal, kin, pkey, model):
         for lo, hi in ((0, 3), (3, 8), (8, 12), (12, 13), (13, 25), (25, 27)):
             assert rel_l2(a[:, lo:hi], b[:, lo:hi]) < 1e-8, (name, step, lo)
         assert rel_l2(g_cm, cm) < 1e-7, (name, step)
+        # fused L-vector entry (gathers nodes, computes and writes J): same answers as the E-vector entry, J == exa_jacobians
+        if step in (0, len(dts) - 1):
+            import torch
+            d_conn = torch.tensor(rve["conn"].astype(np.int32).ravel(), dtype=torch.int32, device="cuda")
+            ctx.check(L.exa_set_connectivity(ctx.h, d_conn.data_ptr(), rve["NN"]))
+            d_x, d_v = dev.up(x), dev.up(v_nodes)
+            o2 = [dev.zeros(6 * P), dev.zeros(28 * P), dev.zeros(36 * P)]; d_J2 = dev.zeros(9 * P)
+            ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(d[1]), ptr(d[2]), ptr(o2[0]), ptr(o2[1]), ptr(o2[2]), ptr(d_J2), None))
+            assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+            assert rel_l2(d_J2.cpu().numpy(), J) < 1e-14
+            assert rel_l2(o2[0].cpu().numpy(), g_s1) < 1e-12 and rel_l2(o2[2].cpu().numpy(), g_cm) < 1e-10
+            assert rel_l2(o2[1].cpu().numpy().reshape(P, 28)[:, keep], a) < 1e-12
         s0, sv0 = s1, sv1                          # both sides continue from the oracle's state
     # the last steps must be plastic for the test to mean anything
     assert np.abs(sv0.reshape(P, 28)[:, 14:26]).sum(axis=1).min() > 0
