@@ -1,0 +1,106 @@
+"""Parity at BASELINE.json's full sizes (64^3 and 128^3 elements) through size-independent properties, since the oracle cannot
+run 16.8 M quadrature points in test time:
+  * a random sample of elements is re-computed by the oracle from the very inputs the GPU pass consumed (stress 1e-9, tangent 1e-7);
+  * internal forces are self-equilibrated: the nodal residual sums to zero per component (sum_a grad N_a = 0);
+  * the gradient action is linear, and partial assembly == element assembly (on the transposed tangent field, see below).
+All calls go through the C ABI; torch is the allocator."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import hipref
+from hipref import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def ptr(t):
+    return t.data_ptr()
+
+
+@pytest.mark.parametrize("N", [64, 128])
+def test_full_size_properties(oracle, N):
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, N)
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    props = np.loadtxt(os.path.join(orc.REFDATA, "props_cp_voce.txt")).ravel()
+    ctx = L.Context(L.EXA_FCC_VOCE, props, 298.0, 1, E, assembly=L.EXA_ASSEMBLY_PA)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+    quats = hipref.random_quats(E)
+    d_sv = [dev.zeros(28 * P), dev.zeros(28 * P)]
+    d_s = [dev.zeros(6 * P), dev.zeros(6 * P)]
+    d_cm = dev.zeros(36 * P); d_J = dev.zeros(9 * P)
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_sv[0]), ptr(dev.up(quats.ravel())), None))
+    v_nodes = hipref.velocity_field(rve)
+    d_v = dev.up(v_nodes); d_x = dev.up(rve["X"])
+    dts = [0.005, 0.195, 0.4, 0.4]                      # 0.1 % strain: plastic
+    for i, dt in enumerate(dts):
+        d_x += dt * d_v
+        if i == len(dts) - 1:
+            sv_in, s_in = d_sv[0].clone(), d_s[0].clone()
+        ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(d_s[0]), ptr(d_sv[0]), ptr(d_s[1]), ptr(d_sv[1]), ptr(d_cm), ptr(d_J), None))
+        assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+        d_sv.reverse(); d_s.reverse()
+    sig, sv1 = d_s[0], d_sv[0]                            # end-of-step values of the last pass
+    assert float(sv1.view(P, 28)[:, 14:26].abs().sum(dim=1).min()) > 0          # every point is slipping
+
+    # ---- (1) sampled elements against the oracle on identical inputs
+    rng = np.random.default_rng(N)
+    es = np.sort(rng.choice(E, 48, replace=False))
+    qidx = torch.from_numpy((es[:, None] * Q + np.arange(Q)[None, :]).ravel()).to(dev.dev)
+    take = lambda t, w: t.view(P, w)[qidx].cpu().numpy().ravel()
+    sub = dict(rve, E=len(es))
+    conn = rve["conn"].reshape(E, n)[es]
+    x_end = d_x.cpu().numpy(); 
+    xe = np.stack([x_end[conn + NN * c] for c in range(3)], axis=1).ravel()
+    ve = np.stack([v_nodes[conn + NN * c] for c in range(3)], axis=1).ravel()
+    Js = np.zeros(9 * len(es) * Q); orc.lib().orc_jacobians(1, len(es), orc._p(xe), orc._p(Js))
+    assert rel_l2(take(d_J, 9), Js) < 1e-13
+    s1 = np.zeros(6 * len(es) * Q); sv = np.zeros(28 * len(es) * Q); cm = np.zeros(36 * len(es) * Q)
+    nf = orc.lib().orc_model_setup(0, 0, orc._p(props), len(props), Q, len(es), n, 28, C.c_double(dts[-1]), C.c_double(298.0), orc._p(Js), orc._p(rve["G"]),
+                                   orc._p(ve), orc._p(take(s_in, 6)), orc._p(take(sv_in, 28)), orc._p(s1), orc._p(sv), orc._p(cm), None, 1, 0, 0)
+    assert nf == 0
+    assert rel_l2(take(sig, 6), s1) < 1e-9
+    assert rel_l2(take(d_cm, 36), cm) < 1e-7
+    keep = np.ones(28, bool); keep[3] = False
+    assert rel_l2(take(sv1, 28).reshape(-1, 28)[:, keep], sv.reshape(-1, 28)[:, keep]) < 1e-8
+
+    # ---- (2) self-equilibrated internal forces
+    d_y = dev.zeros(3 * NN)
+    ctx.check(L.exa_residual_lvec(ctx.h, ptr(d_J), ptr(sig), ptr(d_y), None))
+    y = d_y.view(3, NN)
+    assert float(y.sum(dim=1).abs().max()) < 1e-10 * float(y.abs().sum())
+
+    # ---- (3) gradient action: linear, and PA == EA on the same tangent field
+    ctx.check(L.exa_grad_setup(ctx.h, dts[-1], ptr(d_J), ptr(d_cm), None))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x1 = torch.rand(3 * NN, generator=g, dtype=torch.float64).to(dev.dev) - 0.5
+    x2 = torch.rand(3 * NN, generator=g, dtype=torch.float64).to(dev.dev) - 0.5
+    mask = torch.zeros(3 * NN, dtype=torch.uint8, device=dev.dev)
+
+    def apply(c, x):
+        y = dev.zeros(3 * NN)
+        c.check(L.exa_grad_apply_lvec(c.h, ptr(x), ptr(y), ptr(mask), None))
+        return y
+    y1, y2, y12 = apply(ctx, x1), apply(ctx, x2), apply(ctx, 0.7 * x1 - 1.9 * x2)
+    assert float((y12 - (0.7 * y1 - 1.9 * y2)).norm() / y12.norm()) < 1e-12
+    ea = L.Context(L.EXA_FCC_VOCE, props, 298.0, 1, E, assembly=L.EXA_ASSEMBLY_EA)
+    ea.check(L.exa_set_connectivity(ea.h, ptr(d_conn), NN))
+    # The reference's AssembleEA contracts the tangent with the trial/test roles exchanged relative to AssembleGradPA
+    # (src/mechanics_integrators.cpp:893-960 vs :425-511,592-620): for a non-symmetric tangent EA(C) == PA(C^T).  Its own
+    # equivalence tests use symmetric C only (test/mechanics_test.cpp); both paths here follow the reference, so the identity
+    # is checked with the transposed field (and the raw difference is of the size of the tangent's asymmetry, ~1e-4).
+    d_cmT = d_cm.view(P, 6, 6).transpose(1, 2).contiguous().view(-1)
+    ea.check(L.exa_grad_setup(ea.h, dts[-1], ptr(d_J), ptr(d_cmT), None))
+    z1 = apply(ea, x1)
+    assert float((z1 - y1).norm() / y1.norm()) < 1e-12
+    ea.check(L.exa_grad_setup(ea.h, dts[-1], ptr(d_J), ptr(d_cm), None))
+    assert float((apply(ea, x1) - y1).norm() / y1.norm()) < 1e-3
+    ea.close(); ctx.close()

@@ -155,3 +155,27 @@ def test_bbar_nrls_case_runs(oracle):
     # B-bar only changes the volumetric sampling: same average stress to a few percent on this coarse mesh, not identical
     d = np.abs(out["avg_stress"][:, 2] / ref["avg_stress"][:, 2] - 1.0)
     assert 1e-9 < d.max() < 5e-2
+
+
+def test_ea_is_pa_of_transposed_tangent(oracle):
+    """Reference fact worth pinning: with a NON-symmetric tangent the reference's element-assembly operator equals its
+    partial-assembly operator applied to the transposed tangent (AssembleEA src/mechanics_integrators.cpp:893-960 vs
+    AssembleGradPA/AddMultGradPA :425-511,592-620); the reference's own equivalence tests only use symmetric C."""
+    orc = oracle
+    rve = hipref.make_rve(orc, 2, p=1, distort=0.2)
+    E, Q, n = rve["E"], rve["Q"], rve["n"]
+    P = E * Q
+    xe = hipref.l_to_e(rve, rve["X"])
+    J = np.zeros(9 * P); orc.lib().orc_jacobians(1, E, orc._p(xe), orc._p(J))
+    rng = np.random.default_rng(0)
+    Cb = rng.uniform(-1, 1, (P, 6, 6))
+    x = rng.uniform(-1, 1, 3 * n * E)
+    C4 = np.zeros(81 * P); D4 = np.zeros(81 * P)
+    orc.lib().orc_transform_4d(C.c_int64(P), orc._p(Cb.ravel().copy()), orc._p(C4))
+    orc.lib().orc_assemble_grad_pa(Q, E, C.c_double(1.0), orc._p(rve["W"]), orc._p(J), orc._p(C4), orc._p(D4))
+    y_pa = np.zeros(3 * n * E); orc.lib().orc_add_mult_grad_pa(Q, E, n, orc._p(rve["G"]), orc._p(D4), orc._p(x), orc._p(y_pa))
+    for Cuse, same in ((Cb, False), (Cb.transpose(0, 2, 1), True)):
+        emat = np.zeros(9 * n * n * E)
+        orc.lib().orc_assemble_ea(Q, E, n, C.c_double(1.0), orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(np.ascontiguousarray(Cuse).ravel()), orc._p(emat))
+        y_ea = np.zeros(3 * n * E); orc.lib().orc_ea_mult(E, n, orc._p(emat), orc._p(x), orc._p(y_ea))
+        assert (rel_l2(y_pa, y_ea) < 1e-13) == same
