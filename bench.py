@@ -201,6 +201,13 @@ def main():
                 traffic["_file"] = "profiles/" + cands[-1]
         except Exception:
             traffic = {}
+        flops = None
+        try:
+            cf = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_flops.json"))
+            if cf:
+                flops = json.load(open(os.path.join(ROOT, "profiles", cf[-1])))["k_model_setup"]["plastic"]["flop_per_qpt"]
+        except Exception:
+            flops = None
         model_gbs = MODEL_BYTES_PER_QPT * P_local / (kern_ms * 1e-3) / 1e9
         apply_gbs = APPLY_BYTES_PER_QPT * P_local / (apply_ms * 1e-3) / 1e9
         iter_bytes = APPLY_BYTES_PER_QPT * P_local + PCG_VEC_BYTES_PER_DOF * ndof_local
@@ -218,7 +225,10 @@ def main():
                          "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS,
                          "traffic": traffic["k_model_setup"] * P_local if "k_model_setup" in traffic else None, "traffic_source": traffic.get("_file"),
                          "bytes_per_qpt": MODEL_BYTES_PER_QPT, "avg_kernel_ms": kern_ms,
-                         "note": "FP64-VALU/transcendental-bound kernel (SURVEY 8(d)): the HBM fraction is reported as the contract asks; "
+                         "fp64_flop_per_qpt": flops, "fp64_tflops": (flops * P_local / (kern_ms * 1e-3) / 1e12) if flops else None,
+                         "fp64_vector_frac": (flops * P_local / (kern_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TFLOPS) if flops else None,
+                         "note": "FP64-VALU-bound kernel (78 % VALU-busy, SURVEY 8(d)): the HBM fraction of the ALGORITHMIC bytes is reported as the "
+                                 "contract asks; measured traffic (PMC) is ~2x the algorithmic bytes (parking + spills, DESIGN 4.1); "
                                  "see roofline_pcg_apply for the HBM-bound half of the metric"},
             "roofline_pcg_apply": {"kernel": "k_grad_apply_p1<LVEC> (AddMultGradPA + gather/scatter)", "bound": "hbm", "achieved": apply_gbs,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": apply_gbs / HBM_PEAK_GBS,
