@@ -111,6 +111,8 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if os.environ.get("EXA_BENCH_SAME_DEVICE"):   # plumbing check of the multi-rank path on a one-GPU box (all ranks share device 0)
+        local = 0
     torch.cuda.set_device(local)
     uid = None
     if world > 1:

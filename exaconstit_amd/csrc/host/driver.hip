@@ -3,6 +3,8 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -50,13 +52,47 @@ RcclApi& rccl() {
 void nccl_check(ncclResult_t r, const char* what) { if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + rccl().GetErrorString(r)); }
 }  // namespace
 
+// ---- in-process loopback transport (test infrastructure for the multi-rank logic on a one-GPU box) -----------------------------
+// Several SystemDrivers, one host thread each, share one device; collectives are host-synchronous exchanges through this group.
+// It exercises exactly the code RCCL is used from (partition, pack / unpack-add, weighted dots, reductions); only the RCCL calls
+// themselves are replaced.  RCCL cannot be used for this: it refuses two ranks on one device ("Duplicate GPU detected").
+struct LoopbackGroup {
+   int n; std::mutex m; std::condition_variable cv; int waiting = 0; uint64_t gen = 0;
+   std::vector<std::vector<double>> red;                 // per-rank contribution of the current reduction
+   std::vector<std::vector<const double*>> sendbuf;      // [rank][neighbour slot] device send buffers of the current halo exchange
+   std::vector<std::vector<int>> nbr_rank;               // [rank][slot] neighbour rank
+   explicit LoopbackGroup(int n_) : n(n_), red(n_), sendbuf(n_), nbr_rank(n_) {}
+   void barrier() {
+      std::unique_lock<std::mutex> lk(m);
+      const uint64_t g = gen;
+      if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); }
+      else cv.wait(lk, [&] { return gen != g; });
+   }
+};
+static const char kLoopMagic[8] = { 'E', 'X', 'A', 'L', 'O', 'O', 'P', '1' };
+
+void Comm::loopback_create(int nranks, void* out128) {
+   std::memset(out128, 0, 128);
+   std::memcpy(out128, kLoopMagic, 8);
+   LoopbackGroup* g = new LoopbackGroup(nranks);
+   std::memcpy((char*)out128 + 8, &g, sizeof(g));
+}
+void Comm::loopback_destroy(const void* id128) {
+   if (std::memcmp(id128, kLoopMagic, 8) != 0) return;
+   LoopbackGroup* g; std::memcpy(&g, (const char*)id128 + 8, sizeof(g)); delete g;
+}
+
 void Comm::get_unique_id(void* out128) { ncclUniqueId id; nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId"); std::memcpy(out128, &id, sizeof(id)); }
 
 void Comm::init(int rank_, int nranks_, const void* uid) {
    rank = rank_; nranks = nranks_;
    // EXA_FORCE_RCCL=1 routes the one-rank case through RCCL too (plumbing check on a single-GPU box)
    force_ = (nranks == 1 && std::getenv("EXA_FORCE_RCCL") != nullptr);
-   if (nranks > 1 || force_) {
+   if (uid && std::memcmp(uid, kLoopMagic, 8) == 0) {
+      LoopbackGroup* g; std::memcpy(&g, (const char*)uid + 8, sizeof(g));
+      if (g->n != nranks) throw std::runtime_error("Comm::init: loopback group size mismatch");
+      loop_ = g;
+   } else if (nranks > 1 || force_) {
       ncclUniqueId id;
       if (uid) std::memcpy(&id, uid, sizeof(id));
       else if (force_) nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
@@ -68,11 +104,29 @@ void Comm::init(int rank_, int nranks_, const void* uid) {
 }
 Comm::~Comm() { if (comm_) rccl().CommDestroy((ncclComm_t)comm_); }
 
-void Comm::allreduce_sum(double* dev, int n, hipStream_t s) { if (nranks > 1 || force_) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)comm_, s), "ncclAllReduce"); }
-void Comm::allreduce_min(double* dev, int n, hipStream_t s) { if (nranks > 1 || force_) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclMin, (ncclComm_t)comm_, s), "ncclAllReduce"); }
+// op: 0 sum, 1 min, 2 max; host-synchronous, rank-ordered (deterministic)
+void Comm::loopback_reduce(double* dev, int n, int op, hipStream_t s) {
+   LoopbackGroup* g = (LoopbackGroup*)loop_;
+   std::vector<double>& mine = g->red[rank]; mine.resize(n);
+   EXA_HC(hipMemcpyAsync(mine.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+   g->barrier();
+   std::vector<double> r(g->red[0].begin(), g->red[0].begin() + n);
+   for (int k = 1; k < g->n; k++) for (int i = 0; i < n; i++) { const double v = g->red[k][i]; r[i] = op == 0 ? r[i] + v : (op == 1 ? std::min(r[i], v) : std::max(r[i], v)); }
+   g->barrier();   // everybody has read before the next reduction overwrites
+   EXA_HC(hipMemcpyAsync(dev, r.data(), sizeof(double) * n, hipMemcpyHostToDevice, s)); EXA_HC(hipStreamSynchronize(s));
+}
+void Comm::allreduce_sum(double* dev, int n, hipStream_t s) {
+   if (loop_) { if (nranks > 1) loopback_reduce(dev, n, 0, s); return; }
+   if (nranks > 1 || force_) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)comm_, s), "ncclAllReduce");
+}
+void Comm::allreduce_min(double* dev, int n, hipStream_t s) {
+   if (loop_) { if (nranks > 1) loopback_reduce(dev, n, 1, s); return; }
+   if (nranks > 1 || force_) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclMin, (ncclComm_t)comm_, s), "ncclAllReduce");
+}
 
 double Comm::max_over_ranks(double v) {
    if (nranks == 1) return v;
+   if (loop_) { EXA_HC(hipMemcpy(tmp_.p, &v, sizeof(double), hipMemcpyHostToDevice)); loopback_reduce(tmp_.p, 1, 2, nullptr); EXA_HC(hipMemcpy(&v, tmp_.p, sizeof(double), hipMemcpyDeviceToHost)); return v; }
    EXA_HC(hipMemcpy(tmp_.p, &v, sizeof(double), hipMemcpyHostToDevice));
    nccl_check(rccl().AllReduce(tmp_.p, tmp_.p, 1, ncclDouble, ncclMax, (ncclComm_t)comm_, nullptr), "ncclAllReduce");
    EXA_HC(hipMemcpy(&v, tmp_.p, sizeof(double), hipMemcpyDeviceToHost));
@@ -91,6 +145,26 @@ void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
    if (nranks == 1 && !force_) return;
    const size_t nb = part.nbrs.size();
    for (size_t i = 0; i < nb; i++) vk_pack((int64_t)idx_[i].n, idx_[i].p, y, sbuf_[i].p, s);
+   if (loop_) {
+      LoopbackGroup* g = (LoopbackGroup*)loop_;
+      g->sendbuf[rank].resize(nb); g->nbr_rank[rank].resize(nb);
+      for (size_t i = 0; i < nb; i++) { g->sendbuf[rank][i] = sbuf_[i].p; g->nbr_rank[rank][i] = part.nbrs[i].rank; }
+      EXA_HC(hipStreamSynchronize(s));
+      g->barrier();
+      for (size_t i = 0; i < nb; i++) {   // my slot i talks to rank r; r's slot that talks to me holds what I receive (same dof order on both sides)
+         const int r = part.nbrs[i].rank; const double* src = nullptr;
+         for (size_t k = 0; k < g->nbr_rank[r].size(); k++) if (g->nbr_rank[r][k] == rank) {
+            // a pair of ranks can be neighbours through exactly one (dx,dy,dz) offset in a block decomposition
+            src = g->sendbuf[r][k]; break;
+         }
+         if (!src) throw std::runtime_error("loopback halo: asymmetric neighbour lists");
+         EXA_HC(hipMemcpyAsync(rbuf_[i].p, src, sizeof(double) * rbuf_[i].n, hipMemcpyDeviceToDevice, s));
+      }
+      EXA_HC(hipStreamSynchronize(s));
+      g->barrier();
+      for (size_t i = 0; i < nb; i++) vk_unpack_add((int64_t)idx_[i].n, idx_[i].p, rbuf_[i].p, y, s);
+      return;
+   }
    nccl_check(rccl().GroupStart(), "ncclGroupStart");
    for (size_t i = 0; i < nb; i++) {
       nccl_check(rccl().Send(sbuf_[i].p, sbuf_[i].n, ncclDouble, part.nbrs[i].rank, (ncclComm_t)comm_, s), "ncclSend");

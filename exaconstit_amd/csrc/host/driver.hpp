@@ -26,6 +26,9 @@ class Comm {
    ~Comm();
    void init(int rank_, int nranks_, const void* nccl_unique_id /*128 bytes, identical on all ranks*/);
    static void get_unique_id(void* out128);
+   // in-process loopback transport for tests: several ranks (one host thread each) on ONE device, host-synchronous exchanges
+   static void loopback_create(int nranks, void* out128);
+   static void loopback_destroy(const void* id128);
    void allreduce_sum(double* dev, int n, hipStream_t s);
    void allreduce_min(double* dev, int n, hipStream_t s);
    // y(shared dofs) <- sum over all ranks holding them
@@ -33,7 +36,8 @@ class Comm {
    void setup_halo(const Partition& part);
    double max_over_ranks(double v);
  private:
-   void* comm_ = nullptr; bool force_ = false;
+   void loopback_reduce(double* dev, int n, int op, hipStream_t s);
+   void* comm_ = nullptr; void* loop_ = nullptr; bool force_ = false;
    std::vector<DevBuf<int32_t>> idx_; std::vector<DevBuf<double>> sbuf_, rbuf_;
    DevBuf<double> tmp_;
 };

@@ -24,6 +24,9 @@ int exa_rccl_unique_id(void* out128) {
    try { Comm::get_unique_id(out128); return 0; } catch (const std::exception& e) { std::fprintf(stderr, "exa_rccl_unique_id: %s\n", e.what()); return -1; }
 }
 
+int exa_loopback_group_create(int nranks, void* out128) { try { Comm::loopback_create(nranks, out128); return 0; } catch (...) { return -1; } }
+void exa_loopback_group_destroy(const void* id128) { Comm::loopback_destroy(id128); }
+
 exa_driver* exa_driver_create(const char* toml_path, const char* out_dir, int rank, int nranks, const void* uid, int jacobi, int write_files, char* err, int errlen) {
    try {
       ExaOptions opt; opt.parse_options(toml_path);

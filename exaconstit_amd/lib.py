@@ -126,6 +126,8 @@ class ExaSynthConfig(C.Structure):
 
 
 exa_rccl_unique_id = _sig("exa_rccl_unique_id", C.c_int, C.c_void_p)
+exa_loopback_group_create = _sig("exa_loopback_group_create", C.c_int, C.c_int, C.c_void_p)
+exa_loopback_group_destroy = _sig("exa_loopback_group_destroy", None, C.c_void_p)
 exa_driver_create = _sig("exa_driver_create", C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int)
 exa_driver_create_synthetic = _sig("exa_driver_create_synthetic", C.c_void_p, C.POINTER(ExaSynthConfig), C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int)
 exa_driver_destroy = _sig("exa_driver_destroy", None, C.c_void_p)

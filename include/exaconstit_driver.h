@@ -30,6 +30,10 @@ typedef struct {
 } exa_synth_config;
 
 int exa_rccl_unique_id(void* out128);
+/* Test transport: `nranks` drivers on ONE device, one host thread each, exchanging through an in-process group instead of RCCL
+ * (RCCL refuses two ranks on one device).  Pass the 128 bytes as the unique id of every rank; destroy after the drivers. */
+int exa_loopback_group_create(int nranks, void* out128);
+void exa_loopback_group_destroy(const void* id128);
 exa_driver* exa_driver_create(const char* toml_path, const char* out_dir, int rank, int nranks, const void* uid, int jacobi, int write_files, char* err, int errlen);
 exa_driver* exa_driver_create_synthetic(const exa_synth_config* c, int rank, int nranks, const void* uid, char* err, int errlen);
 void exa_driver_destroy(exa_driver* d);
