@@ -29,6 +29,8 @@ FP64_VEC_PEAK_TFLOPS = 78.6       # vendor FP64 vector peak, for the information
 MODEL_BYTES_PER_QPT = 928.0       # read v 3 + J 9 + state 28 + sigma 6, write state 28 + sigma 6 + tangent 36 doubles
 APPLY_BYTES_PER_QPT = 408.0       # tangent 36 + Jacobian 9 + x 3 + y 3 doubles
 PCG_VEC_BYTES_PER_DOF = 128.0
+MODEL_NAMES = {"fcc_voce": "FCC Voce power-law", "bcc_voce": "BCC Voce power-law", "fcc_voce_nl": "FCC non-linear Voce",
+               "fcc_kmdd": "FCC Kocks-Mecking dislocation density", "bcc_kmdd": "BCC Kocks-Mecking dislocation density"}
 PREP_DTS = [0.005, 0.195, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1]   # first 10 steps of the reference schedule: 0.1 % strain, plastic
 
 
@@ -101,6 +103,8 @@ def main():
     ap.add_argument("--n", type=int, default=int(os.environ.get("EXA_BENCH_N", "128")), help="elements per edge of the RVE (default 128)")
     ap.add_argument("--pcg-iters", type=int, default=100)
     ap.add_argument("--assembly", default="PA")
+    ap.add_argument("--model", default="fcc_voce", choices=["fcc_voce", "bcc_voce", "fcc_voce_nl", "fcc_kmdd", "bcc_kmdd"],
+                    help="crystal model of the RVE; the headline metric is quoted on fcc_voce (BASELINE config 4 also names bcc_kmdd)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solve-steps", type=int, default=0, help="additionally run this many real Newton/PCG time steps and report their rates")
     args = ap.parse_args()
@@ -139,11 +143,14 @@ def main():
         return float(t.item())
 
     N = args.n
-    props = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "props_cp_voce.txt")).ravel()
+    xt, sl = args.model.split("_", 1)
+    pfile = {"voce": "props_cp_voce.txt", "voce_nl": "props_cp_vocenl.txt", "kmdd": "props_cp_mts.txt"}[sl]
+    mk = dict(bcc=(xt == "bcc"), slip={"voce": 0, "voce_nl": 1, "kmdd": 2}[sl], temp_k=298.0)
+    props = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", pfile)).ravel()
     rng = np.random.default_rng(20240928)
     quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
     drv = L.Driver.synthetic(N, props, quats.ravel(), np.array(PREP_DTS), assembly=0 if args.assembly.upper() == "PA" else 1,
-                             krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=uid)
+                             krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=uid, **mk)
     del quats
     # elastic regime (first step of the schedule from the virgin state), reported beside the headline plastic-regime value
     drv.bench_prepare(PREP_DTS[:1], advance=False)
@@ -182,7 +189,7 @@ def main():
         rng = np.random.default_rng(20240928)
         quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
         sched = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "custom_dt.txt")).ravel()[:args.solve_steps]
-        drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=0 if args.assembly.upper() == "PA" else 1, rank=rank, nranks=world, uid=uid)
+        drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=0 if args.assembly.upper() == "PA" else 1, rank=rank, nranks=world, uid=uid, **mk)
         barrier(); t0 = time.perf_counter()
         for ti in range(1, args.solve_steps + 1):
             assert drv.step(ti), f"Newton failed at step {ti}"
@@ -218,12 +225,12 @@ def main():
             "value": value, "unit": "qpt-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": t_model / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{N}^3 hex RVE p=1, FCC Voce power-law (ExaCMech evptn), plastic regime; "
+            "config": {"workload": f"{N}^3 hex RVE p=1, {MODEL_NAMES[args.model]} (ExaCMech evptn), plastic regime; "
                                    f"{'partial' if args.assembly.upper() == 'PA' else 'element'}-assembly PCG", "elements": N ** 3,
                        "qpts": P_global, "decomposition": f"{world} block(s)"},
             "pcg_iters_per_s": pcg_it_s, "pcg_iters": pc["iters"], "pcg_ms_per_iter": pcg_ms / max(pc["iters"], 1),
             "pcg_wall_s": t_pcg_wall, "nonconverged_points": m["failed"], "elastic_regime": elastic,
-            "roofline": {"kernel": "k_model_setup<Voce> (fused grad_calc + ExaCMech update + tangent)", "bound": "hbm",
+            "roofline": {"kernel": f"k_model_setup<{'KM-DD' if 'kmdd' in args.model else 'Voce'}> (fused node gather + grad_calc + ExaCMech update + tangent)", "bound": "hbm",
                          "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS,
                          "traffic": traffic["k_model_setup"] * P_local if "k_model_setup" in traffic else None, "traffic_source": traffic.get("_file"),
                          "bytes_per_qpt": MODEL_BYTES_PER_QPT, "avg_kernel_ms": kern_ms,

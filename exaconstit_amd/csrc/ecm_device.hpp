@@ -244,19 +244,22 @@ ECM_DI void voce_gdot12(const MatParams& mp, double g_i, const double tau[NSLIP]
    }
 }
 
+// keeps a uniform branch a branch: without it the compiler speculates the (pure) pow() of the general case and selects afterwards,
+// i.e. every call pays two full pow() expansions (~400 instructions) even when p == q == 1
+#define ECM_NO_SPECULATE() asm volatile("" ::: "memory")
 ECM_DI void mts_dG(const MatParams& mp, double c_e, double t_frac, double& exp_arg, double& dfac) {
    exp_arg = 0.0; dfac = 0.0;
    if (t_frac >= 1.0) return;
    double p_func, dp_func;
    const double at = fabs(t_frac);
-   if (at < TINY_SQRT) { p_func = 0.0; dp_func = (mp.p == 1.0) ? 1.0 : 0.0; }
-   else if (mp.p == 1.0) { p_func = t_frac; dp_func = 1.0; }
-   else { const double pw = pow(at, mp.p); p_func = copysign(pw, t_frac); dp_func = mp.p * pw / at; }
+   if (mp.p == 1.0) { p_func = t_frac; dp_func = 1.0; }
+   else if (at < TINY_SQRT) { p_func = 0.0; dp_func = 0.0; }
+   else { ECM_NO_SPECULATE(); const double pw = pow(at, mp.p); p_func = copysign(pw, t_frac); dp_func = mp.p * pw / at; }
    const double q_arg = 1.0 - p_func;
    if (q_arg <= TINY_SQRT) return;
    double q_func, dq_func;
    if (mp.q == 1.0) { q_func = q_arg; dq_func = 1.0; }
-   else { q_func = pow(q_arg, mp.q); dq_func = mp.q * q_func / q_arg; }
+   else { ECM_NO_SPECULATE(); q_func = pow(q_arg, mp.q); dq_func = mp.q * q_func / q_arg; }
    exp_arg = -c_e * q_func; dfac = c_e * dq_func * dp_func;
 }
 

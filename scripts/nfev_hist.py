@@ -10,10 +10,12 @@ from hipref import ptr
 orc.build()
 dev = hipref.Dev()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+MODEL = sys.argv[2] if len(sys.argv) > 2 else "fcc_voce"
+MID = {"fcc_voce": (L.EXA_FCC_VOCE, "props_cp_voce.txt"), "bcc_voce": (L.EXA_BCC_VOCE, "props_cp_voce.txt"), "fcc_kmdd": (L.EXA_FCC_KMDD, "props_cp_mts.txt"), "bcc_kmdd": (L.EXA_BCC_KMDD, "props_cp_mts.txt")}[MODEL]
 rve = hipref.make_rve(orc, N)
 P = rve["E"] * 8
-props = np.loadtxt(os.path.join(orc.REFDATA, "props_cp_voce.txt")).ravel()
-ctx = L.Context(L.EXA_FCC_VOCE, props, 298.0, 1, rve["E"])
+props = np.loadtxt(os.path.join(orc.REFDATA, MID[1])).ravel()
+ctx = L.Context(MID[0], props, 298.0, 1, rve["E"])
 quats = hipref.random_quats(rve["E"])
 d_q = dev.up(quats.ravel()); sv0 = dev.zeros(28 * P); sv1 = dev.zeros(28 * P); s0 = dev.zeros(6 * P); s1 = dev.zeros(6 * P); cm = dev.zeros(36 * P)
 ctx.check(L.exa_init_state(ctx.h, ptr(sv0), ptr(d_q), None))

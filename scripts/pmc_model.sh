@@ -1,7 +1,7 @@
 #!/bin/bash
 # run on the GPU box: SQ counter pass over the model kernel (last dispatch = plastic-regime pass of bench.py)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python bench.py --steps 3 --warmup 1 --pcg-iters 10 --no-cpu-baseline"
+CMD="python bench.py --model ${MODEL:-fcc_voce} --steps 3 --warmup 1 --pcg-iters 10 --no-cpu-baseline"
 tag=${1:-pmc_model}
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_FLAT --output-format csv -d gpurun_out/$tag -- $CMD > gpurun_out/$tag.log 2>&1
 python - <<PY

@@ -1,10 +1,11 @@
 #!/bin/bash
 # run on the GPU box: rebuild the model kernel with different tuning macros and time the 128^3 constitutive pass
-# usage: scripts/tune_model.sh "<TUNE flags>" ["<TUNE flags>" ...]
+# usage: MODEL=fcc_voce scripts/tune_model.sh "<TUNE flags>" ["<TUNE flags>" ...]
+MODEL=${MODEL:-fcc_voce}
 cd $GRAFT_REPO_ROOT/exaconstit_amd/csrc
 for cfg in "$@"; do
   rm -f model_kernels.o
   make -s -j8 TUNE="$cfg" 2>&1 | grep -E "error"
-  (cd $GRAFT_REPO_ROOT && python bench.py --steps 5 --warmup 1 --pcg-iters 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('TUNE=[$cfg]', 'value %.4g' % d['value'], 'kernel_ms %.3f' % d['roofline']['avg_kernel_ms'], 'elastic_ms %.3f' % d['elastic_regime']['avg_kernel_ms'], 'fail', d['nonconverged_points'])")
+  (cd $GRAFT_REPO_ROOT && python bench.py --model $MODEL --steps 5 --warmup 1 --pcg-iters 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$MODEL TUNE=[$cfg]', 'value %.4g' % d['value'], 'kernel_ms %.3f' % d['roofline']['avg_kernel_ms'], 'elastic_ms %.3f' % d['elastic_regime']['avg_kernel_ms'], 'fail', d['nonconverged_points'])")
 done
 rm -f model_kernels.o
