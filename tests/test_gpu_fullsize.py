@@ -104,3 +104,80 @@ def test_full_size_properties(oracle, N):
     ea.check(L.exa_grad_setup(ea.h, dts[-1], ptr(d_J), ptr(d_cm), None))
     assert float((apply(ea, x1) - y1).norm() / y1.norm()) < 1e-3
     ea.close(); ctx.close()
+
+
+def test_full_size_order2_bbar_element_assembly(oracle):
+    """BASELINE config 5 shape (64^3 elements, p = 2, B-bar, element assembly): a sample of elements is re-computed by the oracle
+    from the inputs of the GPU pass — constitutive update (27 points / element), B-bar residual and B-bar element matrices — and
+    the element mat-vec is checked for linearity on the full operator."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    N, p = 64, 2
+    rve = hipref.make_rve(orc, N, p=p)
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    props = np.loadtxt(os.path.join(orc.REFDATA, "props_cp_voce.txt")).ravel()
+    ctx = L.Context(L.EXA_FCC_VOCE, props, 298.0, p, E, assembly=L.EXA_ASSEMBLY_EA, integ=L.EXA_INTEG_BBAR)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+    d_sv = [dev.zeros(28 * P), dev.zeros(28 * P)]; d_s = [dev.zeros(6 * P), dev.zeros(6 * P)]
+    d_cm = dev.zeros(36 * P); d_J = dev.zeros(9 * P)
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_sv[0]), ptr(dev.up(hipref.random_quats(E).ravel())), None))
+    v_nodes = hipref.velocity_field(rve)
+    d_v = dev.up(v_nodes); d_x = dev.up(rve["X"])
+    dts = [0.2, 0.4, 0.4]
+    for i, dt in enumerate(dts):
+        d_x += dt * d_v
+        if i == len(dts) - 1:
+            sv_in, s_in = d_sv[0].clone(), d_s[0].clone()
+        ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(d_s[0]), ptr(d_sv[0]), ptr(d_s[1]), ptr(d_sv[1]), ptr(d_cm), ptr(d_J), None))
+        assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+        d_sv.reverse(); d_s.reverse()
+    sig = d_s[0]
+    # ---- sample
+    rng = np.random.default_rng(3)
+    es = np.sort(rng.choice(E, 16, replace=False)); ns = len(es)
+    qidx = torch.from_numpy((es[:, None] * Q + np.arange(Q)[None, :]).ravel()).to(dev.dev)
+    take = lambda t, w: t.view(P, w)[qidx].cpu().numpy().ravel()
+    conn = rve["conn"].reshape(E, n)[es]
+    x_end = d_x.cpu().numpy()
+    xe = np.stack([x_end[conn + NN * c] for c in range(3)], axis=1).ravel()
+    ve = np.stack([v_nodes[conn + NN * c] for c in range(3)], axis=1).ravel()
+    Js = np.zeros(9 * ns * Q); orc.lib().orc_jacobians(p, ns, orc._p(xe), orc._p(Js))
+    assert rel_l2(take(d_J, 9), Js) < 1e-13
+    s1 = np.zeros(6 * ns * Q); sv = np.zeros(28 * ns * Q); cm = np.zeros(36 * ns * Q)
+    nf = orc.lib().orc_model_setup(0, 0, orc._p(props), len(props), Q, ns, n, 28, C.c_double(dts[-1]), C.c_double(298.0), orc._p(Js), orc._p(rve["G"]),
+                                   orc._p(ve), orc._p(take(s_in, 6)), orc._p(take(sv_in, 28)), orc._p(s1), orc._p(sv), orc._p(cm), None, 1, 0, 0)
+    assert nf == 0
+    assert rel_l2(take(sig, 6), s1) < 1e-9 and rel_l2(take(d_cm, 36), cm) < 1e-7
+    # ---- B-bar residual of the sampled elements (E-vector) and B-bar element matrices
+    eDS = np.zeros(3 * n * ns); orc.lib().orc_element_eds(Q, ns, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(Js), orc._p(eDS))
+    y_ref = np.zeros(3 * n * ns)
+    orc.lib().orc_add_mult_pa_bbar(Q, ns, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(Js), orc._p(eDS), orc._p(s1), orc._p(y_ref))
+    d_ye = dev.zeros(3 * n * E)
+    ctx.check(L.exa_residual_setup(ctx.h, ptr(d_J), ptr(sig), None))
+    ctx.check(L.exa_residual_apply(ctx.h, ptr(d_ye), None))
+    eidx = torch.from_numpy(es).to(dev.dev)
+    assert rel_l2(d_ye.view(E, 3 * n)[eidx].cpu().numpy(), y_ref) < 1e-9     # sigma itself agrees to 1e-9
+    ctx.check(L.exa_grad_setup(ctx.h, dts[-1], ptr(d_J), ptr(d_cm), None))
+    emat = np.zeros(9 * n * n * ns)
+    orc.lib().orc_assemble_ea_bbar(Q, ns, n, C.c_double(dts[-1]), orc._p(rve["W"]), orc._p(rve["G"]), orc._p(Js), orc._p(eDS), orc._p(take(d_cm, 36)), orc._p(emat))
+    d_em = dev.zeros(9 * n * n * E)
+    ctx.check(L.exa_grad_get_ea(ctx.h, ptr(d_em), None))
+    assert rel_l2(d_em.view(E, 9 * n * n)[eidx].cpu().numpy(), emat) < 1e-11
+    del d_em
+    # ---- element mat-vec on the whole operator: linear
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x1 = torch.rand(3 * NN, generator=g, dtype=torch.float64).to(dev.dev) - 0.5
+    x2 = torch.rand(3 * NN, generator=g, dtype=torch.float64).to(dev.dev) - 0.5
+    mask = torch.zeros(3 * NN, dtype=torch.uint8, device=dev.dev)
+
+    def apply(x):
+        y = dev.zeros(3 * NN)
+        ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(x), ptr(y), ptr(mask), None))
+        return y
+    y1, y2, y12 = apply(x1), apply(x2), apply(0.7 * x1 - 1.9 * x2)
+    assert float((y12 - (0.7 * y1 - 1.9 * y2)).norm() / y12.norm()) < 1e-12
+    ctx.close()
