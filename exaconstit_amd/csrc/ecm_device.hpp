@@ -343,11 +343,14 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #ifndef ECM_STASH_STRIDE
 #define ECM_STASH_STRIDE 256
 #endif
-constexpr int ST_EN = 0, ST_DN = 5, ST_WN = 10, ST_TR = 13, ST_DL = 22, ST_WL = 27, ST_XS = 30, ST_SLOTS = 38;
+constexpr int ST_EN = 0, ST_DN = 5, ST_WN = 10, ST_XS = 13, ST_CD = 21, ST_SLOTS = 38;   // ST_XS: restore copy of the unknowns; ST_CD: parking slots
+constexpr int ST_NCD = ST_SLOTS - ST_CD;
 constexpr int CD_DSM = 0, CD_SOLD = 5, CD_QN = 10, CD_VOLD = 14, CD_VNEW = 15, CD_ENEW = 16, CD_DEFF = 17, CD_BULK = 18, CD_HU = 19;
 #define ECM_ST(p, slot) (p)[(slot) * ECM_STASH_STRIDE]
 // compiler-only barrier: what was parked must be re-loaded later instead of being kept alive in registers
 #define ECM_PARK_BARRIER() asm volatile("" ::: "memory")
+// parking slot c (compile-time): the first ST_NCD live in the LDS stash, the rest in the point's tangent slot in global memory
+#define ECM_CD(c) (*(((c) < ST_NCD) ? &ECM_ST(st, ST_CD + (((c) < ST_NCD) ? (c) : 0)) : &cold[c]))
 
 // ------------------------------------------------------------------------------------------------------------
 // the point problem: unknowns x = (delta e' / E_SCALE, xi / R_SCALE)
@@ -363,7 +366,7 @@ struct Prob {
 //                          M = diag(1/(kd dt)) + A  (Jee = M Kd)
 //   Jre = B Kd             B = Q G P^T
 //   Jer = -M35(d_lat) Tr,  Jrr = I/dt - hat(w_lat) Tr      with Tr, d_lat, w_lat of the last evaluation in the stash
-struct Jac { double A[15], B[3][5]; };
+struct Jac { double A[15], B[3][5]; double Tr[9], dl[5], wl[3]; };   // + rotation data of the evaluation (never live across one)
 
 ECM_DI constexpr int sidx(int i, int j) { return i <= j ? (i * (11 - i)) / 2 + (j - i) : (j * (11 - j)) / 2 + (i - j); }   // 5x5 symmetric packing
 
@@ -485,7 +488,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
    double A[9], Tr[9]; exp_map(xi, A, Tr);
    if (WITHJ) {
 #pragma unroll
-      for (int c = 0; c < 9; c++) ECM_ST(pb.st, ST_TR + c) = Tr[c];
+      for (int c = 0; c < 9; c++) jac.Tr[c] = Tr[c];
    }
    {
       double dn[5], d_lat[5];
@@ -495,7 +498,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 #pragma unroll
       for (int c = 0; c < 5; c++) {
          r[c] = (x[c] * (E_SCALE * pb.dt_ri) + dp[c] - d_lat[c]) * pb.sc;
-         if (WITHJ) ECM_ST(pb.st, ST_DL + c) = d_lat[c];
+         if (WITHJ) jac.dl[c] = d_lat[c];
       }
    }
    {
@@ -504,7 +507,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       for (int c = 0; c < 3; c++) {
          const double w_lat = A[c] * w0 + A[3 + c] * w1 + A[6 + c] * w2;
          r[5 + c] = (xi[c] * pb.dt_ri + mp.qsign * wp[c] - w_lat) * pb.sc;
-         if (WITHJ) ECM_ST(pb.st, ST_WL + c) = w_lat;
+         if (WITHJ) jac.wl[c] = w_lat;
       }
    }
    ECM_PARK_BARRIER();
@@ -528,35 +531,35 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
 }
 
 // ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
-ECM_DI void load_tr(const Prob& pb, double Tr[9]) { for (int c = 0; c < 9; c++) Tr[c] = ECM_ST(pb.st, ST_TR + c); }
-ECM_DI void load_dl(const Prob& pb, double d[5]) { for (int c = 0; c < 5; c++) d[c] = ECM_ST(pb.st, ST_DL + c); }
+ECM_DI void load_tr(const Jac& J, double Tr[9]) { for (int c = 0; c < 9; c++) Tr[c] = J.Tr[c]; }
+ECM_DI void load_dl(const Jac& J, double d[5]) { for (int c = 0; c < 5; c++) d[c] = J.dl[c]; }
 
 // Jer v_r = -M35(d_lat) (Tr v_r)
-ECM_DI void jer_mult(const Prob& pb, const double vr[3], double out[5]) {
-   double Tr[9]; load_tr(pb, Tr);
+ECM_DI void jer_mult(const Jac& J, const double vr[3], double out[5]) {
+   double Tr[9]; load_tr(J, Tr);
    double th[3];
 #pragma unroll
    for (int i = 0; i < 3; i++) th[i] = Tr[3 * i] * vr[0] + Tr[3 * i + 1] * vr[1] + Tr[3 * i + 2] * vr[2];
-   double d[5]; load_dl(pb, d);
+   double d[5]; load_dl(J, d);
    double M[5][3]; m35(d, M);
 #pragma unroll
    for (int k = 0; k < 5; k++) out[k] = -(M[k][0] * th[0] + M[k][1] * th[1] + M[k][2] * th[2]);
 }
 // Jer^T u_e
-ECM_DI void jer_mult_T(const Prob& pb, const double ue[5], double out[3]) {
-   double d[5]; load_dl(pb, d);
+ECM_DI void jer_mult_T(const Jac& J, const double ue[5], double out[3]) {
+   double d[5]; load_dl(J, d);
    double M[5][3]; m35(d, M);
    double th[3];
 #pragma unroll
    for (int j = 0; j < 3; j++) { double v = 0; for (int k = 0; k < 5; k++) v += M[k][j] * ue[k]; th[j] = -v; }
-   double Tr[9]; load_tr(pb, Tr);
+   double Tr[9]; load_tr(J, Tr);
 #pragma unroll
    for (int j = 0; j < 3; j++) out[j] = Tr[j] * th[0] + Tr[3 + j] * th[1] + Tr[6 + j] * th[2];
 }
 // hat(w_lat) Tr as a 3x3 (row-major)
-ECM_DI void wt_matrix(const Prob& pb, double Wt[9]) {
-   double Tr[9]; load_tr(pb, Tr);
-   const double w0 = ECM_ST(pb.st, ST_WL), w1 = ECM_ST(pb.st, ST_WL + 1), w2 = ECM_ST(pb.st, ST_WL + 2);
+ECM_DI void wt_matrix(const Jac& J, double Wt[9]) {
+   double Tr[9]; load_tr(J, Tr);
+   const double w0 = J.wl[0], w1 = J.wl[1], w2 = J.wl[2];
    const double W[3][3] = { { 0.0, -w2, w1 }, { w2, 0.0, -w0 }, { -w1, w0, 0.0 } };
 #pragma unroll
    for (int i = 0; i < 3; i++)
@@ -571,8 +574,8 @@ ECM_DI void wt_matrix(const Prob& pb, double Wt[9]) {
 struct Fact { double Ri[9]; bool ok; };
 
 // Ri = Jrr^-1 = (I/dt - hat(w_lat) Tr)^-1, row-major; returns false if singular
-ECM_DI bool rot_block_inverse(const Prob& pb, double Ri[9]) {
-   double Wt[9]; wt_matrix(pb, Wt);
+ECM_DI bool rot_block_inverse(const Prob& pb, const Jac& J, double Ri[9]) {
+   double Wt[9]; wt_matrix(J, Wt);
    double R[3][3];
 #pragma unroll
    for (int i = 0; i < 3; i++)
@@ -607,7 +610,7 @@ ECM_DI void jac_factor(const MatParams& mp, const Prob& pb, Jac& J, Fact& F) {
       for (int i = k + 1; i < 5; i++) J.A[sidx(k, i)] = li[i];
       J.A[sidx(k, k)] = inv;
    }
-   const bool okr = rot_block_inverse(pb, F.Ri);
+   const bool okr = rot_block_inverse(pb, J, F.Ri);
    F.ok = ok && okr;
 }
 
@@ -655,9 +658,9 @@ ECM_DI void jre_mult(const MatParams& mp, const Jac& J, const double ve[5], doub
 ECM_DI void jac_mult(const MatParams& mp, const Prob& pb, const Jac& J, const double v[8], double y[8]) {
    double a[5] = { mp.kd0 * v[0], mp.kd0 * v[1], mp.kd2 * v[2], mp.kd2 * v[3], mp.kd2 * v[4] };
    m_mult_factored(J, a);                       // Jee v = M (Kd v)
-   double b[5]; jer_mult(pb, v + 5, b);
+   double b[5]; jer_mult(J, v + 5, b);
    double c[3]; jre_mult(mp, J, v, c);
-   double Wt[9]; wt_matrix(pb, Wt);
+   double Wt[9]; wt_matrix(J, Wt);
 #pragma unroll
    for (int i = 0; i < 5; i++) y[i] = a[i] + b[i];
 #pragma unroll
@@ -670,8 +673,8 @@ ECM_DI void jac_mult_T(const MatParams& mp, const Prob& pb, const Jac& J, const 
    const double kd[5] = { mp.kd0, mp.kd0, mp.kd2, mp.kd2, mp.kd2 };
 #pragma unroll
    for (int j = 0; j < 5; j++) y[j] = kd[j] * (mu[j] + J.B[0][j] * u[5] + J.B[1][j] * u[6] + J.B[2][j] * u[7]);
-   double c[3]; jer_mult_T(pb, u, c);
-   double Wt[9]; wt_matrix(pb, Wt);
+   double c[3]; jer_mult_T(J, u, c);
+   double Wt[9]; wt_matrix(J, Wt);
 #pragma unroll
    for (int j = 0; j < 3; j++) y[5 + j] = c[j] + u[5 + j] * pb.dt_ri - (Wt[j] * u[5] + Wt[3 + j] * u[6] + Wt[6 + j] * u[7]);
 }
@@ -687,7 +690,7 @@ ECM_DI void jac_solve(const MatParams& mp, const Prob& pb, const Jac& J, const F
    double xe[5];
 #pragma unroll 1
    for (int sweep = 0; sweep < NSWEEP; sweep++) {
-      double t[5]; jer_mult(pb, xr, t);
+      double t[5]; jer_mult(J, xr, t);
 #pragma unroll
       for (int i = 0; i < 5; i++) xe[i] = rhs[i] - t[i];
       jee_solve(mp, J, xe);
@@ -746,10 +749,10 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += sv0[H_Q + i] * sv0[H_Q + i]; const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = sv0[H_Q + i] * ni; }
       double Cn[9]; quat_to_mat(qn, Cn);
       double dn[5]; rot_vecd_T(Cn, d_sm, dn);
-      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = sv0[H_E + i]; cold[CD_DSM + i] = d_sm[i]; cold[CD_SOLD + i] = s_old[i]; }
+      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = sv0[H_E + i]; ECM_CD(CD_DSM + i) = d_sm[i]; ECM_CD(CD_SOLD + i) = s_old[i]; }
       for (int i = 0; i < 3; i++) ECM_ST(st, ST_WN + i) = Cn[i] * w_sm[0] + Cn[3 + i] * w_sm[1] + Cn[6 + i] * w_sm[2];
-      for (int i = 0; i < 4; i++) cold[CD_QN + i] = qn[i];
-      cold[CD_VOLD] = vOld; cold[CD_VNEW] = vNew; cold[CD_ENEW] = eNew; cold[CD_DEFF] = dEff; cold[CD_BULK] = bulkNew; cold[CD_HU] = h_u;
+      for (int i = 0; i < 4; i++) ECM_CD(CD_QN + i) = qn[i];
+      ECM_CD(CD_VOLD) = vOld; ECM_CD(CD_VNEW) = vNew; ECM_CD(CD_ENEW) = eNew; ECM_CD(CD_DEFF) = dEff; ECM_CD(CD_BULK) = bulkNew; ECM_CD(CD_HU) = h_u;
       double adots_ref;
       if (KIN == KIN_KMBALD) {
          const double sq = sqrt(h_u);
@@ -844,7 +847,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    for (int i = 0; i < 3; i++) xi[i] = x[5 + i] * R_SCALE;
    double Cf[9];
    {
-      const double qn[4] = { cold[CD_QN], cold[CD_QN + 1], cold[CD_QN + 2], cold[CD_QN + 3] };
+      const double qn[4] = { ECM_CD(CD_QN), ECM_CD(CD_QN + 1), ECM_CD(CD_QN + 2), ECM_CD(CD_QN + 3) };
       double qf[4];
       const double th2 = xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2];
       double cq, sq;   // cos(th/2), sin(th/2)/th
@@ -863,19 +866,19 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    const double kdj[5] = { mp.kd0 * pb.detV_ri, mp.kd0 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri };
    double s_lat[5];
    for (int i = 0; i < 5; i++) s_lat[i] = kdj[i] * e_f[i];
-   const double bulkNew = cold[CD_BULK];
+   const double bulkNew = ECM_CD(CD_BULK);
    {
       double s_sm[5]; rot_vecd(Cf, s_lat, s_sm);
-      const double vNew = cold[CD_VNEW];
-      double eNew = cold[CD_ENEW];
-      { double wrk = 0; for (int k = 0; k < 5; k++) wrk += (cold[CD_SOLD + k] + s_sm[k]) * cold[CD_DSM + k]; eNew += 0.25 * (cold[CD_VOLD] + vNew) * dt * wrk; }
+      const double vNew = ECM_CD(CD_VNEW);
+      double eNew = ECM_CD(CD_ENEW);
+      { double wrk = 0; for (int k = 0; k < 5; k++) wrk += (ECM_CD(CD_SOLD + k) + s_sm[k]) * ECM_CD(CD_DSM + k); eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * wrk; }
       sv1[H_SHRATE] = shrate;
       sv1[H_SHR] = sv0[H_SHR] + shrate * dt;
-      sv1[H_FLOW] = ((cold[CD_DEFF] > TINY_SQRT) ? dis_rate * dt : 0.0) + sv0[H_FLOW];   // accumulated plastic work
+      sv1[H_FLOW] = ((ECM_CD(CD_DEFF) > TINY_SQRT) ? dis_rate * dt : 0.0) + sv0[H_FLOW];   // accumulated plastic work
       sv1[H_NFEV] = (double)nfev;
       for (int i = 0; i < 5; i++) sv1[H_E + i] = e_f[i];
       if constexpr (KIN != KIN_KMBALD) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT);
-      sv1[H_H] = cold[CD_HU];
+      sv1[H_H] = ECM_CD(CD_HU);
       sv1[IND_VOL] = vNew; sv1[IND_EINT] = eNew;
       const double pNew = mp.bulk * (1.0 / vNew - 1.0) + mp.gamma * eNew;
       const double t1 = SQR2I * s_sm[0], t2 = SQR6I * s_sm[1];
@@ -891,16 +894,16 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       double Llat[5][5];
       bool okT;
       {
-         double Ri[9]; okT = rot_block_inverse(pb, Ri);
+         double Ri[9]; okT = rot_block_inverse(pb, J, Ri);
          double G[3][5];
 #pragma unroll
          for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 5; j++) G[i][j] = Ri[3 * i] * J.B[0][j] + Ri[3 * i + 1] * J.B[1][j] + Ri[3 * i + 2] * J.B[2][j];
-         double Tr[9]; load_tr(pb, Tr);
+         double Tr[9]; load_tr(J, Tr);
          double S[5][5];
          {
-            double dl[5]; load_dl(pb, dl);
+            double dl[5]; load_dl(J, dl);
             double Md[5][3]; m35(dl, Md);
             const double kdi0 = pb.dt_ri / mp.kd0, kdi2 = pb.dt_ri / mp.kd2;
 #pragma unroll
