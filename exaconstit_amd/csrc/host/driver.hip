@@ -2,6 +2,7 @@
 #include "driver.hpp"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <link.h>
 #include <algorithm>
 #include <condition_variable>
 #include <mutex>
@@ -34,7 +35,14 @@ struct RcclApi {
 RcclApi& rccl() {
    static RcclApi api;
    if (!api.h) {
-      for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1" }) { api.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (api.h) break; }
+      // prefer the RCCL already mapped into the process (PyTorch bundles its own copy next to its HIP runtime): two RCCL builds in
+      // one process would each bring their own device state
+      std::string loaded;
+      dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* out) -> int {
+         if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) { *static_cast<std::string*>(out) = info->dlpi_name; return 1; }
+         return 0; }, &loaded);
+      if (!loaded.empty()) api.h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_GLOBAL);
+      if (!api.h) for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1" }) { api.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (api.h) break; }
       if (!api.h) throw std::runtime_error(std::string("cannot load RCCL: ") + dlerror());
       auto sym = [&](const char* n) { void* p = dlsym(api.h, n); if (!p) throw std::runtime_error(std::string("RCCL symbol missing: ") + n); return p; };
       api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
