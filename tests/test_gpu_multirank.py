@@ -53,3 +53,18 @@ def test_partitioned_run_matches_single_rank(oracle, tmp_path, case, nranks):
     for s, st in got:                                      # every rank reports the same global averages and solver history
         assert np.max(np.abs(s - ref[0])) < 1e-9 * np.abs(ref[0]).max()
         assert list(st[0]) == list(ref[1][0])              # Newton iterations
+
+
+def test_partitioned_order2_bbar_matches_single_rank(oracle, tmp_path):
+    """BASELINE config 5 ingredients (p = 2, B-bar, element assembly, NRLS) on 2 and 4 ranks vs one rank."""
+    import exaconstit_amd.lib as L
+    from test_gpu_driver import _variant_toml
+    edits = [('assembly = "PA"', 'assembly = "EA"\n    integ_model = "BBAR"'), ("prefinement = 1", "p_refinement = 2"), ("ref_ser = 1", "ref_ser = 0"),
+             ("[Solvers.NR]", '[Solvers.NR]\n        nl_solver = "NRLS"')]
+    os.makedirs(str(tmp_path), exist_ok=True)
+    toml = _variant_toml(tmp_path, "voce_pa.toml", edits, "p2bbar")
+    ref = _run_ranks(L, toml, 1, 3, tmp_path / "r1")[0]
+    for nranks in (2, 4):
+        for s, st in _run_ranks(L, toml, nranks, 3, tmp_path / f"r{nranks}"):
+            assert np.max(np.abs(s - ref[0])) < 1e-9 * np.abs(ref[0]).max()
+            assert list(st[0]) == list(ref[1][0])
