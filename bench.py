@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--model", default="fcc_voce", choices=["fcc_voce", "bcc_voce", "fcc_voce_nl", "fcc_kmdd", "bcc_kmdd"],
                     help="crystal model of the RVE; the headline metric is quoted on fcc_voce (BASELINE config 4 also names bcc_kmdd)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--jacobi", action="store_true", help="true Jacobi preconditioner (refreshed every Newton iteration) instead of the reference's effective identity (SURVEY fact 9)")
     ap.add_argument("--solve-steps", type=int, default=0, help="additionally run this many real Newton/PCG time steps and report their rates")
     args = ap.parse_args()
 
@@ -150,7 +151,7 @@ def main():
     rng = np.random.default_rng(20240928)
     quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
     drv = L.Driver.synthetic(N, props, quats.ravel(), np.array(PREP_DTS), assembly=0 if args.assembly.upper() == "PA" else 1,
-                             krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=uid, **mk)
+                             krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=uid, jacobi=args.jacobi, **mk)
     del quats
     # elastic regime (first step of the schedule from the virgin state), reported beside the headline plastic-regime value
     drv.bench_prepare(PREP_DTS[:1], advance=False)
@@ -189,7 +190,7 @@ def main():
         rng = np.random.default_rng(20240928)
         quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
         sched = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "custom_dt.txt")).ravel()[:args.solve_steps]
-        drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=0 if args.assembly.upper() == "PA" else 1, rank=rank, nranks=world, uid=uid, **mk)
+        drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=0 if args.assembly.upper() == "PA" else 1, rank=rank, nranks=world, uid=uid, jacobi=args.jacobi, **mk)
         barrier(); t0 = time.perf_counter()
         for ti in range(1, args.solve_steps + 1):
             assert drv.step(ti), f"Newton failed at step {ti}"
