@@ -87,6 +87,15 @@ int exa_shape_table(const exa_ctx* ctx, double* G_host, double* W_host) {
    return EXA_OK;
 }
 
+int exa_set_quadrature_layout(exa_ctx* ctx, int layout) {
+   if (!ctx || (layout != EXA_QLAYOUT_AOS && layout != EXA_QLAYOUT_EB64)) return fail(ctx, EXA_ERR_ARG, "exa_set_quadrature_layout: bad argument");
+   if (layout == EXA_QLAYOUT_EB64 && (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL))
+      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_set_quadrature_layout: the element-blocked layout is built for p = 1 full integration");
+   ctx->qblk = (layout == EXA_QLAYOUT_EB64); ctx->have_resid = false; ctx->have_grad = false;
+   return EXA_OK;
+}
+int64_t exa_qf_size(const exa_ctx* ctx, int vdim) { return (ctx && vdim > 0) ? (int64_t)exa_qf_doubles(ctx, vdim) : -1; }
+
 int exa_init_state(exa_ctx* ctx, double* state0, const double* quats, exa_stream s) {
    if (!ctx || !state0 || !quats) return fail(ctx, EXA_ERR_ARG, "exa_init_state: null pointer");
    double* hist_dev = ctx->scratch_dev;   // 26 doubles
@@ -134,6 +143,7 @@ int exa_grad_calc(exa_ctx* ctx, const double* J, const double* fe, double* out, 
 
 int exa_residual_setup(exa_ctx* ctx, const double* J, const double* stress1, exa_stream s) {
    if (!ctx || !J || !stress1) return fail(ctx, EXA_ERR_ARG, "exa_residual_setup: null pointer");
+   if (ctx->qblk) return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_residual_setup: E-vector residual is AOS-only; with the element-blocked layout use exa_residual_lvec");
    ctx->have_resid = true;
    if (ctx->cfg.integ == EXA_INTEG_BBAR) {      // ICExaNLFIntegrator::AssemblePA: element-average gradient; J and sigma are read by AddMultPA
       if (!ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * ctx->E));

@@ -350,7 +350,7 @@ constexpr int CD_DSM = 0, CD_SOLD = 5, CD_QN = 10, CD_VOLD = 14, CD_VNEW = 15, C
 // compiler-only barrier: what was parked must be re-loaded later instead of being kept alive in registers
 #define ECM_PARK_BARRIER() asm volatile("" ::: "memory")
 // parking slot c (compile-time): the first ST_NCD live in the LDS stash, the rest in the point's tangent slot in global memory
-#define ECM_CD(c) (*(((c) < ST_NCD) ? &ECM_ST(st, ST_CD + (((c) < ST_NCD) ? (c) : 0)) : &cold[c]))
+#define ECM_CD(c) (*(((c) < ST_NCD) ? &ECM_ST(st, ST_CD + (((c) < ST_NCD) ? (c) : 0)) : &cold[(c) * QS]))
 
 // ------------------------------------------------------------------------------------------------------------
 // the point problem: unknowns x = (delta e' / E_SCALE, xi / R_SCALE)
@@ -358,6 +358,7 @@ constexpr int CD_DSM = 0, CD_SOLD = 5, CD_QN = 10, CD_VOLD = 14, CD_VNEW = 15, C
 struct Prob {
    double dt_ri, detV_ri, sc, sc_i, g_i;   // sc = epsdot_scale_inv, sc_i = 1/sc, g_i = 1/g
    double* st;                             // per-thread stash
+   int gs;                                 // stride of the slip-rate outputs (1 or 64, see point_update's QS)
    KinVals kv;
 };
 
@@ -452,7 +453,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       const double tau = pq[0] * k[0] + pq[1] * k[1] + pq[2] * k[2] + pq[3] * k[3] + pq[4] * k[4];
       double gd, dg;
       kmbald_gdot(mp, pb.kv, tau, gd, dg);
-      if (gdot_out) gdot_out[a] = gd;
+      if (gdot_out) gdot_out[a * pb.gs] = gd;
       dis += tau * gd; shr += fabs(gd);
       ok = ok && isfinite(gd);
 #pragma unroll
@@ -527,7 +528,7 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
    }
    voce_gdot12<false, true>(mp, pb.g_i, tau, gd, nullptr);
 #pragma unroll
-   for (int a = 0; a < NSLIP; a++) gdot_out[a] = gd[a];
+   for (int a = 0; a < NSLIP; a++) gdot_out[a * pb.gs] = gd[a];
 }
 
 // ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
@@ -718,11 +719,13 @@ ECM_DI double norm8(const double v[8]) { double s = 0; for (int i = 0; i < 8; i+
 //   st     : per-thread stash (LDS), ST_SLOTS slots of stride ECM_STASH_STRIDE
 // returns 0 on success, 1 if the local solve failed to converge
 // ------------------------------------------------------------------------------------------------------------
-template <int KIN>
-ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const double sv0[NSTATEV], const double s0[6],
-                        double sv1[NSTATEV], double s1[6], double cmat[36], double* st) {
+// QS: distance (in doubles) between consecutive values of one point in the state / stress / tangent arrays: 1 for the reference's
+// AoS quadrature functions, 64 for the element-blocked layout (exa_internal.hpp, QView)
+template <int KIN, int QS>
+ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const double* __restrict__ sv0, const double* __restrict__ s0,
+                        double* __restrict__ sv1, double* __restrict__ s1, double* __restrict__ cmat, double* st) {
    double* cold = cmat;
-   Prob pb; pb.st = st;
+   Prob pb; pb.st = st; pb.gs = QS;
    pb.dt_ri = 1.0 / dt;
    {
       // ---- kernel_setup (reference src/mechanics_ecmech.cpp:42-99)
@@ -734,22 +737,22 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
                   0.5 * (L[2 + 3 * 1] + L[1 + 3 * 2]), d_sm);
       double dnorm2 = 0; for (int i = 0; i < 5; i++) dnorm2 += d_sm[i] * d_sm[i];
       const double dnorm = sqrt(dnorm2), dEff = SQR2B3 * dnorm;
-      const double vOld = sv0[IND_VOL], vNew = vOld * exp(dkk * dt), delv = vNew - vOld;
-      const double pOld = -(1.0 / 3.0) * (s0[0] + s0[1] + s0[2]);
-      double s_old[5]; sym_to_vecd(s0[0] + pOld, s0[1] + pOld, s0[2] + pOld, s0[5], s0[4], s0[3], s_old);
+      const double vOld = sv0[(IND_VOL) * QS], vNew = vOld * exp(dkk * dt), delv = vNew - vOld;
+      const double pOld = -(1.0 / 3.0) * (s0[(0) * QS] + s0[(1) * QS] + s0[(2) * QS]);
+      double s_old[5]; sym_to_vecd(s0[(0) * QS] + pOld, s0[(1) * QS] + pOld, s0[(2) * QS] + pOld, s0[(5) * QS], s0[(4) * QS], s0[(3) * QS], s_old);
       // ---- EOS ("updateSimple", EosModelConst<false>): p = K (1/v - 1) + Gamma e
-      const double eNew = sv0[IND_EINT] - delv * pOld;
+      const double eNew = sv0[(IND_EINT) * QS] - delv * pOld;
       const double tK = mp.tK0 + eNew * mp.dtde;
       const double bulkNew = mp.bulk * vNew + mp.gamma * pOld * vNew;
       // ---- hardness to end of step with begin-of-step slip rates
-      double shrate_o = 0; for (int a = 0; a < NSLIP; a++) shrate_o += fabs(sv0[H_GDOT + a]);
-      const double h_u = kin_update_h<KIN>(mp, sv0[H_H], dt, shrate_o);
+      double shrate_o = 0; for (int a = 0; a < NSLIP; a++) shrate_o += fabs(sv0[(H_GDOT + a) * QS]);
+      const double h_u = kin_update_h<KIN>(mp, sv0[(H_H) * QS], dt, shrate_o);
       // ---- point problem set-up
       pb.detV_ri = 1.0 / vNew;
-      double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += sv0[H_Q + i] * sv0[H_Q + i]; const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = sv0[H_Q + i] * ni; }
+      double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += sv0[(H_Q + i) * QS] * sv0[(H_Q + i) * QS]; const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = sv0[(H_Q + i) * QS] * ni; }
       double Cn[9]; quat_to_mat(qn, Cn);
       double dn[5]; rot_vecd_T(Cn, d_sm, dn);
-      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = sv0[H_E + i]; ECM_CD(CD_DSM + i) = d_sm[i]; ECM_CD(CD_SOLD + i) = s_old[i]; }
+      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = sv0[(H_E + i) * QS]; ECM_CD(CD_DSM + i) = d_sm[i]; ECM_CD(CD_SOLD + i) = s_old[i]; }
       for (int i = 0; i < 3; i++) ECM_ST(st, ST_WN + i) = Cn[i] * w_sm[0] + Cn[3 + i] * w_sm[1] + Cn[6 + i] * w_sm[2];
       for (int i = 0; i < 4; i++) ECM_CD(CD_QN + i) = qn[i];
       ECM_CD(CD_VOLD) = vOld; ECM_CD(CD_VNEW) = vNew; ECM_CD(CD_ENEW) = eNew; ECM_CD(CD_DEFF) = dEff; ECM_CD(CD_BULK) = bulkNew; ECM_CD(CD_HU) = h_u;
@@ -771,7 +774,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    double x[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
    double r[8], dis_rate, shrate;
    Jac J; Fact F;
-   double* gdot_out = (KIN == KIN_KMBALD) ? sv1 + H_GDOT : nullptr;
+   double* gdot_out = (KIN == KIN_KMBALD) ? sv1 + H_GDOT * QS : nullptr;
    int nfev = 1; bool conv = false;
    bool ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);
    double res_0 = norm8(r);
@@ -861,7 +864,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       quat_to_mat(qf, Cf);
       double dq = 0; for (int i = 0; i < 4; i++) dq += qf[i] * qn[i];
       const double sg = dq < 0 ? -1.0 : 1.0;
-      for (int i = 0; i < 4; i++) sv1[H_Q + i] = sg * qf[i];
+      for (int i = 0; i < 4; i++) sv1[(H_Q + i) * QS] = sg * qf[i];
    }
    const double kdj[5] = { mp.kd0 * pb.detV_ri, mp.kd0 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri };
    double s_lat[5];
@@ -872,18 +875,18 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       const double vNew = ECM_CD(CD_VNEW);
       double eNew = ECM_CD(CD_ENEW);
       { double wrk = 0; for (int k = 0; k < 5; k++) wrk += (ECM_CD(CD_SOLD + k) + s_sm[k]) * ECM_CD(CD_DSM + k); eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * wrk; }
-      sv1[H_SHRATE] = shrate;
-      sv1[H_SHR] = sv0[H_SHR] + shrate * dt;
-      sv1[H_FLOW] = ((ECM_CD(CD_DEFF) > TINY_SQRT) ? dis_rate * dt : 0.0) + sv0[H_FLOW];   // accumulated plastic work
-      sv1[H_NFEV] = (double)nfev;
-      for (int i = 0; i < 5; i++) sv1[H_E + i] = e_f[i];
-      if constexpr (KIN != KIN_KMBALD) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT);
-      sv1[H_H] = ECM_CD(CD_HU);
-      sv1[IND_VOL] = vNew; sv1[IND_EINT] = eNew;
+      sv1[(H_SHRATE) * QS] = shrate;
+      sv1[(H_SHR) * QS] = sv0[(H_SHR) * QS] + shrate * dt;
+      sv1[(H_FLOW) * QS] = ((ECM_CD(CD_DEFF) > TINY_SQRT) ? dis_rate * dt : 0.0) + sv0[(H_FLOW) * QS];   // accumulated plastic work
+      sv1[(H_NFEV) * QS] = (double)nfev;
+      for (int i = 0; i < 5; i++) sv1[(H_E + i) * QS] = e_f[i];
+      if constexpr (KIN != KIN_KMBALD) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS);
+      sv1[(H_H) * QS] = ECM_CD(CD_HU);
+      sv1[(IND_VOL) * QS] = vNew; sv1[(IND_EINT) * QS] = eNew;
       const double pNew = mp.bulk * (1.0 / vNew - 1.0) + mp.gamma * eNew;
       const double t1 = SQR2I * s_sm[0], t2 = SQR6I * s_sm[1];
-      s1[0] = t1 - t2 - pNew; s1[1] = -t1 - t2 - pNew; s1[2] = SQR2B3 * s_sm[1] - pNew;
-      s1[3] = SQR2I * s_sm[4]; s1[4] = SQR2I * s_sm[3]; s1[5] = SQR2I * s_sm[2];
+      s1[(0) * QS] = t1 - t2 - pNew; s1[(1) * QS] = -t1 - t2 - pNew; s1[(2) * QS] = SQR2B3 * s_sm[1] - pNew;
+      s1[(3) * QS] = SQR2I * s_sm[4]; s1[(4) * QS] = SQR2I * s_sm[3]; s1[(5) * QS] = SQR2I * s_sm[2];
    }
 #ifndef ECM_NO_TANGENT
    // ---- tangent (last: it overwrites the parking area): lattice-frame d sigma'/d D' by implicit differentiation on the converged
@@ -996,9 +999,9 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          for (int k = 0; k < 5; k++) T2[k] = (j < 5) ? T1[k][j] : Llat[k][0];
          const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
          const double bk = (j < 3) ? bulkNew : 0.0;
-         // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[i + 6 j]
-         cmat[0 + 6 * j] = t1 - t2 + bk; cmat[1 + 6 * j] = -t1 - t2 + bk; cmat[2 + 6 * j] = SQR2B3 * T2[1] + bk;
-         cmat[3 + 6 * j] = SQR2I * T2[4]; cmat[4 + 6 * j] = SQR2I * T2[3]; cmat[5 + 6 * j] = SQR2I * T2[2];
+         // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[(i + 6 j) * QS]
+         cmat[(0 + 6 * j) * QS] = t1 - t2 + bk; cmat[(1 + 6 * j) * QS] = -t1 - t2 + bk; cmat[(2 + 6 * j) * QS] = SQR2B3 * T2[1] + bk;
+         cmat[(3 + 6 * j) * QS] = SQR2I * T2[4]; cmat[(4 + 6 * j) * QS] = SQR2I * T2[3]; cmat[(5 + 6 * j) * QS] = SQR2I * T2[2];
       }
    }
 #endif

@@ -41,6 +41,7 @@ struct exa_ctx {
    double* tbuf = nullptr;                  // generic PA action: per-point T (3,3,Q,E)
    const double* resid_J = nullptr; const double* resid_S = nullptr;   // B-bar residual reads J and sigma at apply time, like the reference
    bool ea_generic = false;
+   bool qblk = false;                       // quadrature functions in the element-blocked layout (see QView below)
    bool have_resid = false, have_grad = false;
    // L-vector support
    const int32_t* conn = nullptr; int nnodes = 0;
@@ -53,5 +54,19 @@ struct exa_ctx {
 // host-side reference element (H1 hex of order p at (p+1)^3 Gauss-Legendre points), src/mechanics_operator.cpp:237-261
 void exa_build_ref_elem(int p, std::vector<double>& G, std::vector<double>& W);
 bool exa_fill_mat_params(const exa_config& cfg, ecmdev::MatParams& mp, double* hist_init, std::string& err);
+
+// Quadrature-function addressing.  AOS is the reference's QuadratureFunction layout (vdim values of a point contiguous, points of an
+// element consecutive).  EB64 is the internal layout of the stand-alone driver: [block of 64 elements][point q][value k][lane = element],
+// the same blocking as the PA record, so that a wave whose lanes are 64 consecutive elements reads or writes one contiguous 512-byte
+// row per value — the per-lane 224/288-byte strides of AOS cost the constitutive kernel 5 of its 7.5 ms at 128^3.
+struct QView { int64_t base; int stride; };
+template <bool QB>
+__device__ __forceinline__ QView qview(int W, int Q, int64_t e, int q) {
+   if (QB) return { ((((e >> 6) * Q + q) * (int64_t)W) << 6) + (e & 63), 64 };
+   return { (int64_t)W * (q + (int64_t)Q * e), 1 };
+}
+static inline size_t exa_qf_doubles(const exa_ctx* ctx, int vdim) {
+   return ctx->qblk ? (size_t)vdim * 64 * ctx->Q * ((ctx->E + 63) / 64) : (size_t)vdim * ctx->P;
+}
 
 static inline size_t pa_bytes(int E, int Q) { return (size_t)((E + PA_BLK - 1) / PA_BLK) * Q * PA_SLOTS * PA_BLK * sizeof(double); }

@@ -220,12 +220,15 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    fast_p1_ = (part.p == 1 && !bbar);          // fused L-vector kernels exist for p = 1 full integration
    lvec_grad_ = fast_p1_ || opt.assembly == Assembly::EA;
    fused_setup_ = std::getenv("EXA_UNFUSED_SETUP") == nullptr;   // A/B switch for measurements; the fused launch is the product path
-   const size_t P = (size_t)E_ * npe_;
+   // internal quadrature-function layout: element-blocked on the fused p = 1 path (EXA_QLAYOUT=aos switches back for A/B runs)
+   const char* ql = std::getenv("EXA_QLAYOUT");
+   if (fast_p1_ && !(ql && std::string(ql) == "aos")) abi_check(ctx_, exa_set_quadrature_layout(ctx_, EXA_QLAYOUT_EB64), "exa_set_quadrature_layout");
+   auto qf = [&](int vdim) { return (size_t)exa_qf_size(ctx_, vdim); };
    conn.upload(part.conn); abi_check(ctx_, exa_set_connectivity(ctx_, conn.p, nn_), "exa_set_connectivity");
    x_ref.upload(part.X); x_beg.upload(part.X); x_cur.upload(part.X);
    weight.upload(part.weight);
-   el_x.alloc(3 * (size_t)npe_ * E_); el_v.alloc(3 * (size_t)npe_ * E_); el_y_.alloc(3 * (size_t)npe_ * E_); el_jac.alloc(9 * P);
-   stress0.alloc(6 * P); stress1.alloc(6 * P); matVars0.alloc(28 * P); matVars1.alloc(28 * P); matGrad.alloc(36 * P);
+   el_x.alloc(3 * (size_t)npe_ * E_); el_v.alloc(3 * (size_t)npe_ * E_); el_y_.alloc(3 * (size_t)npe_ * E_); el_jac.alloc(qf(9));
+   stress0.alloc(qf(6)); stress1.alloc(qf(6)); matVars0.alloc(qf(28)); matVars1.alloc(qf(28)); matGrad.alloc(qf(36));
    stress0.zero(); stress1.zero(); matVars1.zero(); matGrad.zero();
    diag.alloc(nd_); dinv.alloc(nd_); tmp_l_.alloc(nd_); tmp_r_.alloc(nd_); el_x2_.alloc(3 * (size_t)npe_ * E_); ess_mask.alloc(nd_); ess_mask.zero();
    partial.alloc(DOT_BLOCKS * 4); scal.alloc(16); scal.zero();
@@ -546,8 +549,8 @@ void SystemDriver::UpdateModel() {
       avg_pl_work.push_back(a[2]);
       if (root) append_row(out_dir + "/" + opt_.avg_pl_work_fname, a + 2, 1);
       // CalculateDeformationGradient: gradient of the current coordinates on the reference configuration
-      const size_t P = (size_t)part.E * part.n;
-      DevBuf<double> jref(9 * P), F(9 * P), xe(3 * (size_t)part.n * part.E);
+      const size_t nq9 = (size_t)exa_qf_size(ctx, 9);
+      DevBuf<double> jref(nq9), F(nq9), xe(3 * (size_t)part.n * part.E);
       abi_check(ctx, exa_restrict(ctx, op.x_ref.p, xe.p, s), "exa_restrict");
       abi_check(ctx, exa_jacobians(ctx, xe.p, jref.p, s), "exa_jacobians");
       abi_check(ctx, exa_restrict(ctx, op.x_cur.p, op.el_x.p, s), "exa_restrict");   // x_true -> E-vector (reference src/mechanics_operator.cpp:411-414)

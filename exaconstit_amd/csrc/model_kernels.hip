@@ -18,7 +18,9 @@ using namespace ecmdev;
 //               SetupJacobianTerms (reference src/mechanics_operator.cpp:310-391) ride inside this VALU-bound kernel for free.
 // NFIX = 8: trilinear elements, node loops fully unrolled so that all gathers of a point are in flight together (two memory round
 // trips instead of one dependent index->value chain per node); NFIX = 0: run-time n.
-template <int KIN, bool LVEC, int NFIX>
+// QB: quadrature functions (J, stress, state, tangent) in the element-blocked layout; then a wave is (64 consecutive elements, one
+// point index q) so that every per-value access of the wave is one contiguous 512-byte row.
+template <int KIN, bool LVEC, int NFIX, bool QB>
 __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatParams mp, const int Q, const int n_rt, const int64_t P, const double dt,
                                                      double* __restrict__ Jio, const double* __restrict__ G,
                                                      const double* __restrict__ vel, const double* __restrict__ xl, const int32_t* __restrict__ conn, const int nnodes,
@@ -29,10 +31,18 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    extern __shared__ double sG[];   // (n,3,Q)
    for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
    __syncthreads();
-   const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-   if (ip >= P) return;
-   const int q = (int)(ip % Q);
-   const int64_t e = ip / Q;
+   int q; int64_t e;
+   if (QB) {   // wave = (block of 64 elements, q); lane = element
+      const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+      q = (int)(gw % Q); e = (gw / Q) * 64 + (threadIdx.x & 63);
+      if (e * Q >= P) return;
+   } else {
+      const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      if (ip >= P) return;
+      q = (int)(ip % Q); e = ip / Q;
+   }
+   constexpr int QS = QB ? 64 : 1;
+   const QView vJ = qview<QB>(9, Q, e, q), vS = qview<QB>(6, Q, e, q), vV = qview<QB>(NSTATEV, Q, e, q), vC = qview<QB>(36, Q, e, q);
    const double* Gq = sG + 3 * n * q;
    double J11, J21, J31, J12, J22, J32, J13, J23, J33;
    if (LVEC) {
@@ -48,11 +58,11 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
          J12 += x0 * g1; J22 += x1 * g1; J32 += x2 * g1;
          J13 += x0 * g2; J23 += x1 * g2; J33 += x2 * g2;
       }
-      double* Jo = Jio + 9 * ip;
-      Jo[0] = J11; Jo[1] = J21; Jo[2] = J31; Jo[3] = J12; Jo[4] = J22; Jo[5] = J32; Jo[6] = J13; Jo[7] = J23; Jo[8] = J33;
+      double* Jo = Jio + vJ.base;
+      Jo[0] = J11; Jo[QS] = J21; Jo[2 * QS] = J31; Jo[3 * QS] = J12; Jo[4 * QS] = J22; Jo[5 * QS] = J32; Jo[6 * QS] = J13; Jo[7 * QS] = J23; Jo[8 * QS] = J33;
    } else {
-      const double* Jq = Jio + 9 * ip;
-      J11 = Jq[0]; J21 = Jq[1]; J31 = Jq[2]; J12 = Jq[3]; J22 = Jq[4]; J32 = Jq[5]; J13 = Jq[6]; J23 = Jq[7]; J33 = Jq[8];
+      const double* Jq = Jio + vJ.base;
+      J11 = Jq[0]; J21 = Jq[QS]; J31 = Jq[2 * QS]; J12 = Jq[3 * QS]; J22 = Jq[4 * QS]; J32 = Jq[5 * QS]; J13 = Jq[6 * QS]; J23 = Jq[7 * QS]; J33 = Jq[8 * QS];
    }
    // inverse Jacobian (reference src/mechanics_kernels.cpp:38-61)
    const double detJ = J11 * (J22 * J33 - J32 * J23) - J21 * (J12 * J33 - J32 * J13) + J31 * (J12 * J23 - J22 * J13);
@@ -80,50 +90,62 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    }
    // per-thread stash behind the shape table in LDS: slot s of this thread at stash[s * 256 + threadIdx.x]
    double* st = sG + n * 3 * Q + threadIdx.x;
-   const int rc = point_update<KIN>(mp, dt, L, state0 + NSTATEV * ip, stress0 + 6 * ip, state1 + NSTATEV * ip, stress1 + 6 * ip, cmat + 36 * ip, st);
+   const int rc = point_update<KIN, QS>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, cmat + vC.base, st);
    if (rc) atomicAdd(fail, 1);
 }
 
+template <bool QB>
 __global__ void k_init_state(const int Q, const int64_t P, const double* __restrict__ hist, const double* __restrict__ quats, double* __restrict__ state0) {
    const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (ip >= P) return;
    const int64_t e = ip / Q;
-   double* sv = state0 + NSTATEV * ip;
-   for (int i = 0; i < NUM_HIST; i++) sv[i] = hist[i];
-   for (int i = 0; i < 4; i++) sv[H_Q + i] = quats[4 * e + i];
-   sv[IND_VOL] = 1.0; sv[IND_EINT] = 0.0;
+   const QView v = qview<QB>(NSTATEV, Q, e, (int)(ip % Q));
+   double* sv = state0 + v.base; const int64_t st = v.stride;
+   for (int i = 0; i < NUM_HIST; i++) sv[i * st] = hist[i];
+   for (int i = 0; i < 4; i++) sv[(H_Q + i) * st] = quats[4 * e + i];
+   sv[IND_VOL * st] = 1.0; sv[IND_EINT * st] = 0.0;
 }
 
 // calcDpMat (reference src/mechanics_ecmech.hpp:315-356)
-__global__ void k_calc_dp(const double qsign, const int64_t P, const double* __restrict__ state, double* __restrict__ dp) {
+template <bool QB>
+__global__ void k_calc_dp(const double qsign, const int Q, const int64_t P, const double* __restrict__ state, double* __restrict__ dp) {
    const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (ip >= P) return;
-   const double* sv = state + NSTATEV * ip;
+   const QView vs = qview<QB>(NSTATEV, Q, ip / Q, (int)(ip % Q)), vd = qview<QB>(9, Q, ip / Q, (int)(ip % Q));
+   const double* sv = state + vs.base; const int64_t ss = vs.stride, ds = vd.stride;
    double dphat[5] = { 0, 0, 0, 0, 0 };
 #pragma unroll
    for (int a = 0; a < NSLIP; a++) {
-      const double g = sv[H_GDOT + a];
+      const double g = sv[(H_GDOT + a) * ss];
 #pragma unroll
       for (int c = 0; c < 5; c++) dphat[c] += P_TAB[c][a] * g;
    }
    (void)qsign;
-   const double q[4] = { sv[H_Q], sv[H_Q + 1], sv[H_Q + 2], sv[H_Q + 3] };
+   const double q[4] = { sv[H_Q * ss], sv[(H_Q + 1) * ss], sv[(H_Q + 2) * ss], sv[(H_Q + 3) * ss] };
    double C[9]; quat_to_mat(q, C);
    double sm[5]; rot_vecd(C, dphat, sm);
    double t00, t11, t22, t01, t02, t12; vecd_to_sym(sm, t00, t11, t22, t01, t02, t12);
-   double* o = dp + 9 * ip;
-   o[0] = t00; o[1] = t01; o[2] = t02; o[3] = t01; o[4] = t11; o[5] = t12; o[6] = t02; o[7] = t12; o[8] = t22;
+   double* o = dp + vd.base;
+   o[0] = t00; o[ds] = t01; o[2 * ds] = t02; o[3 * ds] = t01; o[4 * ds] = t11; o[5 * ds] = t12; o[6 * ds] = t02; o[7 * ds] = t12; o[8 * ds] = t22;
+}
+
+template <int KIN, bool LVEC, int NFIX, bool QB>
+static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
+                         double* stress1, double* state1, double* cmat, hipStream_t s) {
+   const int bs = 256;
+   // QB: one wave per (64-element block, q)
+   const int64_t nb = QB ? (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64) : (ctx->P + bs - 1) / bs;
+   const size_t lds = sizeof(double) * ((size_t)ctx->n * 3 * ctx->Q + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE);
+   static_assert(ECM_STASH_STRIDE == 256, "stash stride must equal the block size");
+   hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+                      ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
 }
 
 template <int KIN, bool LVEC, int NFIX>
 static void launch_model_n(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
-                         double* stress1, double* state1, double* cmat, hipStream_t s) {
-   const int bs = 256;
-   const int64_t nb = (ctx->P + bs - 1) / bs;
-   const size_t lds = sizeof(double) * ((size_t)ctx->n * 3 * ctx->Q + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE);
-   static_assert(ECM_STASH_STRIDE == 256, "stash stride must equal the block size");
-   hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX>), dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
-                      ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
+                           double* stress1, double* state1, double* cmat, hipStream_t s) {
+   if (ctx->qblk) launch_model_q<KIN, LVEC, NFIX, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+   else launch_model_q<KIN, LVEC, NFIX, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
 }
 
 template <int KIN, bool LVEC>
@@ -158,14 +180,16 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
 
 int exa_launch_init_state(exa_ctx* ctx, double* state0, const double* quats, const double* hist_dev, hipStream_t s) {
    const int bs = 256;
-   hipLaunchKernelGGL(k_init_state, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->Q, ctx->P, hist_dev, quats, state0);
+   if (ctx->qblk) hipLaunchKernelGGL(k_init_state<true>, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->Q, ctx->P, hist_dev, quats, state0);
+   else hipLaunchKernelGGL(k_init_state<false>, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->Q, ctx->P, hist_dev, quats, state0);
    EXA_HIP_CHECK(ctx, hipGetLastError());
    return EXA_OK;
 }
 
 int exa_launch_calc_dp(exa_ctx* ctx, const double* state, double* dp, hipStream_t s) {
    const int bs = 256;
-   hipLaunchKernelGGL(k_calc_dp, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->mp.qsign, ctx->P, state, dp);
+   if (ctx->qblk) hipLaunchKernelGGL(k_calc_dp<true>, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->mp.qsign, ctx->Q, ctx->P, state, dp);
+   else hipLaunchKernelGGL(k_calc_dp<false>, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->mp.qsign, ctx->Q, ctx->P, state, dp);
    EXA_HIP_CHECK(ctx, hipGetLastError());
    return EXA_OK;
 }

@@ -30,8 +30,8 @@ constexpr double G1(int a, int j, int q) {
 
 __device__ __forceinline__ int64_t pa_off(int64_t blk, int Q, int q, int pair) { return (((blk * Q + q) * PA_PAIRS + pair) * PA_BLK) * 2; }
 
-__device__ __forceinline__ void adj_det(const double* Jq, double adj[9], double& detJ) {
-   const double J11 = Jq[0], J21 = Jq[1], J31 = Jq[2], J12 = Jq[3], J22 = Jq[4], J32 = Jq[5], J13 = Jq[6], J23 = Jq[7], J33 = Jq[8];
+__device__ __forceinline__ void adj_det(const double* Jq, double adj[9], double& detJ, const int st = 1) {
+   const double J11 = Jq[0], J21 = Jq[st], J31 = Jq[2 * st], J12 = Jq[3 * st], J22 = Jq[4 * st], J32 = Jq[5 * st], J13 = Jq[6 * st], J23 = Jq[7 * st], J33 = Jq[8 * st];
    adj[0] = J22 * J33 - J23 * J32; adj[1] = J32 * J13 - J12 * J33; adj[2] = J12 * J23 - J22 * J13;
    adj[3] = J31 * J23 - J21 * J33; adj[4] = J11 * J33 - J13 * J31; adj[5] = J21 * J13 - J11 * J23;
    adj[6] = J21 * J32 - J31 * J22; adj[7] = J31 * J12 - J11 * J32; adj[8] = J11 * J22 - J12 * J21;
@@ -39,6 +39,7 @@ __device__ __forceinline__ void adj_det(const double* Jq, double adj[9], double&
 }
 
 // ---- generic-order kernels -------------------------------------------------------------------------------------------
+template <bool QB>
 __global__ void k_jacobians(const int Q, const int n, const int64_t P, const double* __restrict__ G, const double* __restrict__ xe, double* __restrict__ J) {
    extern __shared__ double sG[];
    for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
@@ -55,9 +56,11 @@ __global__ void k_jacobians(const int Q, const int n, const int64_t P, const dou
       Jl[3] += x0 * g1; Jl[4] += x1 * g1; Jl[5] += x2 * g1;
       Jl[6] += x0 * g2; Jl[7] += x1 * g2; Jl[8] += x2 * g2;
    }
-   for (int i = 0; i < 9; i++) J[9 * ip + i] = Jl[i];
+   const QView v = qview<QB>(9, Q, e, q);
+   for (int i = 0; i < 9; i++) J[v.base + (int64_t)i * v.stride] = Jl[i];
 }
 
+template <bool QB>
 __global__ void k_grad_calc(const int Q, const int n, const int64_t P, const double* __restrict__ J, const double* __restrict__ G,
                             const double* __restrict__ fe, double* __restrict__ out) {
    extern __shared__ double sG[];
@@ -66,7 +69,8 @@ __global__ void k_grad_calc(const int Q, const int n, const int64_t P, const dou
    const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (ip >= P) return;
    const int q = (int)(ip % Q); const int64_t e = ip / Q;
-   double adj[9], detJ; adj_det(J + 9 * ip, adj, detJ);
+   const QView v = qview<QB>(9, Q, e, q);
+   double adj[9], detJ; adj_det(J + v.base, adj, detJ, v.stride);
    const double di = 1.0 / detJ;
    const double* f = fe + (int64_t)3 * n * e; const double* Gq = sG + 3 * n * q;
    double L[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -77,7 +81,7 @@ __global__ void k_grad_calc(const int Q, const int n, const int64_t P, const dou
       const double v0 = f[r], v1 = f[r + n], v2 = f[r + 2 * n];
       for (int t = 0; t < 3; t++) { L[3 * t] += v0 * b[t]; L[3 * t + 1] += v1 * b[t]; L[3 * t + 2] += v2 * b[t]; }
    }
-   for (int i = 0; i < 9; i++) out[9 * ip + i] = L[i];
+   for (int i = 0; i < 9; i++) out[v.base + (int64_t)i * v.stride] = L[i];
 }
 
 // D(j,k,q,e) = W_q sum_l sigma(k,l) adj(J)(j,l)
@@ -115,18 +119,19 @@ __global__ void k_residual_apply(const int Q, const int n, const int E, const do
 }
 
 // pa record for every point of an element; one lane per element (coalesced 16-byte stores)
+template <bool QB>
 __global__ __launch_bounds__(PA_BLK) void k_grad_setup_pa(const int Q, const int E, const double dt, const double* __restrict__ W,
                                                           const double* __restrict__ J, const double* __restrict__ C, double* __restrict__ pa) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
    if (e >= E) return;
    for (int q = 0; q < Q; q++) {
-      const int64_t ip = q + (int64_t)Q * e;
-      double adj[9], detJ; adj_det(J + 9 * ip, adj, detJ);
+      const QView vj = qview<QB>(9, Q, e, q), vc = qview<QB>(36, Q, e, q);
+      double adj[9], detJ; adj_det(J + vj.base, adj, detJ, vj.stride);
       const double sc = dt * W[q] / detJ;
-      const double* c = C + 36 * ip;
+      const double* c = C + vc.base;
       double2* rec = reinterpret_cast<double2*>(pa + pa_off(blk, Q, q, 0)) + lane;
 #pragma unroll
-      for (int pr = 0; pr < 18; pr++) rec[pr * PA_BLK] = make_double2(c[2 * pr] * sc, c[2 * pr + 1] * sc);
+      for (int pr = 0; pr < 18; pr++) rec[pr * PA_BLK] = make_double2(c[(2 * pr) * vc.stride] * sc, c[(2 * pr + 1) * vc.stride] * sc);
 #pragma unroll
       for (int pr = 0; pr < 4; pr++) rec[(18 + pr) * PA_BLK] = make_double2(adj[2 * pr], adj[2 * pr + 1]);
       rec[22 * PA_BLK] = make_double2(adj[8], W[q] * detJ);
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_diag_p1(const int E, const doub
 }
 
 // fused AssemblePA + AddMultPA + scatter-add for p = 1
-template <bool LVEC>
+template <bool LVEC, bool QB>
 __global__ __launch_bounds__(PA_BLK) void k_residual_p1(const int E, const double* __restrict__ W, const double* __restrict__ J, const double* __restrict__ S,
                                                         double* __restrict__ y, const int32_t* __restrict__ conn, const int nnodes) {
    const int64_t e = (int64_t)blockIdx.x * PA_BLK + threadIdx.x;
@@ -262,9 +267,10 @@ __global__ __launch_bounds__(PA_BLK) void k_residual_p1(const int E, const doubl
       for (int a = 0; a < 8; a++) Y[c][a] = 0.0;
 #pragma unroll
    for (int q = 0; q < 8; q++) {
-      const int64_t ip = q + 8 * e;
-      double adj[9], detJ; adj_det(J + 9 * ip, adj, detJ);
-      const double* s = S + 6 * ip;
+      const QView vj = qview<QB>(9, 8, e, q), vs = qview<QB>(6, 8, e, q);
+      double adj[9], detJ; adj_det(J + vj.base, adj, detJ, vj.stride);
+      const double* sp = S + vs.base;
+      const double s[6] = { sp[0], sp[vs.stride], sp[2 * vs.stride], sp[3 * vs.stride], sp[4 * vs.stride], sp[5 * vs.stride] };
       const double w = W[q];
       const double sg[3][3] = { { s[0], s[5], s[4] }, { s[5], s[1], s[3] }, { s[4], s[3], s[2] } };
       double D[3][3];   // D[j][k]
@@ -405,6 +411,7 @@ __global__ void k_restrict_T(const int n, const int E, const int nnodes, const i
 }
 
 // partial sums of W detJ * qf(c) and of W detJ: one block -> (vdim + 1) partials
+template <bool QB>
 __global__ void k_vol_avg_partial(const int Q, const int64_t P, const int vdim, const double* __restrict__ W, const double* __restrict__ J,
                                   const double* __restrict__ qf, double* __restrict__ partial) {
    extern __shared__ double sm[];   // blockDim.x
@@ -412,9 +419,11 @@ __global__ void k_vol_avg_partial(const int Q, const int64_t P, const int vdim, 
    for (int c = 0; c <= vdim; c++) {
       double acc = 0;
       for (int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ip < P; ip += (int64_t)nb * blockDim.x) {
-         double adj[9], detJ; adj_det(J + 9 * ip, adj, detJ);
-         const double w = W[ip % Q] * detJ;
-         acc += (c < vdim) ? w * qf[c + (int64_t)vdim * ip] : w;
+         const int q = (int)(ip % Q); const int64_t e = ip / Q;
+         const QView vj = qview<QB>(9, Q, e, q), vq = qview<QB>(vdim, Q, e, q);
+         double adj[9], detJ; adj_det(J + vj.base, adj, detJ, vj.stride);
+         const double w = W[q] * detJ;
+         acc += (c < vdim) ? w * qf[vq.base + (int64_t)c * vq.stride] : w;
       }
       sm[threadIdx.x] = acc; __syncthreads();
       for (int s = blockDim.x / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
@@ -429,11 +438,13 @@ __global__ void k_vol_avg_partial(const int Q, const int64_t P, const int vdim, 
 static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 int exa_launch_jacobians(exa_ctx* ctx, const double* xe, double* J, hipStream_t s) {
-   hipLaunchKernelGGL(k_jacobians, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, xe, J);
+   if (ctx->qblk) hipLaunchKernelGGL(k_jacobians<true>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, xe, J);
+   else hipLaunchKernelGGL(k_jacobians<false>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, xe, J);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_grad_calc(exa_ctx* ctx, const double* J, const double* fe, double* out, hipStream_t s) {
-   hipLaunchKernelGGL(k_grad_calc, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, J, ctx->G_dev, fe, out);
+   if (ctx->qblk) hipLaunchKernelGGL(k_grad_calc<true>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, J, ctx->G_dev, fe, out);
+   else hipLaunchKernelGGL(k_grad_calc<false>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, J, ctx->G_dev, fe, out);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_residual_setup(exa_ctx* ctx, const double* J, const double* S, hipStream_t s) {
@@ -450,12 +461,15 @@ int exa_launch_residual_apply_from(exa_ctx* ctx, const double* D, double* Y, hip
 }
 int exa_launch_residual_p1(exa_ctx* ctx, const double* J, const double* S, double* y, bool lvec, hipStream_t s) {
    const unsigned nb = nblk(ctx->E, PA_BLK);
-   if (lvec) hipLaunchKernelGGL(k_residual_p1<true>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
-   else hipLaunchKernelGGL(k_residual_p1<false>, dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
+   if (lvec && ctx->qblk) hipLaunchKernelGGL((k_residual_p1<true, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
+   else if (lvec) hipLaunchKernelGGL((k_residual_p1<true, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
+   else if (ctx->qblk) hipLaunchKernelGGL((k_residual_p1<false, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
+   else hipLaunchKernelGGL((k_residual_p1<false, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_grad_setup_pa(exa_ctx* ctx, double dt, const double* J, const double* C, hipStream_t s) {
-   hipLaunchKernelGGL(k_grad_setup_pa, dim3(nblk(ctx->E, PA_BLK)), dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa);
+   if (ctx->qblk) hipLaunchKernelGGL(k_grad_setup_pa<true>, dim3(nblk(ctx->E, PA_BLK)), dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa);
+   else hipLaunchKernelGGL(k_grad_setup_pa<false>, dim3(nblk(ctx->E, PA_BLK)), dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s) {
@@ -495,6 +509,7 @@ int exa_launch_restrict_T(exa_ctx* ctx, const double* Ev, double* L, hipStream_t
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_vol_avg(exa_ctx* ctx, const double* J, const double* qf, int vdim, double* partial, int nb, hipStream_t s) {
-   hipLaunchKernelGGL(k_vol_avg_partial, dim3(nb), dim3(256), sizeof(double) * 256, s, ctx->Q, ctx->P, vdim, ctx->W_dev, J, qf, partial);
+   if (ctx->qblk) hipLaunchKernelGGL(k_vol_avg_partial<true>, dim3(nb), dim3(256), sizeof(double) * 256, s, ctx->Q, ctx->P, vdim, ctx->W_dev, J, qf, partial);
+   else hipLaunchKernelGGL(k_vol_avg_partial<false>, dim3(nb), dim3(256), sizeof(double) * 256, s, ctx->Q, ctx->P, vdim, ctx->W_dev, J, qf, partial);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }

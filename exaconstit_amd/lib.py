@@ -51,6 +51,9 @@ exa_num_state_vars = _sig("exa_num_state_vars", C.c_int, C.c_void_p)
 exa_nodes_per_elem = _sig("exa_nodes_per_elem", C.c_int, C.c_void_p)
 exa_qpts_per_elem = _sig("exa_qpts_per_elem", C.c_int, C.c_void_p)
 exa_shape_table = _sig("exa_shape_table", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+exa_set_quadrature_layout = _sig("exa_set_quadrature_layout", C.c_int, C.c_void_p, C.c_int)
+exa_qf_size = _sig("exa_qf_size", C.c_int64, C.c_void_p, C.c_int)
+EXA_QLAYOUT_AOS, EXA_QLAYOUT_EB64 = 0, 1
 exa_init_state = _sig("exa_init_state", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_model_setup = _sig("exa_model_setup", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_setup_lvec = _sig("exa_model_setup_lvec", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)

@@ -60,6 +60,16 @@ int exa_qpts_per_elem(const exa_ctx* ctx);
 /* reference-element tables built on the host once: src/mechanics_operator.cpp:237-261, src/mechanics_integrators.cpp:184-197 */
 int exa_shape_table(const exa_ctx* ctx, double* G_host /*(n,3,Q)*/, double* W_host /*(Q)*/);
 
+/* Layout of every quadrature function passed to this context (jacobian, stress, state, ddsdde, dp, any exa_vol_avg field):
+ *   EXA_QLAYOUT_AOS  (default) the reference's QuadratureFunction layout (vdim, Q, E), first index fastest;
+ *   EXA_QLAYOUT_EB64 [block of 64 elements][q][component][lane = element], exa_qf_size(ctx, vdim) doubles per field.  It is the
+ *                    internal layout of the stand-alone driver (every per-value access of a wave is one contiguous 512-byte row:
+ *                    the constitutive launch is 1.4x faster at 128^3); p = 1 full integration with the L-vector entry points only
+ *                    (exa_residual_setup / exa_residual_apply stay AOS).  An MFEM adapter keeps AOS. */
+enum { EXA_QLAYOUT_AOS = 0, EXA_QLAYOUT_EB64 = 1 };
+int exa_set_quadrature_layout(exa_ctx* ctx, int layout);
+int64_t exa_qf_size(const exa_ctx* ctx, int vdim);
+
 /* ExaModel seam ------------------------------------------------------------------------------------------------ */
 /* getHistInfo + init_state_vars (src/mechanics_ecmech.hpp:248-300) with setStateVarData's quaternion splice
  * (src/mechanics_driver.cpp:1058-1154): fills state0 (28,Q,E) from one quaternion per element. */

@@ -326,3 +326,73 @@ def test_model_setup_p2_matches_oracle(oracle):
         assert rel_l2(o[2].cpu().numpy(), cm) < 1e-7
         s0, sv0 = s1, sv1
     ctx.close()
+
+
+def _eb64_to_aos(t, E, Q, W):
+    """[block of 64 elements][q][component][lane] -> (E*Q, W) rows in the reference's point order"""
+    nb = (E + 63) // 64
+    return t.view(nb, Q, W, 64).permute(0, 3, 1, 2).reshape(nb * 64 * Q, W)[: E * Q]
+
+
+@pytest.mark.parametrize("model,pkey", [(0, "voce"), (5, "mts")])
+def test_element_blocked_layout_matches_aos(oracle, model, pkey):
+    """EXA_QLAYOUT_EB64 (the driver's internal quadrature-function layout) gives the same numbers as the reference layout through
+    every entry point that accepts it: init_state, model_setup (E- and L-vector), jacobians, grad_calc, residual_lvec, grad_setup +
+    apply (PA and EA), vol_avg, calc_dp.  E = 125 is not a multiple of 64 (partial last block)."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 5, distort=0.15)
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    props = _props(orc, pkey)
+    quats = hipref.random_quats(E)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    v_nodes = hipref.velocity_field(rve, scale=2.0)
+    res = {}
+    for layout in (L.EXA_QLAYOUT_AOS, L.EXA_QLAYOUT_EB64):
+        for assembly in (L.EXA_ASSEMBLY_PA, L.EXA_ASSEMBLY_EA):
+            ctx = L.Context(model, props, 298.0, 1, E, assembly=assembly)
+            ctx.check(L.exa_set_quadrature_layout(ctx.h, layout))
+            ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+            sz = lambda w: int(L.exa_qf_size(ctx.h, w))
+            assert sz(9) == (9 * P if layout == L.EXA_QLAYOUT_AOS else 9 * 64 * Q * ((E + 63) // 64))
+            aos = (lambda t, w: t.view(-1, w)[:P]) if layout == L.EXA_QLAYOUT_AOS else (lambda t, w: _eb64_to_aos(t, E, Q, w))
+            sv = [dev.zeros(sz(28)), dev.zeros(sz(28))]; sg = [dev.zeros(sz(6)), dev.zeros(sz(6))]
+            cm = dev.zeros(sz(36)); J = dev.zeros(sz(9)); J2 = dev.zeros(sz(9)); F = dev.zeros(sz(9)); dp = dev.zeros(sz(9))
+            ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(dev.up(quats.ravel())), None))
+            d_x = dev.up(rve["X"]); d_v = dev.up(v_nodes)
+            for dt in (0.1, 0.3, 0.5):
+                d_x += dt * d_v
+                ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(sg[0]), ptr(sv[0]), ptr(sg[1]), ptr(sv[1]), ptr(cm), ptr(J), None))
+                assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+                sv.reverse(); sg.reverse()
+            out = dict(state=aos(sv[0], 28).cpu().numpy(), stress=aos(sg[0], 6).cpu().numpy(), cm=aos(cm, 36).cpu().numpy(), J=aos(J, 9).cpu().numpy())
+            # E-vector entry with the Jacobians from exa_jacobians reproduces the fused launch (same begin-of-step data: redo the last step)
+            xe = dev.up(hipref.l_to_e(rve, d_x.cpu().numpy())); ve = dev.up(hipref.l_to_e(rve, v_nodes))
+            ctx.check(L.exa_jacobians(ctx.h, ptr(xe), ptr(J2), None))
+            assert rel_l2(aos(J2, 9).cpu().numpy(), out["J"]) < 1e-14
+            s2 = dev.zeros(sz(6)); v2 = dev.zeros(sz(28)); c2 = dev.zeros(sz(36))
+            ctx.check(L.exa_model_setup(ctx.h, 0.5, ptr(J2), ptr(ve), ptr(sg[1]), ptr(sv[1]), ptr(s2), ptr(v2), ptr(c2), None))
+            assert rel_l2(aos(s2, 6).cpu().numpy(), out["stress"]) < 1e-12 and rel_l2(aos(c2, 36).cpu().numpy(), out["cm"]) < 1e-10
+            ctx.check(L.exa_grad_calc(ctx.h, ptr(J2), ptr(ve), ptr(F), None)); out["vgrad"] = aos(F, 9).cpu().numpy()
+            ctx.check(L.exa_calc_dp(ctx.h, ptr(sv[0]), ptr(dp), None)); out["dp"] = aos(dp, 9).cpu().numpy()
+            y = dev.zeros(3 * NN); ctx.check(L.exa_residual_lvec(ctx.h, ptr(J), ptr(sg[0]), ptr(y), None)); out["resid"] = y.cpu().numpy()
+            ctx.check(L.exa_grad_setup(ctx.h, 0.5, ptr(J), ptr(cm), None))
+            xg = dev.up(np.random.default_rng(1).standard_normal(3 * NN)); yg = dev.zeros(3 * NN)
+            mask = torch.zeros(3 * NN, dtype=torch.uint8, device=dev.dev)
+            ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(xg), ptr(yg), ptr(mask), None)); out["apply"] = yg.cpu().numpy()
+            avg = np.zeros(7); ctx.check(L.exa_vol_avg(ctx.h, ptr(J), ptr(sg[0]), 6, 1, avg.ctypes.data_as(C.POINTER(C.c_double)), None)); out["avg"] = avg.copy()
+            if layout == L.EXA_QLAYOUT_EB64:
+                assert L.exa_residual_setup(ctx.h, ptr(J), ptr(sg[0]), None) == -4          # EXA_ERR_UNSUPPORTED: E-vector residual is AOS-only
+            res[(layout, assembly)] = out
+            ctx.close()
+    for assembly in (L.EXA_ASSEMBLY_PA, L.EXA_ASSEMBLY_EA):
+        a, b = res[(L.EXA_QLAYOUT_AOS, assembly)], res[(L.EXA_QLAYOUT_EB64, assembly)]
+        for k in a:
+            tol = 1e-13 if k in ("J", "vgrad", "dp") else 1e-11      # the fused kernel's thread mapping differs (same arithmetic per point)
+            assert rel_l2(b[k], a[k]) < tol, (assembly, k)
+    p2 = L.Context(0, _props(orc, "voce"), 298.0, 2, 8)
+    assert L.exa_set_quadrature_layout(p2.h, L.EXA_QLAYOUT_EB64) == -4
+    p2.close()
