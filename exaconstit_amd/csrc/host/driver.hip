@@ -286,8 +286,8 @@ void NonlinearMechOperator::GetGradient() {
    vk_jacobi_setup(nd_, ess_mask.p, diag.p, precond == Precond::IDENTITY ? 1 : 0, dinv.p, stream_);
 }
 
-void NonlinearMechOperator::GradMult(const double* x, double* y, bool constrained, const double* done_flag) {
-   vk_fill_if(nd_, done_flag, 0.0, y, stream_);
+void NonlinearMechOperator::GradMult(const double* x, double* y, bool constrained, const double* done_flag, bool y_prezeroed, bool skip_out_mask) {
+   if (!y_prezeroed) vk_fill_if(nd_, done_flag, 0.0, y, stream_);
    if (lvec_grad_) abi_check(ctx_, exa_grad_apply_lvec_gated(ctx_, x, y, constrained ? ess_mask.p : nullptr, done_flag, stream_), "exa_grad_apply_lvec");
    else {   // generic-order partial assembly: mask, L->E, AddMultGradPA, E->L (spec reference src/mechanics_operator_ext.cpp:143-157)
       EXA_HC(hipMemcpyAsync(tmp_l_.p, x, sizeof(double) * nd_, hipMemcpyDeviceToDevice, stream_));
@@ -298,7 +298,7 @@ void NonlinearMechOperator::GradMult(const double* x, double* y, bool constraine
       abi_check(ctx_, exa_restrict_transpose_add(ctx_, el_y_.p, y, stream_), "exa_restrict_transpose_add");
    }
    comm_.halo_sum(part_, y, stream_);
-   if (constrained) vk_mask_zero(nd_, ess_mask.p, y, stream_);
+   if (constrained && !skip_out_mask) vk_mask_zero(nd_, ess_mask.p, y, stream_);
 }
 
 void NonlinearMechOperator::GetUpdateBCsAction(const double* k, const double* x, double* y) {
@@ -425,14 +425,21 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    comm.allreduce_sum(S + 8, 1, s);
    vk_cg_den(S, s);
    double hS[9]; int launched = 0; bool done = false;
+   const bool fused = std::getenv("EXA_PCG_UNFUSED") == nullptr;   // A/B switch for measurements
    while (!done) {
       for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) {
          vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, s);
          comm.allreduce_sum(S + 8, 1, s);
          vk_cg_beta(S, opt_.krylov_iter, s);
-         vk_cg_step2(nd, S, cg_z_.p, cg_d_.p, s);
-         op.GradMult(cg_d_.p, cg_z_.p, true, S + 6);
-         vk_dot(nd, nn, op.weight.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s);
+         if (fused) {
+            vk_cg_step2z(nd, S, cg_z_.p, cg_d_.p, s);                    // d = z + beta d; z = 0
+            op.GradMult(cg_d_.p, cg_z_.p, true, S + 6, true, true);       // z += K d (input masked in the kernel, output mask folded into the dot)
+            vk_mask_dot(nd, nn, op.weight.p, op.ess_mask.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s);
+         } else {
+            vk_cg_step2(nd, S, cg_z_.p, cg_d_.p, s);
+            op.GradMult(cg_d_.p, cg_z_.p, true, S + 6);
+            vk_dot(nd, nn, op.weight.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s);
+         }
          comm.allreduce_sum(S + 8, 1, s);
          vk_cg_den(S, s);
       }

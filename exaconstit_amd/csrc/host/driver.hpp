@@ -86,7 +86,8 @@ class NonlinearMechOperator {
    // Jacobian set-up + Jacobi diagonal (reference src/mechanics_operator.cpp:436-443)
    void GetGradient();
    // y = K x with essential columns/rows masked (constrained) or the plain local action
-   void GradMult(const double* x, double* y, bool constrained, const double* done_flag = nullptr);
+   // y_prezeroed / skip_out_mask: the PCG loop folds the zero fill into its direction update and the output mask into its dot product
+   void GradMult(const double* x, double* y, bool constrained, const double* done_flag = nullptr, bool y_prezeroed = false, bool skip_out_mask = false);
    // reference src/mechanics_operator.cpp:446-483
    void GetUpdateBCsAction(const double* k, const double* x, double* y);
    void ResidualAction(double* y);

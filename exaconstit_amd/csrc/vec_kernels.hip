@@ -120,6 +120,26 @@ __global__ void k_cg_step2(int64_t n, const double* __restrict__ S, const double
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = z[i] + beta * d[i];
 }
 
+// d = z + beta d, then z = 0: the operator action that follows accumulates into z with atomics, so the separate fill pass is folded in
+__global__ void k_cg_step2z(int64_t n, const double* __restrict__ S, double* __restrict__ z, double* __restrict__ d) {
+   if (S[6] != 0.0) return;
+   const double beta = S[5];
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { d[i] = z[i] + beta * d[i]; z[i] = 0.0; }
+}
+
+// essential rows of b zeroed in place + partial weighted dot (a, b): the operator's output mask and the PCG denominator in one pass
+__global__ void k_mask_dot_partial(int64_t n, int64_t nn, const double* __restrict__ w, const uint8_t* __restrict__ m, const double* __restrict__ a,
+                                   double* __restrict__ b, const double* __restrict__ flag, double* __restrict__ partial) {
+   __shared__ double sm[RBLK];
+   if (flag && flag[0] != 0.0) return;
+   double acc = 0;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      if (m[i]) b[i] = 0.0; else acc += w[i % nn] * a[i] * b[i];
+   }
+   const double s = block_sum(acc, sm);
+   if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
 __global__ void k_fill_if(int64_t n, const double* __restrict__ flag, double val, double* __restrict__ y) {
    if (flag && flag[0] != 0.0) return;
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = val;
@@ -203,6 +223,12 @@ void vk_min3(int64_t nn, const double* x, double* partial, double* out3, hipStre
 void vk_vgrad_velocity(int64_t nn, const uint8_t* m, const double* x, const double* org, const double* L9, double* v, hipStream_t s) {
    double9 L; for (int i = 0; i < 9; i++) L.a[i] = L9[i];
    hipLaunchKernelGGL(k_vgrad_velocity, dim3(nblk(nn)), dim3(256), 0, s, nn, m, x, org, L, v);
+}
+void vk_cg_step2z(int64_t n, const double* S, double* z, double* d, hipStream_t s) { hipLaunchKernelGGL(k_cg_step2z, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, d); }
+void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* a, double* b, const double* flag, double* partial, double* out, hipStream_t s) {
+   const unsigned nb = gblk(n);
+   hipLaunchKernelGGL(k_mask_dot_partial, dim3(nb), dim3(RBLK), 0, s, n, nn, w, m, a, b, flag, partial);
+   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out);
 }
 void vk_cg_init(double* S, double rel, double abs_, hipStream_t s) { hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1), 0, s, S, rel, abs_); }
 void vk_cg_den(double* S, hipStream_t s) { hipLaunchKernelGGL(k_cg_den, dim3(1), dim3(1), 0, s, S); }
