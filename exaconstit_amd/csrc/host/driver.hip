@@ -327,6 +327,15 @@ static void load_case_data(const ExaOptions& opt, const Partition& part, std::ve
    props = ExaOptions::load_numbers(opt.resolve(opt.props_file));
    if ((int)props.size() != opt.nprops) throw std::runtime_error("Properties file does not hold num_props values");
    std::vector<double> ori = ExaOptions::load_numbers(opt.resolve(opt.ori_file));
+   quats_local.resize((size_t)4 * part.E);
+   if (part.from_file) {   // grain id = element attribute (reference src/mechanics_driver.cpp:1117-1125)
+      for (int e = 0; e < part.E; e++) {
+         const int grain = part.elem_attr[e] - 1;
+         if (grain < 0 || 4 * (grain + 1) > (int)ori.size()) throw std::runtime_error("Element attribute outside the orientation file");
+         for (int q = 0; q < 4; q++) quats_local[4 * (size_t)e + q] = ori[4 * (size_t)grain + q];
+      }
+      return;
+   }
    std::vector<double> gmap = ExaOptions::load_numbers(opt.resolve(opt.grain_file));
    const int f = 1 << opt.ref_ser;
    const int c0 = opt.ncuts[0], c1 = opt.ncuts[1], c2 = opt.ncuts[2];
@@ -344,8 +353,10 @@ static void load_case_data(const ExaOptions& opt, const Partition& part, std::ve
 
 SystemDriver::SystemDriver(const ExaOptions& opt, int rank, int nranks, const void* uid) : opt_(opt) {
    comm.init(rank, nranks, uid);
-   const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
-   part.build(N, opt.length, rank, nranks, opt.order);
+   if (opt.mesh_type == "auto") {
+      const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
+      part.build(N, opt.length, rank, nranks, opt.order);
+   } else part.build_from_mfem_mesh(opt.resolve(opt.mesh_file), rank, nranks);
    std::vector<double> props, quats; load_case_data(opt, part, props, quats);
    init(props, quats);
 }

@@ -8,7 +8,12 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
 #include <vector>
+#include <algorithm>
 
 namespace exa_host {
 
@@ -25,6 +30,8 @@ struct Partition {
    std::vector<int64_t> elem_gid;    // global element index, x fastest
    std::vector<double> weight;       // 1 / (number of ranks holding the node)
    std::vector<Neighbor> nbrs;
+   // meshes read from a file (Mesh.type = "other"): grain id = element attribute, boundary ids = boundary-element attributes
+   bool from_file = false; std::vector<int> elem_attr; std::vector<std::vector<uint8_t>> bdr_nodes;   // [attribute - 1][node]
    int64_t E_global() const { return (int64_t)N[0] * N[1] * N[2]; }
 
    static void split(int n, int p, int r, int& start, int& cnt) { const int b = n / p, rem = n % p; cnt = b + (r < rem ? 1 : 0); start = r * b + (r < rem ? r : rem); }
@@ -106,8 +113,67 @@ struct Partition {
       }
    }
 
+   // MFEM mesh v1.0 reader for trilinear hexahedra (what the reference gets from `Mesh(mesh_file, 1, 1, true)`, src/mechanics_driver.cpp:239-241;
+   // format of workflows/Stage3/main_simulations/simulation.mesh): sections `dimension`, `elements` (attr geom=5 v0..v7, MFEM vertex order =
+   // this repo's native order), `boundary` (attr geom=3 v0..v3), `vertices` with inline coordinates or a `nodes` grid function (H1 order 1).
+   // One rank only: there is no graph partitioner here (the reference uses METIS through ParMesh).
+   void build_from_mfem_mesh(const std::string& path, int rank_, int nranks_) {
+      if (nranks_ != 1) throw std::runtime_error("Mesh.type = \"other\": file meshes run on one rank (no graph partitioner in this driver)");
+      std::ifstream f(path);
+      if (!f) throw std::runtime_error("Cannot open mesh file: " + path);
+      auto next_token_line = [&](std::string& line) {   // next non-empty, non-comment line
+         while (std::getline(f, line)) { size_t a = line.find_first_not_of(" \t\r"); if (a == std::string::npos || line[a] == '#') continue; line = line.substr(a); while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back(); return true; }
+         return false;
+      };
+      std::string line;
+      if (!next_token_line(line) || line.rfind("MFEM mesh v1.0", 0) != 0) throw std::runtime_error("Not an MFEM mesh v1.0 file: " + path);
+      p = 1; n = 8; rank = rank_; nranks = nranks_; from_file = true;
+      for (int d = 0; d < 3; d++) { N[d] = 0; pg[d] = 1; rc[d] = 0; e0[d] = 0; ne[d] = 0; nn[d] = 0; }
+      int nv = -1; std::vector<std::array<int, 5>> bdr;
+      while (next_token_line(line)) {
+         if (line == "dimension") { next_token_line(line); if (std::stoi(line) != 3) throw std::runtime_error("mesh: dimension must be 3"); }
+         else if (line == "elements") {
+            next_token_line(line); E = std::stoi(line);
+            conn.resize((size_t)8 * E); elem_attr.resize(E); elem_gid.resize(E);
+            for (int e = 0; e < E; e++) {
+               next_token_line(line); std::istringstream is(line); int attr, geom; is >> attr >> geom;
+               if (geom != 5) throw std::runtime_error("mesh: only hexahedra (geometry 5) are supported");
+               elem_attr[e] = attr; elem_gid[e] = e;
+               for (int a = 0; a < 8; a++) { int v; if (!(is >> v)) throw std::runtime_error("mesh: short element line"); conn[a + (size_t)8 * e] = v; }
+            }
+         } else if (line == "boundary") {
+            next_token_line(line); const int nbe = std::stoi(line);
+            for (int b = 0; b < nbe; b++) {
+               next_token_line(line); std::istringstream is(line); int attr, geom; is >> attr >> geom;
+               if (geom != 3) throw std::runtime_error("mesh: only quadrilateral boundary elements (geometry 3) are supported");
+               std::array<int, 5> q; q[0] = attr; for (int a = 0; a < 4; a++) is >> q[1 + a];
+               bdr.push_back(q);
+            }
+         } else if (line == "vertices") {
+            next_token_line(line); nv = std::stoi(line); NN = nv; X.assign((size_t)3 * NN, 0.0);
+            next_token_line(line);
+            bool by_nodes_order = false;
+            if (line == "nodes") {   // grid-function form: header lines up to the first coordinate line
+               while (next_token_line(line)) {
+                  if (line.rfind("Ordering:", 0) == 0) { by_nodes_order = (std::stoi(line.substr(9)) == 0); break; }
+                  if (line.rfind("FiniteElementCollection:", 0) == 0 && line.find("H1_3D_P1") == std::string::npos) throw std::runtime_error("mesh: only H1_3D_P1 nodes are supported");
+               }
+            } else if (std::stoi(line) != 3) throw std::runtime_error("mesh: vertex dimension must be 3");
+            if (by_nodes_order) { for (int d = 0; d < 3; d++) for (int g = 0; g < NN; g++) { next_token_line(line); X[g + (size_t)NN * d] = std::stod(line); } }
+            else for (int g = 0; g < NN; g++) { next_token_line(line); std::istringstream is(line); for (int d = 0; d < 3; d++) is >> X[g + (size_t)NN * d]; }
+         }
+      }
+      if (E <= 0 || nv <= 0) throw std::runtime_error("mesh: missing elements or vertices section");
+      for (int32_t v : conn) if (v < 0 || v >= NN) throw std::runtime_error("mesh: vertex index out of range");
+      int maxattr = 0; for (auto& q : bdr) maxattr = std::max(maxattr, q[0]);
+      bdr_nodes.assign(maxattr, std::vector<uint8_t>(NN, 0));
+      for (auto& q : bdr) for (int a = 0; a < 4; a++) bdr_nodes[q[0] - 1][q[1 + a]] = 1;
+      weight.assign(NN, 1.0); nbrs.clear();
+   }
+
    // is local node g on global boundary face id?
    bool on_face(int g, int id) const {
+      if (from_file) return id >= 1 && id <= (int)bdr_nodes.size() && bdr_nodes[id - 1][g] != 0;
       const int i = g % nn[0] + e0[0] * p, j = (g / nn[0]) % nn[1] + e0[1] * p, k = g / (nn[0] * nn[1]) + e0[2] * p;
       switch (id) { case 1: return k == 0; case 2: return i == 0; case 3: return j == 0; case 4: return k == N[2] * p; case 5: return i == N[0] * p; default: return j == N[1] * p; }
    }

@@ -102,7 +102,7 @@ struct ExaOptions {
    Assembly assembly = Assembly::EA; NLSolver nl_solver = NLSolver::NR; std::string integ_model = "FULL";
    int newton_iter = 25; double newton_rel = 1e-5, newton_abs = 1e-10;
    int krylov_iter = 200; double krylov_rel = 1e-10, krylov_abs = 1e-30; std::string krylov_solver = "PCG";
-   int ref_ser = 0, order = 1; int ncuts[3] = { 1, 1, 1 }; double length[3] = { 1, 1, 1 }; std::string mesh_type = "auto";
+   int ref_ser = 0, order = 1; int ncuts[3] = { 1, 1, 1 }; double length[3] = { 1, 1, 1 }; std::string mesh_type = "auto", mesh_file;
 
    static std::vector<double> load_numbers(const std::string& path) {
       std::ifstream f(path); if (!f) throw std::runtime_error("Cannot open data file: " + path);
@@ -194,10 +194,16 @@ struct ExaOptions {
       krylov_solver = d.str("Solvers.Krylov.solver", "PCG");
       ref_ser = (int)d.num("Mesh.ref_ser", 0); order = (int)d.num("Mesh.p_refinement", 1);   // tests write "prefinement": ignored like the reference (src/option_parser.cpp:677)
       mesh_type = lower(d.str("Mesh.type", "other"));
-      if (mesh_type != "auto") throw std::runtime_error("Only Mesh.type = \"auto\" is supported by this driver");
-      const TomlValue* nc = d.get("Mesh.Auto.ncuts"); const TomlValue* ln = d.get("Mesh.Auto.length");
-      if (!nc || !ln || nc->arr.size() != 3 || ln->arr.size() != 3) throw std::runtime_error("Must input mesh geometry/discretization for hex_mesh_gen");
-      for (int i = 0; i < 3; i++) { ncuts[i] = (int)nc->arr[i].num; length[i] = ln->arr[i].num; }
+      mesh_file = d.str("Mesh.floc", "");
+      if (mesh_type == "other" || mesh_type == "cubit") {   // file mesh (reference src/mechanics_driver.cpp:239-241); MFEM mesh v1.0 hexahedra only
+         if (mesh_file.empty()) throw std::runtime_error("Mesh.floc is required for Mesh.type = \"other\"");
+         if (ref_ser != 0) throw std::runtime_error("Mesh.ref_ser > 0 is only built for auto-generated meshes");
+         if (order != 1) throw std::runtime_error("File meshes run at p_refinement = 1");
+      } else if (mesh_type == "auto") {
+         const TomlValue* nc = d.get("Mesh.Auto.ncuts"); const TomlValue* ln = d.get("Mesh.Auto.length");
+         if (!nc || !ln || nc->arr.size() != 3 || ln->arr.size() != 3) throw std::runtime_error("Must input mesh geometry/discretization for hex_mesh_gen");
+         for (int i = 0; i < 3; i++) { ncuts[i] = (int)nc->arr[i].num; length[i] = ln->arr[i].num; }
+      } else throw std::runtime_error("Mesh.type must be \"auto\", \"other\" or \"cubit\"");
       if (order != 1 && order != 2) throw std::runtime_error("Only p_refinement = 1 or 2 is built");
    }
 };

@@ -150,3 +150,27 @@ def test_auto_time_stepping_matches_oracle(oracle, tmp_path):
     assert np.linalg.norm(s[:, 2] - ref["avg_stress"][:, 2]) / np.linalg.norm(ref["avg_stress"][:, 2]) < 1e-6
     dts = np.loadtxt(os.path.join(str(tmp_path), "auto_dt_out.txt"))
     assert np.allclose(dts, ref["dts"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("mesh", ["cube5_nodes.mesh", "cube5_shuffled.mesh"])
+def test_file_mesh_matches_generated_mesh(oracle, tmp_path, mesh):
+    """Mesh.type = "other" (MFEM mesh v1.0 file, reference src/mechanics_driver.cpp:239-241; grain ids = element attributes, boundary ids
+    = boundary attributes): the 5^3 RVE read from a file — natural order with a `nodes` grid function, and with elements / vertices
+    permuted — gives the run of the generated mesh (explicit connectivity: no kernel depends on the structured numbering)."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    n = 4
+    auto = _variant_toml(tmp_path, "voce_pa.toml", [("ref_ser = 1", "ref_ser = 0")], "auto5")
+    filem = _variant_toml(tmp_path, "voce_pa.toml", [("ref_ser = 1", "ref_ser = 0"), ('type = "auto"', 'type = "other"'),
+                                                     ('floc = "../../data/cube-hex-ro.mesh"', 'floc = "%s"' % os.path.join(orc.REFDATA, mesh))], "file5")
+    out = []
+    for path in (auto, filem):
+        d = L.Driver.from_toml(path, out_dir=str(tmp_path))
+        for ti in range(1, n + 1):
+            assert d.step(ti)
+        out.append((d.avgs(0, 6), d.stats()))
+        d.close()
+    assert np.max(np.abs(out[0][0] - out[1][0])) < 1e-10 * np.abs(out[0][0]).max()
+    assert list(out[0][1][0]) == list(out[1][1][0])
+    ref = orc.run_case(orc.load_case(auto), nsteps=n)
+    assert np.linalg.norm(out[1][0][:, 2:] - ref["avg_stress"][:, 2:]) / np.linalg.norm(ref["avg_stress"][:, 2:]) < 1e-6

@@ -53,6 +53,10 @@ def test_options_reader_rejects_unsupported(tmp_path):
     assert rc == -1 and "essential_vel_grad was not provided" in msg      # reference src/option_parser.cpp:217-219
     rc, msg = q(txt.replace('mech_type = "exacmech"', 'mech_type = "umat"'))
     assert rc == -1 and "exacmech" in msg
+    rc, msg = q(txt.replace('type = "auto"', 'type = "other"').replace('floc = "../../data/cube-hex-ro.mesh"', 'floc = "%s"' % os.path.join(REF, "cube5_nodes.mesh")).replace("ref_ser = 1", "ref_ser = 0"))
+    assert rc == 0, msg                                      # MFEM mesh v1.0 file meshes (reference src/mechanics_driver.cpp:239-241)
+    rc, msg = q(txt.replace('type = "auto"', 'type = "other"'))
+    assert rc == -1 and "ref_ser" in msg                     # uniform refinement of file meshes is not built: loud
     rc, msg = q(txt.replace('assembly = "EA"', 'assembly = "PA"\n    integ_model = "BBAR"'))
     assert rc == -1 and "BBAR" in msg                        # no partial-assembly gradient for B-bar (reference README.md:20)
 
