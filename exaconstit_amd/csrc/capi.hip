@@ -5,6 +5,7 @@
 
 int exa_launch_model_setup(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, hipStream_t);
 int exa_launch_init_state(exa_ctx*, double*, const double*, const double*, hipStream_t);
+int exa_launch_nfev_hist(exa_ctx*, const double*, int*, hipStream_t);
 int exa_launch_calc_dp(exa_ctx*, const double*, double*, hipStream_t);
 int exa_launch_jacobians(exa_ctx*, const double*, double*, hipStream_t);
 int exa_launch_grad_calc(exa_ctx*, const double*, const double*, double*, hipStream_t);
@@ -70,7 +71,7 @@ exa_ctx* exa_create(const exa_config* cfg, int* err) {
 
 void exa_destroy(exa_ctx* ctx) {
    if (!ctx) return;
-   (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->scratch_dev);
+   (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->tail_dev); (void)hipFree(ctx->scratch_dev);
    (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->tbuf);
    delete ctx;
 }
@@ -122,6 +123,28 @@ int exa_model_status(exa_ctx* ctx, exa_stream s) {
    if (!ctx) return EXA_ERR_ARG;
    int h = 0;
    EXA_HIP_CHECK(ctx, hipMemcpyAsync(&h, ctx->fail_count_dev, sizeof(int), hipMemcpyDeviceToHost, S(s)));
+   EXA_HIP_CHECK(ctx, hipStreamSynchronize(S(s)));
+   return h;
+}
+
+int exa_set_newton_cap(exa_ctx* ctx, int max_evals) {
+   if (!ctx || (max_evals != 0 && max_evals < 2)) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_cap: 0 (off) or >= 2");
+   ctx->newton_cap = max_evals; return EXA_OK;
+}
+int exa_model_nfev_hist(exa_ctx* ctx, const double* state, int* hist64_host, exa_stream s) {
+   if (!ctx || !state || !hist64_host) return fail(ctx, EXA_ERR_ARG, "exa_model_nfev_hist: null pointer");
+   int* hd = reinterpret_cast<int*>(ctx->scratch_dev);
+   int rc = exa_launch_nfev_hist(ctx, state, hd, S(s));
+   if (rc) return rc;
+   EXA_HIP_CHECK(ctx, hipMemcpyAsync(hist64_host, hd, sizeof(int) * 64, hipMemcpyDeviceToHost, S(s)));
+   EXA_HIP_CHECK(ctx, hipStreamSynchronize(S(s)));
+   return EXA_OK;
+}
+int exa_model_tail_count(exa_ctx* ctx, exa_stream s) {
+   if (!ctx) return EXA_ERR_ARG;
+   if (!ctx->tail_dev || ctx->newton_cap <= 0) return 0;
+   int h = 0;
+   EXA_HIP_CHECK(ctx, hipMemcpyAsync(&h, ctx->tail_dev, sizeof(int), hipMemcpyDeviceToHost, S(s)));
    EXA_HIP_CHECK(ctx, hipStreamSynchronize(S(s)));
    return h;
 }

@@ -717,13 +717,13 @@ ECM_DI double norm8(const double v[8]) { double s = 0; for (int i = 0; i < 8; i+
 //   sv1/s1 : end-of-step outputs;  cmat: 6x6 tangent d sigma / d eps (engineering shear), column-major (used as a parking
 //            area for cold values until it is written at the very end)
 //   st     : per-thread stash (LDS), ST_SLOTS slots of stride ECM_STASH_STRIDE
-// returns 0 on success, 1 if the local solve failed to converge
+// returns 0 on success, 1 if the local solve failed to converge, 2 if it was cut off after kcap evaluations (nothing written)
 // ------------------------------------------------------------------------------------------------------------
 // QS: distance (in doubles) between consecutive values of one point in the state / stress / tangent arrays: 1 for the reference's
 // AoS quadrature functions, 64 for the element-blocked layout (exa_internal.hpp, QView)
 template <int KIN, int QS>
 ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const double* __restrict__ sv0, const double* __restrict__ s0,
-                        double* __restrict__ sv1, double* __restrict__ s1, double* __restrict__ cmat, double* st) {
+                        double* __restrict__ sv1, double* __restrict__ s1, double* __restrict__ cmat, double* st, const int kcap) {
    double* cold = cmat;
    Prob pb; pb.st = st; pb.gs = QS;
    pb.dt_ri = 1.0 / dt;
@@ -782,6 +782,9 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    if (ok && !conv) {
       double delta = 1.0;
       for (int it = 0; it < 200; it++) {
+         // tail split: a point that needs more than kcap evaluations is handed to the dense tail launch (which starts over, so the
+         // result is the one of an uncapped solve); the wave stops waiting for its slowest lanes
+         if (nfev >= kcap) return 2;
          // Newton step first; the steepest-descent data (grad = Js^T r, Jg = Js grad) only when the step leaves the trust region
          double nr[8], t[8];
          jac_factor(mp, pb, J, F);

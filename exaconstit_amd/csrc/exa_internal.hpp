@@ -47,6 +47,7 @@ struct exa_ctx {
    const int32_t* conn = nullptr; int nnodes = 0;
    // status
    int* fail_count_dev = nullptr;
+   int newton_cap = 0; int* tail_dev = nullptr;   // tail split of the constitutive launch: [0] = count, [1..] = deferred point ids
    double* scratch_dev = nullptr; size_t scratch_bytes = 0;   // reductions
    double hist_init[ecmdev::NUM_HIST];
 };

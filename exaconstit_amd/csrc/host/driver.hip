@@ -219,7 +219,11 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    nn_ = part.NN; nd_ = 3 * nn_; E_ = part.E; npe_ = part.n;
    fast_p1_ = (part.p == 1 && !bbar);          // fused L-vector kernels exist for p = 1 full integration
    lvec_grad_ = fast_p1_ || opt.assembly == Assembly::EA;
-   fused_setup_ = std::getenv("EXA_UNFUSED_SETUP") == nullptr;   // A/B switch for measurements; the fused launch is the product path
+   fused_setup_ = std::getenv("EXA_UNFUSED_SETUP") == nullptr;
+   // tail split of the constitutive launch (include/exaconstit_hip.h): EXA_NEWTON_CAP=off | <K> | unset (chosen from the evaluation-count histogram of the previous launch)
+   if (const char* nc = std::getenv("EXA_NEWTON_CAP")) { cap_auto_ = false; newton_cap_ = (std::string(nc) == "off") ? 0 : std::atoi(nc); }
+   tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.5 : 4.0;
+   abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 path (EXA_QLAYOUT=aos switches back for A/B runs)
    const char* ql = std::getenv("EXA_QLAYOUT");
    if (fast_p1_ && !(ql && std::string(ql) == "aos")) abi_check(ctx_, exa_set_quadrature_layout(ctx_, EXA_QLAYOUT_EB64), "exa_set_quadrature_layout");
@@ -241,6 +245,38 @@ NonlinearMechOperator::~NonlinearMechOperator() { exa_destroy(ctx_); (void)hipEv
 
 void NonlinearMechOperator::UpdateEssTDofs(const std::vector<uint8_t>& mask) { ess_mask.upload(mask); }
 
+// Cost model of the tail split in units of one residual evaluation per point.  A wave costs the largest evaluation count among its 64
+// lanes: E[max of 64 draws].  With cap K the first launch draws from min(n, K) and the dense second launch from {n > K} (plus ~2
+// evaluations' worth of set-up / tangent / I/O per redone point):  C(K) = Emax64(min(n,K)) + 0.2 + f_tail w (Emax64(n | n > K) + 2).
+// w = measured cost of a point in the second launch relative to the first (its lanes are scattered points: 8-byte accesses into the
+// blocked rows): 4 for the Voce kernels, whose first launch is close to the memory system's limits, 1.5 for the compute-heavy
+// Kocks-Mecking kernel; 0.2 = the second launch's fixed cost.  Measured at 128^3: BCC KM-DD 31.6 -> 16.0 ms, FCC KM-DD 70.9 -> 55.9 ms,
+// Voce stays uncapped (6.9 ms; K = 5 would cost 10.2 ms, which the model reproduces).
+// Returns the K minimising C, or 0 (off) when it does not beat the uncapped launch by 3 %.
+int NonlinearMechOperator::choose_newton_cap(const int* hist) {
+   double tot = 0; for (int i = 0; i < 64; i++) tot += hist[i];
+   if (tot <= 0) return 0;
+   auto emax = [&](int lo, int hi, double n) {   // E[max of 64 draws] of the histogram restricted to bins lo..hi (n = its population)
+      if (n <= 0) return 0.0;
+      double F = 0, prev = 0, e = 0;
+      for (int m = lo; m <= hi; m++) { F += hist[m] / n; const double f64 = std::pow(std::min(F, 1.0), 64.0); e += m * (f64 - prev); prev = f64; }
+      return e;
+   };
+   const double c_inf = emax(0, 63, tot);
+   double best = c_inf; int bestk = 0;
+   for (int K = 3; K < 40; K++) {
+      double ntail = 0; for (int m = K + 1; m < 64; m++) ntail += hist[m];
+      if (ntail == 0) break;
+      // first launch: bins above K collapse onto K
+      double F = 0, prev = 0, e = 0;
+      for (int m = 0; m <= K; m++) { F += (m < K ? hist[m] : tot - [&] { double a = 0; for (int j = 0; j < K; j++) a += hist[j]; return a; }()) / tot;
+                                     const double f64 = std::pow(std::min(F, 1.0), 64.0); e += m * (f64 - prev); prev = f64; }
+      const double c = e + 0.2 + ntail / tot * tail_cost_ * (emax(K + 1, 63, ntail) + 2.0);
+      if (c < best) { best = c; bestk = K; }
+   }
+   return (best < 0.97 * c_inf) ? bestk : 0;
+}
+
 template <bool upd_crds>
 void NonlinearMechOperator::Setup(const double* k) {
    if (upd_crds) vk_update_coords(nd_, x_beg.p, k, dt_, x_cur.p, stream_);   // ExaModel::UpdateEndCoords (halo copies stay consistent)
@@ -256,6 +292,11 @@ void NonlinearMechOperator::Setup(const double* k) {
    EXA_HC(hipEventSynchronize(ev1_));
    float ms = 0; EXA_HC(hipEventElapsedTime(&ms, ev0_, ev1_));
    timers.t_model_ms += ms; timers.qpt_updates += (int64_t)E_ * npe_; model_calls++;
+   if (cap_auto_ && (model_calls <= 4 || model_calls % 4 == 0)) {   // tail split: next cap from the evaluation counts of this launch (the distribution drifts slowly)
+      int h[64]; abi_check(ctx_, exa_model_nfev_hist(ctx_, matVars1.p, h, stream_), "exa_model_nfev_hist");
+      newton_cap_ = choose_newton_cap(h);
+      abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");
+   }
 }
 template void NonlinearMechOperator::Setup<true>(const double*);
 template void NonlinearMechOperator::Setup<false>(const double*);

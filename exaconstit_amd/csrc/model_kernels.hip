@@ -26,13 +26,19 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
                                                      const double* __restrict__ vel, const double* __restrict__ xl, const int32_t* __restrict__ conn, const int nnodes,
                                                      const double* __restrict__ stress0,
                                                      const double* __restrict__ state0, double* __restrict__ stress1,
-                                                     double* __restrict__ state1, double* __restrict__ cmat, int* __restrict__ fail) {
+                                                     double* __restrict__ state1, double* __restrict__ cmat, int* __restrict__ fail,
+                                                     const int kcap, int* __restrict__ tail, const int tail_mode) {
    const int n = NFIX ? NFIX : n_rt;
    extern __shared__ double sG[];   // (n,3,Q)
    for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
    __syncthreads();
    int q; int64_t e;
-   if (QB) {   // wave = (block of 64 elements, q); lane = element
+   if (tail_mode) {   // dense pass over the points the capped launch handed over: thread t owns point tail[1 + t]
+      const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      if (t >= tail[0]) return;
+      const int64_t ipt = tail[1 + t];
+      q = (int)(ipt % Q); e = ipt / Q;
+   } else if (QB) {   // wave = (block of 64 elements, q); lane = element
       const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
       q = (int)(gw % Q); e = (gw / Q) * 64 + (threadIdx.x & 63);
       if (e * Q >= P) return;
@@ -90,8 +96,9 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    }
    // per-thread stash behind the shape table in LDS: slot s of this thread at stash[s * 256 + threadIdx.x]
    double* st = sG + n * 3 * Q + threadIdx.x;
-   const int rc = point_update<KIN, QS>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, cmat + vC.base, st);
-   if (rc) atomicAdd(fail, 1);
+   const int rc = point_update<KIN, QS>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, cmat + vC.base, st, kcap);
+   if (rc == 2) { const int slot = atomicAdd(&tail[0], 1); tail[1 + slot] = (int)(e * Q + q); }
+   else if (rc) atomicAdd(fail, 1);
 }
 
 template <bool QB>
@@ -129,6 +136,30 @@ __global__ void k_calc_dp(const double qsign, const int Q, const int64_t P, cons
    o[0] = t00; o[ds] = t01; o[2 * ds] = t02; o[3 * ds] = t01; o[4 * ds] = t11; o[5 * ds] = t12; o[6 * ds] = t02; o[7 * ds] = t12; o[8 * ds] = t22;
 }
 
+// histogram of the local-solver evaluation counts (state slot 3) of a state array: input of the tail-split controller
+template <bool QB>
+__global__ void k_nfev_hist(const int Q, const int64_t P, const double* __restrict__ state, int* __restrict__ hist /*64*/) {
+   __shared__ int sh[64];
+   if (threadIdx.x < 64) sh[threadIdx.x] = 0;
+   __syncthreads();
+   for (int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ip < P; ip += (int64_t)gridDim.x * blockDim.x) {
+      const QView v = qview<QB>(NSTATEV, Q, ip / Q, (int)(ip % Q));
+      const double nf = state[v.base + (int64_t)H_NFEV * v.stride];
+      const int b = nf < 0.0 ? 0 : (nf > 63.0 ? 63 : (int)nf);
+      atomicAdd(&sh[b], 1);
+   }
+   __syncthreads();
+   if (threadIdx.x < 64 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+int exa_launch_nfev_hist(exa_ctx* ctx, const double* state, int* hist_dev, hipStream_t s) {
+   EXA_HIP_CHECK(ctx, hipMemsetAsync(hist_dev, 0, sizeof(int) * 64, s));
+   if (ctx->qblk) hipLaunchKernelGGL(k_nfev_hist<true>, dim3(1024), dim3(256), 0, s, ctx->Q, ctx->P, state, hist_dev);
+   else hipLaunchKernelGGL(k_nfev_hist<false>, dim3(1024), dim3(256), 0, s, ctx->Q, ctx->P, state, hist_dev);
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   return EXA_OK;
+}
+
 template <int KIN, bool LVEC, int NFIX, bool QB>
 static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
                          double* stress1, double* state1, double* cmat, hipStream_t s) {
@@ -137,8 +168,14 @@ static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel
    const int64_t nb = QB ? (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64) : (ctx->P + bs - 1) / bs;
    const size_t lds = sizeof(double) * ((size_t)ctx->n * 3 * ctx->Q + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE);
    static_assert(ECM_STASH_STRIDE == 256, "stash stride must equal the block size");
+   const bool split = ctx->newton_cap > 0 && ctx->tail_dev != nullptr;
    hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
-                      ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev);
+                      ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, split ? ctx->newton_cap : (1 << 30), ctx->tail_dev, 0);
+   if (split) {   // same kernel, thread = listed point, uncapped.  The grid covers the worst case; blocks beyond the list exit at once.
+      const int64_t nbt = (ctx->P + bs - 1) / bs;
+      hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nbt), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+                         ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, 1 << 30, ctx->tail_dev, 1);
+   }
 }
 
 template <int KIN, bool LVEC, int NFIX>
@@ -159,6 +196,10 @@ static void launch_model(exa_ctx* ctx, double dt, double* J, const double* vel, 
 int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
                            double* stress1, double* state1, double* cmat, hipStream_t s) {
    EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->fail_count_dev, 0, sizeof(int), s));
+   if (ctx->newton_cap > 0) {
+      if (!ctx->tail_dev) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tail_dev, sizeof(int) * ((size_t)ctx->P + 1)));
+      EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->tail_dev, 0, sizeof(int), s));
+   }
    const bool lv = xl != nullptr;
    switch (ctx->mp.kin) {
       case KIN_VOCE:

@@ -57,6 +57,9 @@ EXA_QLAYOUT_AOS, EXA_QLAYOUT_EB64 = 0, 1
 exa_init_state = _sig("exa_init_state", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_model_setup = _sig("exa_model_setup", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_setup_lvec = _sig("exa_model_setup_lvec", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
+exa_set_newton_cap = _sig("exa_set_newton_cap", C.c_int, C.c_void_p, C.c_int)
+exa_model_tail_count = _sig("exa_model_tail_count", C.c_int, C.c_void_p, C.c_void_p)
+exa_model_nfev_hist = _sig("exa_model_nfev_hist", C.c_int, C.c_void_p, dptr, C.POINTER(C.c_int), C.c_void_p)
 exa_model_status = _sig("exa_model_status", C.c_int, C.c_void_p, C.c_void_p)
 exa_calc_dp = _sig("exa_calc_dp", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_jacobians = _sig("exa_jacobians", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)

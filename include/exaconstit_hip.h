@@ -88,6 +88,16 @@ int exa_model_setup(exa_ctx* ctx, double dt, const double* jacobian_dev /*(3,3,Q
 int exa_model_setup_lvec(exa_ctx* ctx, double dt, const double* coords_lvec_dev /*(nnodes,3) byNODES*/, const double* vel_lvec_dev,
                          const double* stress0_dev, const double* state0_dev,
                          double* stress1_dev, double* state1_dev, double* ddsdde_dev, double* jacobian_out_dev, exa_stream s);
+/* Tail split of the constitutive launch (0 = off, the default).  The local Newton solve needs 3-6 evaluations at most points and
+ * 10-19 at a few per cent of them, and a wave waits for its slowest lane (measured wave max / mean = 1.2 ... 2.7).  With max_evals = K
+ * the launch stops a point after K residual evaluations and a second, dense launch of the same kernel redoes exactly those points from
+ * scratch without a cap, so every output - the evaluation count in state slot 3 included - is the one of the uncapped solve.
+ * exa_model_tail_count (synchronises) returns how many points the last launch handed over. */
+int exa_set_newton_cap(exa_ctx* ctx, int max_evals);
+int exa_model_tail_count(exa_ctx* ctx, exa_stream s);
+/* histogram (64 bins, last bin = 63 and more) of the evaluation counts stored in slot 3 of a state array; synchronises.  The driver
+ * picks max_evals from it (host/driver.hip, choose_newton_cap). */
+int exa_model_nfev_hist(exa_ctx* ctx, const double* state_dev, int* hist64_host, exa_stream s);
 /* synchronises the stream; returns the number of non-converged points of the last exa_model_setup (>= 0) */
 int exa_model_status(exa_ctx* ctx, exa_stream s);
 

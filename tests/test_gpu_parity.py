@@ -396,3 +396,41 @@ def test_element_blocked_layout_matches_aos(oracle, model, pkey):
     p2 = L.Context(0, _props(orc, "voce"), 298.0, 2, 8)
     assert L.exa_set_quadrature_layout(p2.h, L.EXA_QLAYOUT_EB64) == -4
     p2.close()
+
+
+@pytest.mark.parametrize("model,pkey,cap", [(0, "voce", 4), (5, "mts", 3), (4, "mts", 5)])
+def test_tail_split_is_bitwise_neutral(oracle, model, pkey, cap):
+    """exa_set_newton_cap: points cut off after K evaluations are redone from scratch by the dense tail launch, so stress, state
+    (evaluation count in slot 3 included), tangent and Jacobians are bit-for-bit those of the uncapped launch, in both layouts."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 6, distort=0.15)
+    E, Q, NN = rve["E"], rve["Q"], rve["NN"]
+    props = _props(orc, pkey)
+    quats = hipref.random_quats(E)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    v_nodes = hipref.velocity_field(rve, scale=2.0)
+    for layout in (L.EXA_QLAYOUT_AOS, L.EXA_QLAYOUT_EB64):
+        outs = []
+        for k in (0, cap):
+            ctx = L.Context(model, props, 298.0, 1, E)
+            ctx.check(L.exa_set_quadrature_layout(ctx.h, layout)); ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+            ctx.check(L.exa_set_newton_cap(ctx.h, k))
+            sz = lambda w: int(L.exa_qf_size(ctx.h, w))
+            sv = [dev.zeros(sz(28)), dev.zeros(sz(28))]; sg = [dev.zeros(sz(6)), dev.zeros(sz(6))]; cm = dev.zeros(sz(36)); J = dev.zeros(sz(9))
+            ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(dev.up(quats.ravel())), None))
+            d_x = dev.up(rve["X"]); d_v = dev.up(v_nodes)
+            tails = []
+            for dt in (0.1, 0.3, 0.5, 0.5):
+                d_x += dt * d_v
+                ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(sg[0]), ptr(sv[0]), ptr(sg[1]), ptr(sv[1]), ptr(cm), ptr(J), None))
+                assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+                tails.append(L.exa_model_tail_count(ctx.h, None))
+                sv.reverse(); sg.reverse()
+            outs.append((sv[0].clone(), sg[0].clone(), cm.clone(), J.clone(), tails))
+            ctx.close()
+        assert sum(outs[0][4]) == 0 and max(outs[1][4]) > 0, outs[1][4]          # the capped run really used the tail launch
+        for a, b in zip(outs[0][:4], outs[1][:4]):
+            assert torch.equal(a, b)
