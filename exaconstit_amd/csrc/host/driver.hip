@@ -253,7 +253,7 @@ void NonlinearMechOperator::UpdateEssTDofs(const std::vector<uint8_t>& mask) { e
 // Kocks-Mecking kernel; 0.2 = the second launch's fixed cost.  Measured at 128^3: BCC KM-DD 31.6 -> 16.0 ms, FCC KM-DD 70.9 -> 55.9 ms,
 // Voce stays uncapped (6.9 ms; K = 5 would cost 10.2 ms, which the model reproduces).
 // Returns the K minimising C, or 0 (off) when it does not beat the uncapped launch by 3 %.
-int NonlinearMechOperator::choose_newton_cap(const int* hist) {
+int choose_newton_cap(const int* hist, double tail_cost_) {
    double tot = 0; for (int i = 0; i < 64; i++) tot += hist[i];
    if (tot <= 0) return 0;
    auto emax = [&](int lo, int hi, double n) {   // E[max of 64 draws] of the histogram restricted to bins lo..hi (n = its population)
@@ -294,7 +294,7 @@ void NonlinearMechOperator::Setup(const double* k) {
    timers.t_model_ms += ms; timers.qpt_updates += (int64_t)E_ * npe_; model_calls++;
    if (cap_auto_ && (model_calls <= 4 || model_calls % 4 == 0)) {   // tail split: next cap from the evaluation counts of this launch (the distribution drifts slowly)
       int h[64]; abi_check(ctx_, exa_model_nfev_hist(ctx_, matVars1.p, h, stream_), "exa_model_nfev_hist");
-      newton_cap_ = choose_newton_cap(h);
+      newton_cap_ = choose_newton_cap(h, tail_cost_);
       abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");
    }
 }

@@ -73,6 +73,9 @@ class ExaCMechModel {
    DevBuf<double>*stress0_, *stress1_, *matGrad_, *matVars0_, *matVars1_;
 };
 
+// tail-split controller (see driver.hip): cap on local-solver evaluations from a 64-bin histogram of their counts; 0 = no cap
+int choose_newton_cap(const int* hist64, double tail_cost);
+
 class NonlinearMechOperator {
  public:
    NonlinearMechOperator(const ExaOptions& opt, const Partition& part, Comm& comm, const std::vector<double>& props, const std::vector<double>& quats_per_elem);
@@ -114,7 +117,6 @@ class NonlinearMechOperator {
    int nn_, nd_, E_, npe_ = 8; double dt_ = 1.0;
    bool fast_p1_ = true, lvec_grad_ = true, fused_setup_ = true;
    bool cap_auto_ = true; int newton_cap_ = 0; double tail_cost_ = 4.0;
-   int choose_newton_cap(const int* hist64);
    DevBuf<double> tmp_l_, tmp_r_, el_y_, el_x2_;
 };
 

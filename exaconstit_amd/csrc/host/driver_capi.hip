@@ -175,6 +175,8 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out, char* err, int e
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }
 
+int exa_choose_newton_cap(const int* hist64, double tail_cost) { return choose_newton_cap(hist64, tail_cost); }
+
 int exa_options_query(const char* toml_path, double* out, char* err, int errlen) {
    try {
       ExaOptions o; o.parse_options(toml_path);

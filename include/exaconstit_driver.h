@@ -55,6 +55,10 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out3, char* err, int 
  * {temp_k, nprops, num_grains, xtal, slip, dt_cust, dt_auto, nsteps, assembly(0 PA,1 EA), nl_solver(0 NR,1 NRLS), newton_iter, newton_rel,
  *  newton_abs, krylov_iter, krylov_rel, krylov_abs, ref_ser, ncuts0, additional_avgs, number of BC change steps}; returns 0 or -1 (err) */
 int exa_options_query(const char* toml_path, double* out20, char* err, int errlen);
+/* the driver's tail-split controller as a pure function (host logic; tests): cap on local-solver evaluations chosen from a 64-bin
+ * histogram of evaluation counts, 0 = leave the launch uncapped.  tail_cost = relative cost of a point in the second launch. */
+int exa_choose_newton_cap(const int* hist64, double tail_cost);
+
 /* block decomposition of an N0 x N1 x N2 element grid (reference: ParMesh/METIS, src/mechanics_driver.cpp:312): sizes first
  * (info[0..7] = {E, NN, nneighbors, pg0, pg1, pg2, total shared dofs, n}; info[7] is in/out: H1 order p on input (0 or 1 -> 1, 2 -> 2),
  * nodes per element n = (p+1)^3 on output), then the arrays when the pointers are non-null:

@@ -92,3 +92,19 @@ def test_block_decomposition_is_a_partition(nranks, order):
             g2 = pu.global_node_ids(q, N)
             found = any([(g2[d % q["NN"]], d // q["NN"]) for d in b] == mine for b in back)
             assert found, (r, r2)
+
+
+def test_tail_split_controller():
+    """Histograms measured on the 24^3 RVE (scripts/nfev_hist.py): the controller leaves the narrow Voce distribution uncapped, cuts the
+    BCC Kocks-Mecking launch at 4 evaluations (1.3 % of the points carry counts of 5-13) and the broad FCC one at 6."""
+    import exaconstit_amd.lib as L
+
+    def cap(counts, w):
+        h = (C.c_int * 64)(*([0] * 64))
+        for n, c in counts.items():
+            h[n] = c
+        return L.exa_choose_newton_cap(h, w)
+    assert cap({5: 97598, 6: 12531, 7: 463}, 4.0) == 0
+    assert cap({3: 87029, 4: 21603, 5: 404, 6: 191, 7: 196, 8: 42, 9: 1, 10: 8, 11: 160, 12: 197, 13: 222}, 1.5) == 4
+    assert cap({3: 36464, 4: 29018, 5: 16278, 6: 8254, 7: 2499, 8: 1509, 9: 2919, 10: 4377, 11: 4438, 12: 2875, 13: 1529}, 1.5) == 6
+    assert cap({}, 1.5) == 0 and cap({4: 1000}, 1.5) == 0
