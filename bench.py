@@ -161,7 +161,7 @@ def main():
     barrier(); t_el = max_over_ranks(time.perf_counter() - t0)
     elastic = {"value": 8 * N ** 3 * max(1, args.steps // 2) / t_el, "unit": "qpt-updates/s", "avg_kernel_ms": max_over_ranks(me["kernel_ms"]) / max(1, args.steps // 2),
                "regime": "elastic (step 1 of the schedule, dt = 0.005, virgin state)"}
-    drv.bench_prepare(PREP_DTS)
+    t0 = time.perf_counter(); drv.bench_prepare(PREP_DTS); barrier(); prep_s = time.perf_counter() - t0
     P_local = L.exa_driver_local_qpts(drv.h)
     P_global = 8 * N ** 3
     # ---- timed region 1: constitutive passes -------------------------------------------------------------------------
@@ -231,6 +231,7 @@ def main():
                        "qpts": P_global, "decomposition": f"{world} block(s)"},
             "pcg_iters_per_s": pcg_it_s, "pcg_iters": pc["iters"], "pcg_ms_per_iter": pcg_ms / max(pc["iters"], 1),
             "pcg_wall_s": t_pcg_wall, "nonconverged_points": m["failed"], "elastic_regime": elastic,
+            "prepare_passes": {"passes": len(PREP_DTS), "wall_s": prep_s, "note": "the 10 kinematic passes through the elastic-plastic transition that bring the RVE to the benchmark state"},
             "roofline": {"kernel": f"k_model_setup<{'KM-DD' if 'kmdd' in args.model else 'Voce'}> (fused node gather + grad_calc + ExaCMech update + tangent)", "bound": "hbm",
                          "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS,
                          "traffic": traffic["k_model_setup"] * P_local if "k_model_setup" in traffic else None, "traffic_source": traffic.get("_file"),

@@ -221,7 +221,13 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    lvec_grad_ = fast_p1_ || opt.assembly == Assembly::EA;
    fused_setup_ = std::getenv("EXA_UNFUSED_SETUP") == nullptr;
    // tail split of the constitutive launch (include/exaconstit_hip.h): EXA_NEWTON_CAP=off | <K> | unset (chosen from the evaluation-count histogram of the previous launch)
-   if (const char* nc = std::getenv("EXA_NEWTON_CAP")) { cap_auto_ = false; newton_cap_ = (std::string(nc) == "off") ? 0 : std::atoi(nc); }
+   // The controller runs for the Kocks-Mecking family only: for the Voce kernels the model never finds a paying cap in steady state and
+   // a stale histogram costs 20 % in the elastic-plastic transition passes (measured).  EXA_NEWTON_CAP=auto forces it on.
+   cap_auto_ = (opt.slip == SlipType::MTSDD);
+   if (const char* nc = std::getenv("EXA_NEWTON_CAP")) {
+      if (std::string(nc) == "auto") cap_auto_ = true;
+      else { cap_auto_ = false; newton_cap_ = (std::string(nc) == "off") ? 0 : std::atoi(nc); }
+   }
    tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.5 : 4.0;
    abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 path (EXA_QLAYOUT=aos switches back for A/B runs)
