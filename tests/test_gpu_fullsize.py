@@ -37,7 +37,8 @@ def test_full_size_properties(oracle, N):
     d_sv = [dev.zeros(28 * P), dev.zeros(28 * P)]
     d_s = [dev.zeros(6 * P), dev.zeros(6 * P)]
     d_cm = dev.zeros(36 * P); d_J = dev.zeros(9 * P)
-    ctx.check(L.exa_init_state(ctx.h, ptr(d_sv[0]), ptr(dev.up(quats.ravel())), None))
+    d_quats_keep = dev.up(quats.ravel())   # must outlive the asynchronous launch
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_sv[0]), ptr(d_quats_keep), None))
     v_nodes = hipref.velocity_field(rve)
     d_v = dev.up(v_nodes); d_x = dev.up(rve["X"])
     dts = [0.005, 0.195, 0.4, 0.4]                      # 0.1 % strain: plastic
@@ -124,7 +125,8 @@ def test_full_size_order2_bbar_element_assembly(oracle):
     ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
     d_sv = [dev.zeros(28 * P), dev.zeros(28 * P)]; d_s = [dev.zeros(6 * P), dev.zeros(6 * P)]
     d_cm = dev.zeros(36 * P); d_J = dev.zeros(9 * P)
-    ctx.check(L.exa_init_state(ctx.h, ptr(d_sv[0]), ptr(dev.up(hipref.random_quats(E).ravel())), None))
+    d_quats_keep = dev.up(hipref.random_quats(E).ravel())   # must outlive the asynchronous launch
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_sv[0]), ptr(d_quats_keep), None))
     v_nodes = hipref.velocity_field(rve)
     d_v = dev.up(v_nodes); d_x = dev.up(rve["X"])
     dts = [0.2, 0.4, 0.4]

@@ -308,7 +308,8 @@ def test_model_setup_p2_matches_oracle(oracle):
     ctx = L.Context(L.EXA_FCC_VOCE, props, 298.0, 2, E)
     quats = hipref.random_quats(E)
     d_state0 = dev.zeros(28 * P)
-    ctx.check(L.exa_init_state(ctx.h, ptr(d_state0), ptr(dev.up(quats.ravel())), None))
+    d_quats_keep = dev.up(quats.ravel())   # must outlive the asynchronous launch
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_state0), ptr(d_quats_keep), None))
     sv0 = d_state0.cpu().numpy().copy(); s0 = np.zeros(6 * P)
     v = hipref.velocity_field(rve, scale=2.0); vel_e = hipref.l_to_e(rve, v); x = rve["X"].copy()
     for dt in (0.2, 0.3, 0.5):
@@ -361,7 +362,8 @@ def test_element_blocked_layout_matches_aos(oracle, model, pkey):
             aos = (lambda t, w: t.view(-1, w)[:P]) if layout == L.EXA_QLAYOUT_AOS else (lambda t, w: _eb64_to_aos(t, E, Q, w))
             sv = [dev.zeros(sz(28)), dev.zeros(sz(28))]; sg = [dev.zeros(sz(6)), dev.zeros(sz(6))]
             cm = dev.zeros(sz(36)); J = dev.zeros(sz(9)); J2 = dev.zeros(sz(9)); F = dev.zeros(sz(9)); dp = dev.zeros(sz(9))
-            ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(dev.up(quats.ravel())), None))
+            d_quats_keep = dev.up(quats.ravel())   # must outlive the asynchronous launch
+            ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(d_quats_keep), None))
             d_x = dev.up(rve["X"]); d_v = dev.up(v_nodes)
             for dt in (0.1, 0.3, 0.5):
                 d_x += dt * d_v
@@ -420,7 +422,8 @@ def test_tail_split_is_bitwise_neutral(oracle, model, pkey, cap):
             ctx.check(L.exa_set_newton_cap(ctx.h, k))
             sz = lambda w: int(L.exa_qf_size(ctx.h, w))
             sv = [dev.zeros(sz(28)), dev.zeros(sz(28))]; sg = [dev.zeros(sz(6)), dev.zeros(sz(6))]; cm = dev.zeros(sz(36)); J = dev.zeros(sz(9))
-            ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(dev.up(quats.ravel())), None))
+            d_quats_keep = dev.up(quats.ravel())   # must outlive the asynchronous launch
+            ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(d_quats_keep), None))
             d_x = dev.up(rve["X"]); d_v = dev.up(v_nodes)
             tails = []
             for dt in (0.1, 0.3, 0.5, 0.5):
@@ -434,3 +437,41 @@ def test_tail_split_is_bitwise_neutral(oracle, model, pkey, cap):
         assert sum(outs[0][4]) == 0 and max(outs[1][4]) > 0, outs[1][4]          # the capped run really used the tail launch
         for a, b in zip(outs[0][:4], outs[1][:4]):
             assert torch.equal(a, b)
+
+
+def test_abi_error_behaviour(oracle):
+    """Error paths of the C ABI on a live context: null pointers, calls in the wrong order, unsupported combinations, a one-element mesh.
+    Every entry returns a negative code and leaves a message; nothing aborts (the reference MFEM_ABORTs, src/mechanics_integrators.cpp:178)."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    props = _props(orc, "voce")
+    err = C.c_int(0)
+    for bad in (dict(nelems=0), dict(order=4), dict(integ=7), dict(integ=1, assembly=0)):
+        kw = dict(model=0, nelems=8, order=1, assembly=0, integ=0); kw.update(bad)
+        cfg = L.ExaConfig(kw["model"], len(props), props.ctypes.data_as(C.POINTER(C.c_double)), 298.0, kw["order"], kw["nelems"], kw["assembly"], kw["integ"], -1)
+        assert not L.exa_create(C.byref(cfg), C.byref(err)) and err.value < 0, bad
+    rve = hipref.make_rve(orc, 1)                               # a single element: 8 points, every block partial
+    ctx = L.Context(0, props, 298.0, 1, 1)
+    z = dev.zeros(64 * 36)
+    assert L.exa_model_setup(ctx.h, 0.1, None, ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), None) == -1
+    assert L.exa_model_setup(ctx.h, -1.0, ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), None) == -1
+    assert b"dt" in L.exa_last_error(ctx.h)
+    assert L.exa_grad_apply(ctx.h, ptr(z), ptr(z), None) == -3                     # before exa_grad_setup
+    assert L.exa_residual_apply(ctx.h, ptr(z), None) == -3
+    assert L.exa_residual_lvec(ctx.h, ptr(z), ptr(z), ptr(z), None) == -3          # connectivity not set
+    assert L.exa_set_newton_cap(ctx.h, 1) == -1 and L.exa_set_quadrature_layout(ctx.h, 5) == -1
+    # the one-element problem runs end to end and matches the oracle
+    quats = hipref.random_quats(1)
+    sv0 = dev.zeros(28 * 8); d_q = dev.up(quats.ravel()); ctx.check(L.exa_init_state(ctx.h, ptr(sv0), ptr(d_q), None))
+    v = hipref.velocity_field(rve, scale=0.5); x = rve["X"] + v
+    xe = hipref.l_to_e(rve, x); ve = hipref.l_to_e(rve, v)
+    J = np.zeros(72); orc.lib().orc_jacobians(1, 1, orc._p(xe), orc._p(J))
+    nf, s1, sv1, cm, _ = _orc_model_setup(orc, 0, 0, props, rve, 1.0, J, ve, np.zeros(48), sv0.cpu().numpy())
+    o = [dev.zeros(48), dev.zeros(224), dev.zeros(288)]
+    d_J, d_ve, d_s0 = dev.up(J), dev.up(ve), dev.zeros(48)          # keep the tensors alive across the call
+    ctx.check(L.exa_model_setup(ctx.h, 1.0, ptr(d_J), ptr(d_ve), ptr(d_s0), ptr(sv0), ptr(o[0]), ptr(o[1]), ptr(o[2]), None))
+    assert ctx.check(L.exa_model_status(ctx.h, None)) == 0 and nf == 0
+    assert rel_l2(o[0].cpu().numpy(), s1) < 1e-9 and rel_l2(o[2].cpu().numpy(), cm) < 1e-7
+    ctx.close()
