@@ -37,6 +37,7 @@ CASES = [
     ("fcc_voce", 0, 0, "voce", 0),      # (name, oracle xtal, oracle kin, props, lib model id)
     ("bcc_voce", 1, 0, "voce", 2),
     ("fcc_voce_nl", 0, 1, "vocenl", 1),
+    ("bcc_voce_nl", 1, 1, "vocenl", 3),
     ("fcc_kmdd", 0, 2, "mts", 4),
     ("bcc_kmdd", 1, 2, "mts", 5),
 ]
