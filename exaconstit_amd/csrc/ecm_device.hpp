@@ -33,10 +33,8 @@ constexpr double E_SCALE = 5.0e-4, R_SCALE = 0.01;
 constexpr int H_SHRATE = 0, H_SHR = 1, H_FLOW = 2, H_NFEV = 3, H_E = 4, H_Q = 9, H_H = 13, H_GDOT = 14;
 constexpr int NUM_HIST = 26, NSTATEV = 28, IND_VOL = 26, IND_EINT = 27;
 
-// KIN_KMBALD_B: the same Kocks-Mecking kinetics evaluated two slip systems at a time, branch-free (template choice of the launcher:
-// pays when every system is above its threshold, i.e. the FCC variant whose threshold is the small constant tau_a)
-enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2, KIN_KMBALD_B = 3 };
-constexpr bool kin_is_km(int k) { return k == KIN_KMBALD || k == KIN_KMBALD_B; }
+enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2 };
+constexpr bool kin_is_km(int k) { return k == KIN_KMBALD; }
 
 // Schmid tensors of the 12 FCC {111}<110> systems: P = vecd(sym(s x m)), Q = axial(skew(s x m)).
 // a = sqrt(3)/6, b = sqrt(6)/12.
@@ -266,41 +264,12 @@ ECM_DI void mts_dG(const MatParams& mp, double c_e, double t_frac, double& exp_a
    exp_arg = -c_e * q_func; dfac = c_e * dq_func * dp_func;
 }
 
-ECM_DI void kmbald_gdot(const MatParams& mp, const KinVals& kv, double tau, double& gdot, double& dg) {
-   gdot = 0.0; dg = 0.0;
-   if (tau == 0.0) return;
-   const double g_i = mp.with_g_athermal ? 1.0 / mp.tau_a : 1.0 / kv.g;
-   const double gAth = mp.with_g_athermal ? kv.g : mp.tau_a;
-   const double at = fabs(tau);
-   const double at_0 = fmax(0.0, at - gAth) * g_i;
-   const double exp_arg_r = (at - gAth) / mp.wrD;
-   if (exp_arg_r <= 0.0) return;
-   double gdot_r, dgdot_r;
-   if (exp_arg_r < EPS_SQRT) { gdot_r = kv.gam_r * exp_arg_r; dgdot_r = kv.gam_r / mp.wrD; }
-   else { const double ex = exp(-exp_arg_r); gdot_r = kv.gam_r * (1.0 - ex); dgdot_r = kv.gam_r * ex / mp.wrD; }
-   if (at_0 > mp.t_max) { gdot = copysign(gdot_r, tau); dg = dgdot_r; return; }
-   double ea_f, df_f, ea_b, df_b;
-   mts_dG(mp, kv.c_e, (at - gAth) * g_i, ea_f, df_f);
-   if (ea_f < LN_GAM_RATIO_MIN) return;
-   mts_dG(mp, kv.c_e, (-at - gAth) * g_i, ea_b, df_b);
-   const double ef = exp(ea_f), eb = exp(ea_b);
-   double gdot_w = kv.gam_w * (ef - eb);
-   double dgdot_w = kv.gam_w * (ef * df_f + eb * df_b) * g_i;
-   if (at_0 > mp.t_min) {
-      const double temp = (kv.gam_w * 10.0) * pow_xn(mp, at_0);
-      gdot_w += temp * at_0; dgdot_w += temp * mp.xnn * g_i;
-   }
-   if (gdot_w <= 0.0) return;
-   const double gd = 1.0 / (1.0 / gdot_w + 1.0 / gdot_r);
-   dg = gd * gd * (dgdot_w / (gdot_w * gdot_w) + dgdot_r / (gdot_r * gdot_r));
-   gdot = copysign(gd, tau);
-}
-
-// The same kinetics for KW slip systems at once, branch-free (selects), so that the exp / log chains of the systems are independent
-// instruction streams the FP64 pipeline can overlap (the scalar form leaves it half idle at two waves per SIMD).  Every early return
-// of the scalar form becomes a term of `valid`; arithmetic on discarded lanes may produce inf / NaN, which the selects drop.
-// Measured at 128^3 (FCC, every system active): 72 -> 55 ms; with the athermal-threshold (BCC) variant most systems of a wave are dormant
-// or saturated and the scalar form's early returns win (34 vs 44 ms), hence the template choice.
+// Kocks-Mecking balanced kinetics (thermally activated forward - backward slip with a power-law tail, in series with a drag-limited
+// branch) for KW slip systems at once: the exp / log chains of the systems are independent instruction streams the FP64 pipeline can
+// overlap (one system at a time leaves it half idle at two waves per SIMD).  The early returns of a one-system formulation - dormant
+// below the athermal threshold, drag-limited beyond t_max, forward exponent below ln(1e-60), power-law tail only above t_min - are kept
+// as nested lane conditions, so a wave still skips every phase none of its lanes needs (with the athermal-threshold BCC variant most
+// systems of a wave are dormant or saturated).  Measured at 128^3 against the one-system form: FCC 72 -> 55 ms, BCC 16.2 -> 14.3 ms.
 #ifndef ECM_KW
 #define ECM_KW 2
 #endif
@@ -310,72 +279,81 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
    const double g_i = mp.with_g_athermal ? 1.0 / mp.tau_a : 1.0 / kv.g;
    const double gAth = mp.with_g_athermal ? kv.g : mp.tau_a;
    const double wi = 1.0 / mp.wrD;
-   double at[KW], xr[KW], ex[KW];
-#pragma unroll
-   for (int a = 0; a < KW; a++) { at[a] = fabs(tau[a]); xr[a] = (at[a] - gAth) * wi; }
-#pragma unroll
-   for (int a = 0; a < KW; a++) ex[a] = exp(-fmax(xr[a], 0.0));
-   double gr[KW], dgr[KW];
+   double at[KW], xr[KW], at0[KW];
+   bool live[KW], over[KW], any_live = false;
 #pragma unroll
    for (int a = 0; a < KW; a++) {
-      const bool small = xr[a] < EPS_SQRT;
-      gr[a] = small ? kv.gam_r * xr[a] : kv.gam_r * (1.0 - ex[a]);
-      dgr[a] = (small ? kv.gam_r : kv.gam_r * ex[a]) * wi;
+      at[a] = fabs(tau[a]); xr[a] = (at[a] - gAth) * wi; at0[a] = fmax(0.0, at[a] - gAth) * g_i;
+      live[a] = (tau[a] != 0.0) && (xr[a] > 0.0); over[a] = at0[a] > mp.t_max;
+      any_live = any_live || live[a];
+      gdot[a] = 0.0; if (WITHD) dg[a] = 0.0;
    }
-   // thermally activated forward / backward terms: exp_arg = -c_e q_func(1 - p_func(t))  (mts_dG), p == 1 and q == 1 are uniform cases
-   double eaf[KW], dff[KW], eab[KW], dfb[KW];
+   // the nested ifs are lane conditions: a wave skips a phase when none of its lanes needs it, like the early returns of the scalar form
+   if (any_live) {
+      double ex[KW], gr[KW], dgr[KW];
 #pragma unroll
-   for (int a = 0; a < KW; a++) {
-      mts_dG(mp, kv.c_e, (at[a] - gAth) * g_i, eaf[a], dff[a]);
-      mts_dG(mp, kv.c_e, (-at[a] - gAth) * g_i, eab[a], dfb[a]);
-   }
-   double ef[KW], eb[KW];
+      for (int a = 0; a < KW; a++) ex[a] = exp(-fmax(xr[a], 0.0));
 #pragma unroll
-   for (int a = 0; a < KW; a++) ef[a] = exp(eaf[a]);
-#pragma unroll
-   for (int a = 0; a < KW; a++) eb[a] = exp(eab[a]);
-   double at0[KW], pw[KW];
-   double a0max = 0.0;
-#pragma unroll
-   for (int a = 0; a < KW; a++) { at0[a] = fmax(0.0, at[a] - gAth) * g_i; a0max = fmax(a0max, at0[a]); pw[a] = 0.0; }
-   if (a0max > mp.t_min) {   // power-law tail: only above t_min = (1e-60)^m (rare for large 1/m), skipped when no lane needs it
-      if (mp.xn_int > 0) {
-         double b[KW];
-#pragma unroll
-         for (int a = 0; a < KW; a++) { pw[a] = 1.0; b[a] = at0[a]; }
-         for (int e = mp.xn_int;;) {
-            if (e & 1) {
-#pragma unroll
-               for (int a = 0; a < KW; a++) pw[a] *= b[a];
-            }
-            e >>= 1;
-            if (!e) break;
-#pragma unroll
-            for (int a = 0; a < KW; a++) b[a] *= b[a];
-         }
-      } else {
-#pragma unroll
-         for (int a = 0; a < KW; a++) pw[a] = exp(mp.xn * log(fmax(at0[a], 1.0e-300)));
+      for (int a = 0; a < KW; a++) {
+         const bool small = xr[a] < EPS_SQRT;
+         gr[a] = small ? kv.gam_r * xr[a] : kv.gam_r * (1.0 - ex[a]);
+         dgr[a] = (small ? kv.gam_r : kv.gam_r * ex[a]) * wi;
+         if (live[a] && over[a]) { gdot[a] = copysign(gr[a], tau[a]); if (WITHD) dg[a] = dgr[a]; }   // drag-limited beyond t_max
       }
-   }
+      // thermally activated forward / backward terms: exp_arg = -c_e q_func(1 - p_func(t))  (mts_dG), p == 1 and q == 1 are uniform cases
+      double eaf[KW], dff[KW];
+      bool inwin[KW], any_win = false, any_tail = false;
 #pragma unroll
-   for (int a = 0; a < KW; a++) {
-      double gw = kv.gam_w * (ef[a] - eb[a]);
-      double dgw = kv.gam_w * (ef[a] * dff[a] + eb[a] * dfb[a]) * g_i;
-      const bool tail = at0[a] > mp.t_min;
-      const double temp = (kv.gam_w * 10.0) * pw[a];
-      gw += tail ? temp * at0[a] : 0.0;
-      dgw += tail ? temp * mp.xnn * g_i : 0.0;
-      const bool live = (tau[a] != 0.0) && (xr[a] > 0.0);
-      const bool over = at0[a] > mp.t_max;
-      const bool valid = live && !over && !(eaf[a] < LN_GAM_RATIO_MIN) && (gw > 0.0);
-      const double r1 = 1.0 / gw, r2 = 1.0 / gr[a];
-      const double gd = 1.0 / (r1 + r2);
-      double g = valid ? gd : 0.0;
-      double d = valid ? gd * gd * (dgw * r1 * r1 + dgr[a] * r2 * r2) : 0.0;
-      if (live && over) { g = gr[a]; d = dgr[a]; }
-      gdot[a] = copysign(g, tau[a]);
-      if (WITHD) dg[a] = d;
+      for (int a = 0; a < KW; a++) {
+         mts_dG(mp, kv.c_e, (at[a] - gAth) * g_i, eaf[a], dff[a]);
+         inwin[a] = live[a] && !over[a] && !(eaf[a] < LN_GAM_RATIO_MIN);
+         any_win = any_win || inwin[a];
+         any_tail = any_tail || (inwin[a] && at0[a] > mp.t_min);
+      }
+      if (any_win) {
+         double eab[KW], dfb[KW], ef[KW], eb[KW], pw[KW];
+#pragma unroll
+         for (int a = 0; a < KW; a++) mts_dG(mp, kv.c_e, (-at[a] - gAth) * g_i, eab[a], dfb[a]);
+#pragma unroll
+         for (int a = 0; a < KW; a++) ef[a] = exp(eaf[a]);
+#pragma unroll
+         for (int a = 0; a < KW; a++) eb[a] = exp(eab[a]);
+#pragma unroll
+         for (int a = 0; a < KW; a++) pw[a] = 0.0;
+         if (any_tail) {   // power-law tail: only above t_min = (1e-60)^m (rare for large 1/m)
+            if (mp.xn_int > 0) {
+               double b[KW];
+#pragma unroll
+               for (int a = 0; a < KW; a++) { pw[a] = 1.0; b[a] = at0[a]; }
+               for (int e = mp.xn_int;;) {
+                  if (e & 1) {
+#pragma unroll
+                     for (int a = 0; a < KW; a++) pw[a] *= b[a];
+                  }
+                  e >>= 1;
+                  if (!e) break;
+#pragma unroll
+                  for (int a = 0; a < KW; a++) b[a] *= b[a];
+               }
+            } else {
+#pragma unroll
+               for (int a = 0; a < KW; a++) pw[a] = exp(mp.xn * log(fmax(at0[a], 1.0e-300)));
+            }
+         }
+#pragma unroll
+         for (int a = 0; a < KW; a++) {
+            double gw = kv.gam_w * (ef[a] - eb[a]);
+            double dgw = kv.gam_w * (ef[a] * dff[a] + eb[a] * dfb[a]) * g_i;
+            const bool tail = at0[a] > mp.t_min;
+            const double temp = (kv.gam_w * 10.0) * pw[a];
+            gw += tail ? temp * at0[a] : 0.0;
+            dgw += tail ? temp * mp.xnn * g_i : 0.0;
+            const bool valid = inwin[a] && (gw > 0.0);
+            const double r1 = 1.0 / gw, r2 = 1.0 / gr[a];
+            const double gd = 1.0 / (r1 + r2);
+            if (valid) { gdot[a] = copysign(gd, tau[a]); if (WITHD) dg[a] = gd * gd * (dgw * r1 * r1 + dgr[a] * r2 * r2); }
+         }
+      }
    }
 }
 
@@ -531,7 +509,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 #pragma unroll
          for (int j = 0; j < 5; j++) jac.B[i][j] = 0.0;
    }
-   if constexpr (KIN == KIN_KMBALD_B) {
+   {
 #pragma unroll 1
       for (int a0 = 0; a0 < NSLIP; a0 += KW) {   // rolled over groups: the table rows of a group come in through scalar loads
          double pq[KW][8], tau[KW], gd[KW], dg[KW];
@@ -566,36 +544,6 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
          }
       }
       ok = isfinite(shr);
-   } else {
-#pragma unroll kSlipUnroll
-   for (int a = 0; a < NSLIP; a++) {
-      double pq[8];
-#pragma unroll
-      for (int c = 0; c < 8; c++) pq[c] = PQ_TAB[a][c];
-      const double tau = pq[0] * k[0] + pq[1] * k[1] + pq[2] * k[2] + pq[3] * k[3] + pq[4] * k[4];
-      double gd, dg;
-      kmbald_gdot(mp, pb.kv, tau, gd, dg);
-      if (gdot_out) gdot_out[a * pb.gs] = gd;
-      dis += tau * gd; shr += fabs(gd);
-      ok = ok && isfinite(gd);
-#pragma unroll
-      for (int c = 0; c < 5; c++) dp[c] += pq[c] * gd;
-#pragma unroll
-      for (int c = 0; c < 3; c++) wp[c] += pq[5 + c] * gd;
-      if (WITHJ) {
-         double gp[5];
-#pragma unroll
-         for (int c = 0; c < 5; c++) gp[c] = dg * pq[c];
-#pragma unroll
-         for (int i = 0; i < 5; i++)
-#pragma unroll
-            for (int j = i; j < 5; j++) jac.A[sidx(i, j)] += pq[i] * gp[j];
-#pragma unroll
-         for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 5; j++) jac.B[i][j] += pq[5 + i] * gp[j];
-      }
-   }
    }
    }
    dis_rate = dis * pb.detV_ri; shrate = shr;

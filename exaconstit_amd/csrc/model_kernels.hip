@@ -211,13 +211,8 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
          else launch_model<KIN_VOCE_NL, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
       default:
-         if (!ctx->mp.with_g_athermal) {   // FCC variant: every system above threshold -> two-at-a-time branch-free kinetics
-            if (lv) launch_model<KIN_KMBALD_B, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
-            else launch_model<KIN_KMBALD_B, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
-         } else {
-            if (lv) launch_model<KIN_KMBALD, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
-            else launch_model<KIN_KMBALD, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
-         }
+         if (lv) launch_model<KIN_KMBALD, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         else launch_model<KIN_KMBALD, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
    }
    EXA_HIP_CHECK(ctx, hipGetLastError());
