@@ -2,12 +2,13 @@
 //
 // Replaces, behind the reference's ExaModel seam, what ExaConstit obtains from
 //   ecmech::matModelBase::getResponseECM        (call site reference src/mechanics_ecmech.cpp:176-186)
-// for the models of reference src/mechanics_ecmech.hpp:407-414,460-463.  One thread owns one quadrature point; all
-// small tensors live in registers with compile-time indexing only (no scratch), the 8x8 point system is solved in
-// its 5+3 block form (the rotation block is eliminated analytically, the remaining 5x5 is an un-pivoted LU of a
-// column-scaled SPD matrix), and the slip-system tables are compile-time constants so the compiler folds their
-// zeros.  BCC {110}<111> and FCC {111}<110> share the symmetric Schmid tensors; only the sign of the plastic spin
-// differs, so one table serves both.
+// for the models of reference src/mechanics_ecmech.hpp:407-414,460-463.  One thread owns one quadrature point; small
+// tensors are indexed at compile time only, the 8x8 point system is kept in its 5+3 block form (LDL^T of the symmetric
+// 5x5 block, closed-form inverse of the 3x3 rotation block, block Gauss-Seidel for a Newton step, exact Schur
+// complement for the tangent), and the slip-system tables are small-integer compile-time constants so that the 12
+// systems unroll into adds / FMAs with inline constants.  What does not fit the 256 VGPRs of two waves per SIMD lives in
+// a per-lane LDS stash (see "Register budget").  BCC {110}<111> and FCC {111}<110> share the symmetric Schmid tensors;
+// only the sign of the plastic spin differs, so one table serves both.
 //
 // This is an independent implementation of the same published algorithm that oracle/ecmech_port.hpp restates on
 // the CPU; tests compare the two on identical inputs.  Nothing here includes or links the oracle.
@@ -399,11 +400,13 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 
 // Register budget.  Two waves per SIMD need <= 256 VGPRs; the naive point update wants ~370.  What is not touched inside the
 // slip-system loop is therefore parked outside the register file:
-//   * per-thread LDS stash (slot s of thread t at stash[s * ECM_STASH_STRIDE + t], conflict-free): the vectors an evaluation reads
-//     once (e_n, d_n, w_n), the rotation data of the last evaluation (Tr, d_lat, w_lat: written once per evaluation, read by the
-//     solve) and the restore copy of x — 38 doubles, so two 256-thread blocks fit the 160 KB of a CU;
-//   * values only needed after the local solve (D', old stress, quaternion, volumes, energy ...) are parked in the point's own
-//     36-double tangent slot in global memory, which is written last.
+//   * per-thread LDS stash (slot s of thread t at stash[s * ECM_STASH_STRIDE + t], conflict-free), 38 doubles so that two 256-thread
+//     blocks fit the 160 KB of a CU: the vectors an evaluation reads once (e_n, d_n, w_n), the restore copy of x, and 17 of the 20
+//     values only needed after the local solve (D', old stress, quaternion, volumes, energy);
+//   * the last 3 of those (dEff, bulk modulus, hardness) sit in the point's own tangent slot in global memory, which is written last.
+// The rotation data of an evaluation (Tr, d_lat, w_lat) is never live across one and stays in registers (struct Jac).  Rule measured
+// on MI355X: inside a thread's lifetime nothing written to global memory is still in L2 when it is read back, and a reload waits for
+// every earlier store of the wave (vmcnt), so anything that must survive the Newton loop belongs in LDS, not in global memory.
 #ifndef ECM_STASH_STRIDE
 #define ECM_STASH_STRIDE 256
 #endif

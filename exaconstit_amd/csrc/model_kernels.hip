@@ -3,7 +3,9 @@
 //   StressSetup/StateVarsSetup copies, matGrad/vel_grad zero fills, grad_calc (src/mechanics_kernels.cpp:36-77),
 //   kernel_setup (src/mechanics_ecmech.cpp:42-99), getResponseECM, kernel_postprocessing (:116-171).
 // One thread per quadrature point; the reference shape-derivative table is staged in LDS; per-point state is read
-// and written once (928 B per point algorithmic traffic).
+// and written once (928 B per point algorithmic traffic).  Variants (templates): E-vector + Jacobian inputs (the reference's
+// ModelSetup signature) or fused L-vector gathers that also write the Jacobians; reference (AOS) or element-blocked quadrature-function
+// layout; run-time tail split of long local solves into a dense second launch.
 #include "exa_internal.hpp"
 
 using namespace ecmdev;
