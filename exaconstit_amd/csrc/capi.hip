@@ -262,6 +262,11 @@ int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const ui
    return exa_launch_grad_apply_p1(ctx, x, y, true, mask, gate, S(s));
 }
 
+int exa_grad_set_coords(exa_ctx* ctx, const double* coords_lvec) {
+   if (!ctx) return EXA_ERR_ARG;
+   ctx->coords_lvec = coords_lvec; return EXA_OK;
+}
+
 int exa_grad_apply_lvec(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, exa_stream s) {
    return exa_grad_apply_lvec_gated(ctx, x, y, mask, nullptr, s);
 }

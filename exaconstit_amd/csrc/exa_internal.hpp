@@ -45,6 +45,7 @@ struct exa_ctx {
    bool have_resid = false, have_grad = false;
    // L-vector support
    const int32_t* conn = nullptr; int nnodes = 0;
+   const double* coords_lvec = nullptr;     // optional: nodal coordinates the Jacobians of exa_grad_setup came from (geometry recomputed in the apply)
    // status
    int* fail_count_dev = nullptr;
    int newton_cap = 0; int* tail_dev = nullptr;   // tail split of the constitutive launch: [0] = count, [1..] = deferred point ids

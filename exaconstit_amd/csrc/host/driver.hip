@@ -324,6 +324,9 @@ void NonlinearMechOperator::Mult(const double* k, double* y) { Setup<true>(k); R
 
 void NonlinearMechOperator::GetGradient() {
    abi_check(ctx_, exa_grad_setup(ctx_, dt_, el_jac.p, matGrad.p, stream_), "exa_grad_setup");
+   // geometry of the action recomputed from x_cur (unchanged until the next residual evaluation); EXA_APPLY_GEO=off streams it instead
+   if (fast_p1_ && opt_.assembly == Assembly::PA && !(std::getenv("EXA_APPLY_GEO") && std::string(std::getenv("EXA_APPLY_GEO")) == "off"))
+      abi_check(ctx_, exa_grad_set_coords(ctx_, x_cur.p), "exa_grad_set_coords");
    el_y_.zero(stream_);
    abi_check(ctx_, exa_grad_diagonal(ctx_, el_y_.p, stream_), "exa_grad_diagonal");
    diag.zero(stream_);

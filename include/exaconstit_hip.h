@@ -134,6 +134,10 @@ int exa_restrict_transpose_add(exa_ctx* ctx, const double* evec_dev, double* lve
 /* fused gather / apply / scatter-add of the gradient action on L-vectors (the PCG inner kernel): y_L += K x_L.
  * mask_dev (nullable, 3*nnodes bytes): essential dofs — x is read as 0 there (spec src/mechanics_operator_ext.cpp:143-146). */
 int exa_grad_apply_lvec(exa_ctx* ctx, const double* x_lvec_dev, double* y_lvec_dev, const uint8_t* mask_dev, exa_stream s);
+/* Optional (p = 1 partial assembly, L-vector action): the nodal coordinates (nnodes,3 byNODES) the Jacobians given to exa_grad_setup
+ * were computed from.  When set, exa_grad_apply_lvec recomputes adj(J) from them instead of streaming it from its per-point record
+ * (36 instead of 46 doubles per point from HBM); the array must stay unchanged until the next exa_grad_setup.  NULL switches it off. */
+int exa_grad_set_coords(exa_ctx* ctx, const double* coords_lvec_dev);
 /* fused AssemblePA + AddMultPA + E->L: y_L += B^T sigma */
 int exa_residual_lvec(exa_ctx* ctx, const double* jacobian_dev, const double* stress1_dev, double* y_lvec_dev, exa_stream s);
 /* volume average  sum_q W detJ val / sum_q W detJ  (src/mechanics_kernels.hpp:19-134); out_host[vdim] (+ volume in out_host[vdim]).

@@ -209,6 +209,13 @@ def test_integrators_match_oracle(oracle, assembly):
     d_xL = dev.up(xL); d_mask = dev.up(mask); d_yL = dev.zeros(3 * NN)
     ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xL), ptr(d_yL), ptr(d_mask), None))
     assert rel_l2(d_yL.cpu().numpy(), yL_ref) < 1e-12
+    if assembly == 0:
+        # same action with adj(J) recomputed in the kernel from the nodal coordinates the Jacobians came from
+        d_X = dev.up(rve["X"]); d_yL2 = dev.zeros(3 * NN)
+        ctx.check(L.exa_grad_set_coords(ctx.h, ptr(d_X)))
+        ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xL), ptr(d_yL2), ptr(d_mask), None))
+        assert rel_l2(d_yL2.cpu().numpy(), yL_ref) < 1e-12
+        ctx.check(L.exa_grad_set_coords(ctx.h, None))
     # restriction pair
     d_e = dev.zeros(3 * n * E)
     ctx.check(L.exa_restrict(ctx.h, ptr(d_xL), ptr(d_e), None))
