@@ -26,6 +26,7 @@ int exa_launch_eds(exa_ctx*, const double*, hipStream_t);
 int exa_launch_residual_bbar(exa_ctx*, const double*, const double*, double*, hipStream_t);
 int exa_launch_assemble_ea_gen(exa_ctx*, hipStream_t);
 int exa_launch_ea_apply_gen(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t);
+int exa_launch_mf_apply_p2(exa_ctx*, const double*, double*, const uint8_t*, const double*, bool, hipStream_t);
 int exa_launch_ea_diag_gen(exa_ctx*, double*, hipStream_t);
 int exa_launch_ea_export_gen(exa_ctx*, double*, hipStream_t);
 int exa_launch_pa_apply_gen(exa_ctx*, const double*, double*, hipStream_t);
@@ -72,7 +73,7 @@ exa_ctx* exa_create(const exa_config* cfg, int* err) {
 void exa_destroy(exa_ctx* ctx) {
    if (!ctx) return;
    (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->tail_dev); (void)hipFree(ctx->scratch_dev);
-   (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->tbuf);
+   (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->T1_dev); (void)hipFree(ctx->tbuf);
    delete ctx;
 }
 
@@ -169,7 +170,7 @@ int exa_residual_setup(exa_ctx* ctx, const double* J, const double* stress1, exa
    if (ctx->qblk) return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_residual_setup: E-vector residual is AOS-only; with the element-blocked layout use exa_residual_lvec");
    ctx->have_resid = true;
    if (ctx->cfg.integ == EXA_INTEG_BBAR) {      // ICExaNLFIntegrator::AssemblePA: element-average gradient; J and sigma are read by AddMultPA
-      if (!ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * ctx->E));
+      if (!ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * PA_BLK * (size_t)((ctx->E + PA_BLK - 1) / PA_BLK)));
       ctx->resid_J = J; ctx->resid_S = stress1;
       return exa_launch_eds(ctx, J, S(s));
    }
@@ -184,24 +185,36 @@ int exa_residual_apply(exa_ctx* ctx, double* y, exa_stream s) {
    return exa_launch_residual_apply(ctx, y, S(s));
 }
 
+// element matrices from the point records (and eDS) of the last exa_grad_setup
+static int assemble_ea(exa_ctx* ctx, hipStream_t s) {
+   if (ctx->emat_valid) return EXA_OK;
+   const size_t nblocks = (size_t)((ctx->E + PA_BLK - 1) / PA_BLK), nd = 3 * (size_t)ctx->n;
+   if (!ctx->emat) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->emat, nblocks * nd * nd * PA_BLK * sizeof(double)));
+   const int rc = ctx->ea_generic ? exa_launch_assemble_ea_gen(ctx, s) : exa_launch_assemble_ea_p1(ctx, s);
+   ctx->emat_valid = (rc == EXA_OK);
+   return rc;
+}
+
+int exa_set_ea_matrix_free(exa_ctx* ctx, int on) {
+   if (!ctx) return EXA_ERR_ARG;
+   ctx->ea_matfree = on != 0; return EXA_OK;
+}
+
 int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, exa_stream s) {
    if (!ctx || !J || !C) return fail(ctx, EXA_ERR_ARG, "exa_grad_setup: null pointer");
    if (!ctx->pa) { EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa, pa_bytes(ctx->E, ctx->Q))); EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa, 0, pa_bytes(ctx->E, ctx->Q), S(s))); }
    int rc = exa_launch_grad_setup_pa(ctx, dt, J, C, S(s));
    if (rc) return rc;
-   const size_t nblocks = (size_t)((ctx->E + PA_BLK - 1) / PA_BLK);
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
       const bool bbar = ctx->cfg.integ == EXA_INTEG_BBAR;
       ctx->ea_generic = bbar || ctx->p != 1;
-      const size_t nd = 3 * (size_t)ctx->n;
-      const size_t bytes = nblocks * nd * nd * PA_BLK * sizeof(double);
-      if (!ctx->emat) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->emat, bytes));
       if (bbar) {
-         if (!ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * ctx->E));
+         if (!ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * PA_BLK * (size_t)((ctx->E + PA_BLK - 1) / PA_BLK)));
          rc = exa_launch_eds(ctx, J, S(s));
          if (rc) return rc;
       }
-      rc = ctx->ea_generic ? exa_launch_assemble_ea_gen(ctx, S(s)) : exa_launch_assemble_ea_p1(ctx, S(s));
+      ctx->emat_valid = false;
+      if (!(ctx->ea_matfree && ctx->n == 27)) rc = assemble_ea(ctx, S(s));   // matrix-free: assembled on demand only
    } else if (ctx->p != 1) {
       if (!ctx->tbuf) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tbuf, sizeof(double) * 9 * ctx->P));
    }
@@ -212,8 +225,10 @@ int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, ex
 int exa_grad_apply(exa_ctx* ctx, const double* x, double* y, exa_stream s) {
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply: null pointer");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply called before exa_grad_setup");
-   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA)
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
+      if (int rc = assemble_ea(ctx, S(s))) return rc;
       return ctx->ea_generic ? exa_launch_ea_apply_gen(ctx, x, y, false, nullptr, nullptr, S(s)) : exa_launch_ea_apply_p1(ctx, x, y, false, nullptr, nullptr, S(s));
+   }
    if (ctx->p != 1) return exa_launch_pa_apply_gen(ctx, x, y, S(s));
    return exa_launch_grad_apply_p1(ctx, x, y, false, nullptr, nullptr, S(s));
 }
@@ -221,7 +236,10 @@ int exa_grad_apply(exa_ctx* ctx, const double* x, double* y, exa_stream s) {
 int exa_grad_diagonal(exa_ctx* ctx, double* d, exa_stream s) {
    if (!ctx || !d) return fail(ctx, EXA_ERR_ARG, "exa_grad_diagonal: null pointer");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_diagonal called before exa_grad_setup");
-   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) return ctx->ea_generic ? exa_launch_ea_diag_gen(ctx, d, S(s)) : exa_launch_ea_diag_p1(ctx, d, S(s));
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
+      if (int rc = assemble_ea(ctx, S(s))) return rc;
+      return ctx->ea_generic ? exa_launch_ea_diag_gen(ctx, d, S(s)) : exa_launch_ea_diag_p1(ctx, d, S(s));
+   }
    if (ctx->p != 1) return exa_launch_pa_diag_gen(ctx, d, S(s));
    return exa_launch_grad_diag_p1(ctx, d, S(s));
 }
@@ -229,6 +247,7 @@ int exa_grad_diagonal(exa_ctx* ctx, double* d, exa_stream s) {
 int exa_grad_get_ea(exa_ctx* ctx, double* emat, exa_stream s) {
    if (!ctx || !emat) return fail(ctx, EXA_ERR_ARG, "exa_grad_get_ea: null pointer");
    if (!ctx->have_grad || ctx->cfg.assembly != EXA_ASSEMBLY_EA) return fail(ctx, EXA_ERR_STATE, "exa_grad_get_ea: no element matrices assembled");
+   if (int rc = assemble_ea(ctx, S(s))) return rc;
    return ctx->ea_generic ? exa_launch_ea_export_gen(ctx, emat, S(s)) : exa_launch_ea_export_p1(ctx, emat, S(s));
 }
 
@@ -256,9 +275,13 @@ int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const ui
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec: connectivity not set");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec called before exa_grad_setup");
-   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA)
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
+      if (ctx->ea_matfree && ctx->n == 27) return exa_launch_mf_apply_p2(ctx, x, y, mask, gate, true, S(s));
+      if (int rc = assemble_ea(ctx, S(s))) return rc;
       return ctx->ea_generic ? exa_launch_ea_apply_gen(ctx, x, y, true, mask, gate, S(s)) : exa_launch_ea_apply_p1(ctx, x, y, true, mask, gate, S(s));
-   if (ctx->p != 1) return fail(ctx, EXA_ERR_UNSUPPORTED, "fused L-vector partial-assembly action is built for p = 1 only; use exa_restrict + exa_grad_apply");
+   }
+   if (ctx->n == 27) return exa_launch_mf_apply_p2(ctx, x, y, mask, gate, false, S(s));
+   if (ctx->p != 1) return fail(ctx, EXA_ERR_UNSUPPORTED, "fused L-vector partial-assembly action is built for p = 1 and p = 2; use exa_restrict + exa_grad_apply");
    return exa_launch_grad_apply_p1(ctx, x, y, true, mask, gate, S(s));
 }
 

@@ -37,10 +37,12 @@ struct exa_ctx {
    double* dmat = nullptr;                  // (3,3,Q,E)
    double* pa = nullptr;                    // see layout above
    double* emat = nullptr;                  // EA: p=1 full integration [block][24][12 pairs][64][2]; otherwise [block][3n][3n][64]
-   double* eDS = nullptr;                   // B-bar: element-average shape gradient (n,3,E)
+   double* T1_dev = nullptr;                // p = 2 matrix-free action: one-dimensional basis tables (3 x 6)
+   double* eDS = nullptr;                   // B-bar: element-average shape gradient [block][n x 3][64 lanes]
    double* tbuf = nullptr;                  // generic PA action: per-point T (3,3,Q,E)
    const double* resid_J = nullptr; const double* resid_S = nullptr;   // B-bar residual reads J and sigma at apply time, like the reference
    bool ea_generic = false;
+   bool ea_matfree = false, emat_valid = false;   // EA, p = 2: L-vector action computed from the point records, matrices assembled on demand
    bool qblk = false;                       // quadrature functions in the element-blocked layout (see QView below)
    bool have_resid = false, have_grad = false;
    // L-vector support
@@ -55,6 +57,8 @@ struct exa_ctx {
 
 // host-side reference element (H1 hex of order p at (p+1)^3 Gauss-Legendre points), src/mechanics_operator.cpp:237-261
 void exa_build_ref_elem(int p, std::vector<double>& G, std::vector<double>& W);
+// one-dimensional tables [1D Gauss point][B_0..B_p, D_0..D_p] of the order-p nodal basis and the lexicographic -> native node map
+void exa_build_1d_tables(int p, std::vector<double>& T1, std::vector<int>& nat);
 bool exa_fill_mat_params(const exa_config& cfg, ecmdev::MatParams& mp, double* hist_init, std::string& err);
 
 // Quadrature-function addressing.  AOS is the reference's QuadratureFunction layout (vdim values of a point contiguous, points of an

@@ -8,11 +8,14 @@
 // element streams them with loads that are contiguous across the wave; p = 2 (81 x 81 per element, 52 KB) is HBM-bound on exactly
 // this stream.  The p = 1 full-integration fast paths live in pa_kernels.hip.
 #include "exa_internal.hpp"
+#include <type_traits>
 
 namespace {
 
 __device__ __forceinline__ int64_t pa_off(int64_t blk, int Q, int q, int pair) { return (((blk * Q + q) * PA_PAIRS + pair) * PA_BLK) * 2; }
 __device__ __forceinline__ int64_t eag_off(int64_t blk, int nd, int j, int i) { return ((blk * nd + j) * nd + i) * PA_BLK; }
+// element-average gradients, element-blocked like everything else a lane-per-element kernel streams: [block][dof a + n c][64 lanes]
+__device__ __forceinline__ int64_t eds_off(int64_t e, int n, int a, int c) { return ((e / PA_BLK) * (3 * n) + a + n * c) * PA_BLK + (e % PA_BLK); }
 
 __device__ __forceinline__ void adj_det(const double* Jq, double adj[9], double& detJ) {
    const double J11 = Jq[0], J21 = Jq[1], J31 = Jq[2], J12 = Jq[3], J22 = Jq[4], J32 = Jq[5], J13 = Jq[6], J23 = Jq[7], J33 = Jq[8];
@@ -46,7 +49,7 @@ __global__ void k_eds(const int Q, const int n, const int E, const double* __res
       const double g0 = sG[a + n * (3 * q)], g1 = sG[a + n * (3 * q + 1)], g2 = sG[a + n * (3 * q + 2)];
       for (int c = 0; c < 3; c++) acc[c] += w * (g0 * adj[c] + g1 * adj[3 + c] + g2 * adj[6 + c]);
    }
-   for (int c = 0; c < 3; c++) eDS[a + n * (c + 3 * e)] = acc[c] / vol;
+   for (int c = 0; c < 3; c++) eDS[eds_off(e, n, a, c)] = acc[c] / vol;
 }
 
 // Y(a,c,e) += sum_q detJ W B-bar(a,c,:) . sigma ; one thread per (node, element)
@@ -58,7 +61,7 @@ __global__ void k_residual_bbar(const int Q, const int n, const int E, const dou
    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= (int64_t)n * E) return;
    const int a = (int)(t % n); const int64_t e = t / n;
-   const double ge[3] = { eDS[a + n * (3 * e)], eDS[a + n * (1 + 3 * e)], eDS[a + n * (2 + 3 * e)] };
+   const double ge[3] = { eDS[eds_off(e, n, a, 0)], eDS[eds_off(e, n, a, 1)], eDS[eds_off(e, n, a, 2)] };
    double y[3] = { 0, 0, 0 };
    for (int q = 0; q < Q; q++) {
       const int64_t ip = q + (int64_t)Q * e;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(PA_BLK) void k_assemble_ea_gen(const int E, const d
 #pragma unroll
    for (int i = 0; i < ND; i++) M[i] = 0.0;
    double gej[3] = { 0, 0, 0 };
-   if (BBAR) for (int c = 0; c < 3; c++) gej[c] = eDS[aj + N * (c + 3 * e)];
+   if (BBAR) for (int c = 0; c < 3; c++) gej[c] = eDS[eds_off(e, N, aj, c)];
    for (int q = 0; q < Q; q++) {
       const double2* rec = reinterpret_cast<const double2*>(pa + pa_off(blk, Q, q, 0)) + lane;
       double v[PA_SLOTS];
@@ -117,9 +120,9 @@ __global__ __launch_bounds__(PA_BLK) void k_assemble_ea_gen(const int E, const d
          double r1 = b1 * cb[1] + b2 * cb[3] + b0 * cb[5];
          double r2 = b2 * cb[2] + b1 * cb[3] + b0 * cb[4];
          if (BBAR) {
-            r0 += (detJ * eDS[a + N * (0 + 3 * e)] - b0) * (1.0 / 3.0) * cb012;
-            r1 += (detJ * eDS[a + N * (1 + 3 * e)] - b1) * (1.0 / 3.0) * cb012;
-            r2 += (detJ * eDS[a + N * (2 + 3 * e)] - b2) * (1.0 / 3.0) * cb012;
+            r0 += (detJ * eDS[eds_off(e, N, a, 0)] - b0) * (1.0 / 3.0) * cb012;
+            r1 += (detJ * eDS[eds_off(e, N, a, 1)] - b1) * (1.0 / 3.0) * cb012;
+            r2 += (detJ * eDS[eds_off(e, N, a, 2)] - b2) * (1.0 / 3.0) * cb012;
          }
          M[a] += r0; M[a + N] += r1; M[a + 2 * N] += r2;
       }
@@ -158,6 +161,211 @@ __global__ __launch_bounds__(PA_BLK) void k_ea_apply_gen(const int E, const doub
       else y[j + (int64_t)ND * e] += s;
    }
 }
+
+// ---- matrix-free action for p = 2 (27 nodes, 27 points), plain or B-bar, on L-vectors ---------------------------------------------
+// The element matrices of a triquadratic hex are 81 x 81 doubles (52 KB per element); the operator they represent is determined by the
+// 27 x 46-double point records (10 KB per element) [+ 81 element-average gradients for B-bar], so the action is computed from those:
+//   eps = B(-bar) x_e,  s = Ct eps (TRANS: Ct^T eps, the operator the assembled matrices apply, see k_ea_apply_gen),  y_e += B(-bar)^T s.
+// One lane per element, one wave per 64-element block, points in sequence.  y_e (81 doubles) lives in registers, x_e in LDS used as a
+// lane-private register-file extension ([dof][lane], no barriers, no conflicts); 76 of its 81 values, because 4 x 76 x 512 B fits
+// the CU's 160 KB with one wave per SIMD (and leaves the allocator 8 KB of slack).
+// Shape gradients: dN_a/dxi(q) = D[qi][i] B[qj][j] B[qk][k] etc. with the 3 x 3 one-dimensional tables B, D.  Both contractions over
+// the 27 nodes are done as three one-dimensional passes whose coefficients are wave-uniform SGPR operands (18 doubles per point)
+// instead of an 81-double table per point (which does not fit the SGPR file and stalls a lone wave on scalar loads).
+// Software pipeline: the record of point q+1 is requested as soon as the record of point q is consumed and lands behind the two
+// long register-only passes (scatter of q, gather of q+1: 2 x 270 FMAs) - at one wave per SIMD nothing else hides it.
+constexpr int P2N = 27, P2ND = 81, P2XL = 76;
+// lexicographic (i,j,k) -> native node of the triquadratic hexahedron (host_tables.cpp native_order(2); checked at launch)
+__device__ constexpr int P2NAT[27] = { 0, 8, 1, 11, 20, 9, 3, 10, 2, 16, 21, 17, 24, 26, 22, 19, 23, 18, 4, 12, 5, 15, 25, 13, 7, 14, 6 };
+
+// one-dimensional table rows live in the constant address space: wave-uniform reads become scalar loads
+typedef const __attribute__((address_space(4))) double* cptr;
+__device__ __forceinline__ cptr as_const(const double* p) { return (cptr)(uintptr_t)p; }
+
+struct Rows1D { double bx[3], dx[3], by[3], dy[3], bz[3], dz[3]; };
+
+#define P2X(i_) ((i_) < P2XL ? sX[(i_) * PA_BLK] : XR[(i_) < P2XL ? 0 : (i_) - P2XL])
+
+// gx[c][d] = sum_a x_{a,c} dN_a/dxi_d at one point
+__device__ __forceinline__ void mf_gather_p2(const Rows1D& r, const double* sX, const double (&XR)[P2ND - P2XL], double (&gx)[3][3]) {
+#pragma unroll
+   for (int c = 0; c < 3; c++) {
+      double bb[3] = { 0, 0, 0 }, bd[3] = { 0, 0, 0 }, db[3] = { 0, 0, 0 };     // per k: (Bx By), (Bx Dy), (Dx By) contracted over i, j
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+#pragma unroll
+         for (int j = 0; j < 3; j++) {
+            const double x0 = P2X(P2NAT[0 + 3 * j + 9 * k] + P2N * c), x1 = P2X(P2NAT[1 + 3 * j + 9 * k] + P2N * c), x2 = P2X(P2NAT[2 + 3 * j + 9 * k] + P2N * c);
+            const double ub = fma(r.bx[2], x2, fma(r.bx[1], x1, r.bx[0] * x0));
+            const double ud = fma(r.dx[2], x2, fma(r.dx[1], x1, r.dx[0] * x0));
+            bb[k] = fma(r.by[j], ub, bb[k]); bd[k] = fma(r.dy[j], ub, bd[k]); db[k] = fma(r.by[j], ud, db[k]);
+         }
+      }
+      gx[c][0] = fma(r.bz[2], db[2], fma(r.bz[1], db[1], r.bz[0] * db[0]));
+      gx[c][1] = fma(r.bz[2], bd[2], fma(r.bz[1], bd[1], r.bz[0] * bd[0]));
+      gx[c][2] = fma(r.dz[2], bb[2], fma(r.dz[1], bb[1], r.dz[0] * bb[0]));
+      __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from fetching all 81 LDS values up front (162 VGPRs)
+   }
+}
+
+// Y_{a,c} += sum_d dN_a/dxi_d T[d][c]
+__device__ __forceinline__ void mf_scatter_p2(const Rows1D& r, const double (&T)[3][3], double (&Y)[P2ND]) {
+#pragma unroll
+   for (int c = 0; c < 3; c++) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+         const double a0 = r.bz[k] * T[0][c], a1 = r.bz[k] * T[1][c], a2 = r.dz[k] * T[2][c];
+#pragma unroll
+         for (int j = 0; j < 3; j++) {
+            const double pd = r.by[j] * a0;                          // multiplies Dx[i]
+            const double pb = fma(r.by[j], a2, r.dy[j] * a1);        // multiplies Bx[i]
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+               const int idx = P2NAT[i + 3 * j + 9 * k] + P2N * c;
+               Y[idx] = fma(r.bx[i], pb, fma(r.dx[i], pd, Y[idx]));
+            }
+         }
+      }
+   }
+}
+
+template <bool BBAR, bool TRANS>
+__device__ __forceinline__ void mf_point_p2(const double2 (&rec)[PA_PAIRS], const double (&gx)[3][3], const double wq, const double dbar, double& sbar, double (&T)[3][3]) {
+   double v[PA_SLOTS];
+#pragma unroll
+   for (int pr = 0; pr < PA_PAIRS; pr++) { v[2 * pr] = rec[pr].x; v[2 * pr + 1] = rec[pr].y; }
+   const double* Ct = v; const double* adj = v + 36;
+   double h[3][3];
+#pragma unroll
+   for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int t = 0; t < 3; t++) h[c][t] = gx[c][0] * adj[t] + gx[c][1] * adj[3 + t] + gx[c][2] * adj[6 + t];
+   double eps[6] = { h[0][0], h[1][1], h[2][2], h[1][2] + h[2][1], h[0][2] + h[2][0], h[0][1] + h[1][0] };
+   double detJ = 0.0;
+   if (BBAR) {   // volumetric part replaced by the element average: sum_dofs (detJ gbar - b)/3 x
+      detJ = v[45] / wq;
+      const double vol = (detJ * dbar - (h[0][0] + h[1][1] + h[2][2])) * (1.0 / 3.0);
+      eps[0] += vol; eps[1] += vol; eps[2] += vol;
+   }
+   double sg[6];
+#pragma unroll
+   for (int i = 0; i < 6; i++) { double t = 0;
+#pragma unroll
+      for (int j = 0; j < 6; j++) t += (TRANS ? Ct[j + 6 * i] : Ct[i + 6 * j]) * eps[j];
+      sg[i] = t; }
+   const double Sm[3][3] = { { sg[0], sg[5], sg[4] }, { sg[5], sg[1], sg[3] }, { sg[4], sg[3], sg[2] } };
+#pragma unroll
+   for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) T[j][c] = adj[3 * j] * Sm[0][c] + adj[3 * j + 1] * Sm[1][c] + adj[3 * j + 2] * Sm[2][c];
+   if (BBAR) {   // B-bar^T s = B^T s + (detJ gbar - b) tr(s)/3: the -b part folds into T, the gbar part is element-constant
+      const double tr3 = (sg[0] + sg[1] + sg[2]) * (1.0 / 3.0);
+      sbar += detJ * tr3;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+         for (int c = 0; c < 3; c++) T[j][c] -= adj[3 * j + c] * tr3;
+   }
+}
+
+// T1 = one-dimensional tables [1D point][B0 B1 B2 D0 D1 D2]
+template <bool BBAR, bool TRANS>
+__global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const double* __restrict__ pa, const double* __restrict__ T1, const double* __restrict__ W,
+                                                        const double* __restrict__ eDS, const double* __restrict__ x, double* __restrict__ y,
+                                                        const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
+                                                        const double* __restrict__ gate) {
+   __shared__ double sXall[P2XL * PA_BLK];
+   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   if (e >= E) return;
+   if (gate != nullptr && gate[0] != 0.0) return;
+   double* sX = sXall + lane;
+   double XR[P2ND - P2XL]; double dbar = 0.0;
+   double2 rec[PA_PAIRS];
+   auto load = [&](int q) {
+      const double2* r = reinterpret_cast<const double2*>(pa + pa_off(blk, P2N, q, 0)) + lane;
+#pragma unroll
+      for (int pr = 0; pr < PA_PAIRS; pr++) rec[pr] = r[pr * PA_BLK];
+   };
+   load(0);
+   int gidx[P2N];
+#pragma unroll
+   for (int a = 0; a < P2N; a++) gidx[a] = conn[a + P2N * e];
+#pragma unroll
+   for (int a = 0; a < P2N; a++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+         const int i = a + P2N * c;
+         const double xv = x[gidx[a] + (int64_t)nnodes * c];
+         if (i < P2XL) sX[i * PA_BLK] = xv; else XR[i < P2XL ? 0 : i - P2XL] = xv;
+      }
+      if (a % 9 == 8) __builtin_amdgcn_sched_barrier(0);
+   }
+   if (mask != nullptr) {   // essential dofs enter as zeros (second pass: keeps the gather free of branches)
+      uint8_t mk[P2ND];
+#pragma unroll
+      for (int i = 0; i < P2ND; i++) mk[i] = mask[gidx[i % P2N] + (int64_t)nnodes * (i / P2N)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < P2ND; i++) {
+         if (i < P2XL) { if (mk[i]) sX[i * PA_BLK] = 0.0; } else XR[i < P2XL ? 0 : i - P2XL] = mk[i] ? 0.0 : XR[i < P2XL ? 0 : i - P2XL];
+      }
+   }
+   if (BBAR) {
+#pragma unroll
+      for (int i = 0; i < P2ND; i++) {
+         dbar += eDS[eds_off(e, P2N, i % P2N, i / P2N)] * P2X(i);
+         if (i % 9 == 8) __builtin_amdgcn_sched_barrier(0);
+      }
+   }
+   double Y[P2ND];
+#pragma unroll
+   for (int i = 0; i < P2ND; i++) Y[i] = 0.0;
+   double sbar = 0.0;
+   const cptr t1 = as_const(T1);
+   Rows1D r, rn;
+   auto rows = [&](Rows1D& o, int q) {
+      const int qi = q % 3, qj = (q / 3) % 3, qk = q / 9;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+         o.bx[d] = t1[6 * qi + d]; o.dx[d] = t1[6 * qi + 3 + d]; o.by[d] = t1[6 * qj + d]; o.dy[d] = t1[6 * qj + 3 + d];
+         o.bz[d] = t1[6 * qk + d]; o.dz[d] = t1[6 * qk + 3 + d];
+      }
+   };
+   rows(r, 0);
+   // one point: gather, point arithmetic, request of the next record into the registers just consumed, scatter.  PRE is a
+   // compile-time flag and the last point is peeled: a conditional prefetch would turn the record into a loop-carried phi of old and
+   // new values (92 register copies per point, spills).  Two records in flight were measured too: no gain, the launch runs at the
+   // HBM rate of its traffic already.
+   auto step = [&](const int q, auto pre) {
+      rows(rn, q + 1 < P2N ? q + 1 : q);      // scalar loads for the next point, a whole point ahead of their use
+      double gx[3][3], T[3][3];
+      mf_gather_p2(r, sX, XR, gx);
+      mf_point_p2<BBAR, TRANS>(rec, gx, W[q], dbar, sbar, T);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (decltype(pre)::value) load(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mf_scatter_p2(r, T, Y);
+      r = rn;
+   };
+#pragma unroll 1
+   for (int q = 0; q < P2N - 1; q++) step(q, std::true_type{});
+   step(P2N - 1, std::false_type{});
+   // re-read conn and eDS here: carried across the point loop they cost 27 + 162 registers, i.e. scratch traffic inside the loop
+   // (and a scratch load waits for the record prefetch in front of it)
+   const double* eDS2 = eDS; asm volatile("" : "+s"(eDS2));
+#pragma unroll
+   for (int a = 0; a < P2N; a++) {
+      const int gi = conn[a + P2N * e];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+         double v = Y[a + P2N * c];
+         if (BBAR) v += eDS2[eds_off(e, P2N, a, c)] * sbar;
+         atomicAdd(&y[gi + (int64_t)nnodes * c], v);
+      }
+      if (a % 9 == 8) __builtin_amdgcn_sched_barrier(0);
+   }
+}
+#undef P2X
 
 __global__ __launch_bounds__(PA_BLK) void k_ea_diag_gen(const int E, const int nd, const double* __restrict__ emat, double* __restrict__ y) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
@@ -256,6 +464,24 @@ int exa_launch_ea_apply_gen(exa_ctx* ctx, const double* x, double* y, bool lvec,
       if (lvec) hipLaunchKernelGGL((k_ea_apply_gen<27, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
       else hipLaunchKernelGGL((k_ea_apply_gen<27, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
    } else { ctx->err = "element assembly is built for p = 1 and p = 2"; return EXA_ERR_UNSUPPORTED; }
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
+// matrix-free p = 2 action on L-vectors; `trans` selects the operator of the assembled matrices (EA) instead of the PA one
+int exa_launch_mf_apply_p2(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, bool trans, hipStream_t s) {
+   if (ctx->n != 27 || ctx->Q != 27) { ctx->err = "matrix-free action is built for p = 2 (27 nodes, 27 points)"; return EXA_ERR_UNSUPPORTED; }
+   const unsigned nb = nblk(ctx->E, PA_BLK); const bool bbar = ctx->cfg.integ == EXA_INTEG_BBAR;
+   if (!ctx->T1_dev) {   // one-dimensional tables + a check of the node numbering the kernel has compiled in
+      std::vector<double> t1; std::vector<int> nat;
+      exa_build_1d_tables(2, t1, nat);
+      static const int expect[27] = { 0, 8, 1, 11, 20, 9, 3, 10, 2, 16, 21, 17, 24, 26, 22, 19, 23, 18, 4, 12, 5, 15, 25, 13, 7, 14, 6 };
+      for (int i = 0; i < 27; i++) if (nat[i] != expect[i]) { ctx->err = "matrix-free p = 2 action: node numbering mismatch"; return EXA_ERR_STATE; }
+      EXA_HIP_CHECK(ctx, hipMalloc(&ctx->T1_dev, sizeof(double) * t1.size()));
+      EXA_HIP_CHECK(ctx, hipMemcpy(ctx->T1_dev, t1.data(), sizeof(double) * t1.size(), hipMemcpyHostToDevice));
+   }
+#define MF_LAUNCH(B, T) hipLaunchKernelGGL((k_mf_apply_p2<B, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, ctx->T1_dev, ctx->W_dev, ctx->eDS, x, y, ctx->conn, ctx->nnodes, mask, gate)
+   if (bbar) { if (trans) MF_LAUNCH(true, true); else MF_LAUNCH(true, false); }
+   else { if (trans) MF_LAUNCH(false, true); else MF_LAUNCH(false, false); }
+#undef MF_LAUNCH
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_ea_diag_gen(exa_ctx* ctx, double* y, hipStream_t s) {

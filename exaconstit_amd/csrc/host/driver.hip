@@ -218,7 +218,7 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    if (!ctx_) throw std::runtime_error("exa_create failed (" + std::to_string(err) + ")");
    nn_ = part.NN; nd_ = 3 * nn_; E_ = part.E; npe_ = part.n;
    fast_p1_ = (part.p == 1 && !bbar);          // fused L-vector kernels exist for p = 1 full integration
-   lvec_grad_ = fast_p1_ || opt.assembly == Assembly::EA;
+   lvec_grad_ = fast_p1_ || opt.assembly == Assembly::EA || part.p == 2;   // p = 2: matrix-free action from the point records (PA and EA)
    fused_setup_ = std::getenv("EXA_UNFUSED_SETUP") == nullptr;
    // tail split of the constitutive launch (include/exaconstit_hip.h): EXA_NEWTON_CAP=off | <K> | unset (chosen from the evaluation-count histogram of the previous launch)
    // The controller runs for the Kocks-Mecking family only: for the Voce kernels the model never finds a paying cap in steady state and
@@ -229,6 +229,10 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
       else { cap_auto_ = false; newton_cap_ = (std::string(nc) == "off") ? 0 : std::atoi(nc); }
    }
    tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.5 : 4.0;
+   // p = 2 element assembly: the 81 x 81 matrices are 5x the bytes of the records they are built from, so the action is computed from
+   // the records and the matrices only exist if somebody asks for them (diagonal, export); EXA_EA_ASSEMBLED=1 streams them instead
+   if (opt.assembly == Assembly::EA && part.p == 2 && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1"))
+      abi_check(ctx_, exa_set_ea_matrix_free(ctx_, 1), "exa_set_ea_matrix_free");
    abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 path (EXA_QLAYOUT=aos switches back for A/B runs)
    const char* ql = std::getenv("EXA_QLAYOUT");

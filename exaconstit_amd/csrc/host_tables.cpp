@@ -92,6 +92,18 @@ void exa_build_ref_elem(int p, std::vector<double>& G, std::vector<double>& W) {
    }
 }
 
+void exa_build_1d_tables(int p, std::vector<double>& T1, std::vector<int>& nat) {
+   const int np = p + 1;
+   std::vector<double> xq, wq, xn, v, d;
+   gl_rule(np, xq, wq); gll_nodes(np, xn);
+   T1.assign((size_t)np * 2 * np, 0.0);
+   for (int q = 0; q < np; q++) {
+      lagrange(xn, xq[q], v, d);
+      for (int i = 0; i < np; i++) { T1[2 * np * q + i] = v[i]; T1[2 * np * q + np + i] = d[i]; }
+   }
+   nat = native_order(p);
+}
+
 bool exa_fill_mat_params(const exa_config& cfg, ecmdev::MatParams& mp, double* hist_init, std::string& err) {
    using namespace ecmdev;
    mp = MatParams{};

@@ -138,6 +138,11 @@ int exa_grad_apply_lvec(exa_ctx* ctx, const double* x_lvec_dev, double* y_lvec_d
  * were computed from.  When set, exa_grad_apply_lvec recomputes adj(J) from them instead of streaming it from its per-point record
  * (36 instead of 46 doubles per point from HBM); the array must stay unchanged until the next exa_grad_setup.  NULL switches it off. */
 int exa_grad_set_coords(exa_ctx* ctx, const double* coords_lvec_dev);
+/* Element assembly at p = 2: with `on` != 0 exa_grad_setup stops after the per-point records (and the element-average gradients
+ * of the B-bar integrator) and exa_grad_apply_lvec computes the action of the element matrices from them (same operator, 10 KB
+ * instead of 52 KB per element from HBM).  The matrices themselves are assembled on the first call that needs them
+ * (exa_grad_apply on E-vectors, exa_grad_diagonal, exa_grad_get_ea).  No effect at p = 1.  Default: off. */
+int exa_set_ea_matrix_free(exa_ctx* ctx, int on);
 /* fused AssemblePA + AddMultPA + E->L: y_L += B^T sigma */
 int exa_residual_lvec(exa_ctx* ctx, const double* jacobian_dev, const double* stress1_dev, double* y_lvec_dev, exa_stream s);
 /* volume average  sum_q W detJ val / sum_q W detJ  (src/mechanics_kernels.hpp:19-134); out_host[vdim] (+ volume in out_host[vdim]).

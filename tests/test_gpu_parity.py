@@ -301,6 +301,31 @@ def test_generic_order_and_bbar_integrators(oracle, p, assembly, integ):
         d_xL = dev.up(xL); d_mask = dev.up(mask); d_yL = dev.zeros(3 * NN)
         ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xL), ptr(d_yL), ptr(d_mask), None))
         assert rel_l2(d_yL.cpu().numpy(), yL_ref) < 1e-12
+        if p == 2:
+            # the same operator without the matrices: action computed from the point records (k_mf_apply_p2, Ct^T flavour)
+            ctx.check(L.exa_set_ea_matrix_free(ctx.h, 1))
+            ctx.check(L.exa_grad_setup(ctx.h, dt, ptr(d_J), ptr(d_C), None))
+            d_yL2 = dev.zeros(3 * NN)
+            ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xL), ptr(d_yL2), ptr(d_mask), None))
+            assert rel_l2(d_yL2.cpu().numpy(), yL_ref) < 1e-12
+            # matrices still available on demand
+            d_em2 = dev.zeros(9 * n * n * E)
+            ctx.check(L.exa_grad_get_ea(ctx.h, ptr(d_em2), None))
+            assert rel_l2(d_em2.cpu().numpy(), emat) < 1e-12
+    elif p == 2:
+        # partial assembly, fused L-vector action at p = 2 (same kernel, Ct flavour), with and without a mask
+        d_conn = dev.up(rve["conn"]); ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+        xL = rng.standard_normal(3 * NN); conn = rve["conn"].reshape(E, n)
+        for mask in ((rng.uniform(size=3 * NN) < 0.1).astype(np.uint8), None):
+            ye = np.zeros(3 * n * E)
+            xin = xL if mask is None else np.where(mask, 0.0, xL)
+            orc.lib().orc_add_mult_grad_pa(Q, E, n, orc._p(rve["G"]), orc._p(D4), orc._p(hipref.l_to_e(rve, xin)), orc._p(ye))
+            yL_ref = np.zeros(3 * NN)
+            for c in range(3):
+                np.add.at(yL_ref, conn + NN * c, ye.reshape(E, 3, n)[:, c, :])
+            d_xL = dev.up(xL); d_mask = dev.up(mask) if mask is not None else None; d_yL = dev.zeros(3 * NN)
+            ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xL), ptr(d_yL), ptr(d_mask) if d_mask is not None else None, None))
+            assert rel_l2(d_yL.cpu().numpy(), yL_ref) < 1e-12
     ctx.close()
 
 
