@@ -331,12 +331,17 @@ void NonlinearMechOperator::GetGradient() {
    // geometry of the action recomputed from x_cur (unchanged until the next residual evaluation); EXA_APPLY_GEO=off streams it instead
    if (fast_p1_ && opt_.assembly == Assembly::PA && !(std::getenv("EXA_APPLY_GEO") && std::string(std::getenv("EXA_APPLY_GEO")) == "off"))
       abi_check(ctx_, exa_grad_set_coords(ctx_, x_cur.p), "exa_grad_set_coords");
-   el_y_.zero(stream_);
-   abi_check(ctx_, exa_grad_diagonal(ctx_, el_y_.p, stream_), "exa_grad_diagonal");
-   diag.zero(stream_);
-   abi_check(ctx_, exa_restrict_transpose_add(ctx_, el_y_.p, diag.p, stream_), "exa_restrict_transpose_add");
-   comm_.halo_sum(part_, diag.p, stream_);
-   vk_mask_one(nd_, ess_mask.p, diag.p, stream_);
+   // The reference assembles the operator diagonal here on every call, but its Jacobi smoother never reads it (dinv is built once
+   // from diag = 1).  With that default the assembly is skipped: no result depends on it, and for p = 2 element
+   // assembly it would be the only consumer of the 81 x 81 matrices.
+   if (precond != Precond::IDENTITY) {
+      el_y_.zero(stream_);
+      abi_check(ctx_, exa_grad_diagonal(ctx_, el_y_.p, stream_), "exa_grad_diagonal");
+      diag.zero(stream_);
+      abi_check(ctx_, exa_restrict_transpose_add(ctx_, el_y_.p, diag.p, stream_), "exa_restrict_transpose_add");
+      comm_.halo_sum(part_, diag.p, stream_);
+      vk_mask_one(nd_, ess_mask.p, diag.p, stream_);
+   }
    vk_jacobi_setup(nd_, ess_mask.p, diag.p, precond == Precond::IDENTITY ? 1 : 0, dinv.p, stream_);
 }
 
