@@ -27,6 +27,7 @@ int exa_launch_residual_bbar(exa_ctx*, const double*, const double*, double*, hi
 int exa_launch_assemble_ea_gen(exa_ctx*, hipStream_t);
 int exa_launch_ea_apply_gen(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t);
 int exa_launch_mf_apply_p2(exa_ctx*, const double*, double*, const uint8_t*, const double*, bool, hipStream_t);
+int exa_launch_residual_p2(exa_ctx*, const double*, const double*, double*, hipStream_t);
 int exa_launch_ea_diag_gen(exa_ctx*, double*, hipStream_t);
 int exa_launch_ea_export_gen(exa_ctx*, double*, hipStream_t);
 int exa_launch_pa_apply_gen(exa_ctx*, const double*, double*, hipStream_t);
@@ -91,8 +92,8 @@ int exa_shape_table(const exa_ctx* ctx, double* G_host, double* W_host) {
 
 int exa_set_quadrature_layout(exa_ctx* ctx, int layout) {
    if (!ctx || (layout != EXA_QLAYOUT_AOS && layout != EXA_QLAYOUT_EB64)) return fail(ctx, EXA_ERR_ARG, "exa_set_quadrature_layout: bad argument");
-   if (layout == EXA_QLAYOUT_EB64 && (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL))
-      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_set_quadrature_layout: the element-blocked layout is built for p = 1 full integration");
+   if (layout == EXA_QLAYOUT_EB64 && !((ctx->p == 1 && ctx->cfg.integ == EXA_INTEG_FULL) || ctx->p == 2))
+      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_set_quadrature_layout: the element-blocked layout is built for p = 1 full integration and for p = 2");
    ctx->qblk = (layout == EXA_QLAYOUT_EB64); ctx->have_resid = false; ctx->have_grad = false;
    return EXA_OK;
 }
@@ -297,7 +298,11 @@ int exa_grad_apply_lvec(exa_ctx* ctx, const double* x, double* y, const uint8_t*
 int exa_residual_lvec(exa_ctx* ctx, const double* J, const double* stress1, double* y, exa_stream s) {
    if (!ctx || !J || !stress1 || !y) return fail(ctx, EXA_ERR_ARG, "exa_residual_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_residual_lvec: connectivity not set");
-   if (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL) return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_residual_lvec: fused path is built for p = 1 full integration; use exa_residual_setup/apply + exa_restrict_transpose_add");
+   if (ctx->p == 2) {
+      if (ctx->cfg.integ == EXA_INTEG_BBAR && !ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * PA_BLK * (size_t)((ctx->E + PA_BLK - 1) / PA_BLK)));
+      return exa_launch_residual_p2(ctx, J, stress1, y, S(s));
+   }
+   if (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL) return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_residual_lvec: fused path is built for p = 1 full integration and p = 2; use exa_residual_setup/apply + exa_restrict_transpose_add");
    return exa_launch_residual_p1(ctx, J, stress1, y, true, S(s));
 }
 

@@ -56,6 +56,7 @@ struct exa_ctx {
 };
 
 // host-side reference element (H1 hex of order p at (p+1)^3 Gauss-Legendre points), src/mechanics_operator.cpp:237-261
+int exa_ensure_p2_tables(struct exa_ctx* ctx);   // gen_kernels.hip
 void exa_build_ref_elem(int p, std::vector<double>& G, std::vector<double>& W);
 // one-dimensional tables [1D Gauss point][B_0..B_p, D_0..D_p] of the order-p nodal basis and the lexicographic -> native node map
 void exa_build_1d_tables(int p, std::vector<double>& T1, std::vector<int>& nat);

@@ -8,6 +8,7 @@
 // element streams them with loads that are contiguous across the wave; p = 2 (81 x 81 per element, 52 KB) is HBM-bound on exactly
 // this stream.  The p = 1 full-integration fast paths live in pa_kernels.hip.
 #include "exa_internal.hpp"
+#include "p2_basis.hpp"
 #include <type_traits>
 
 namespace {
@@ -17,8 +18,8 @@ __device__ __forceinline__ int64_t eag_off(int64_t blk, int nd, int j, int i) { 
 // element-average gradients, element-blocked like everything else a lane-per-element kernel streams: [block][dof a + n c][64 lanes]
 __device__ __forceinline__ int64_t eds_off(int64_t e, int n, int a, int c) { return ((e / PA_BLK) * (3 * n) + a + n * c) * PA_BLK + (e % PA_BLK); }
 
-__device__ __forceinline__ void adj_det(const double* Jq, double adj[9], double& detJ) {
-   const double J11 = Jq[0], J21 = Jq[1], J31 = Jq[2], J12 = Jq[3], J22 = Jq[4], J32 = Jq[5], J13 = Jq[6], J23 = Jq[7], J33 = Jq[8];
+__device__ __forceinline__ void adj_det(const double* Jq, double adj[9], double& detJ, const int64_t st = 1) {
+   const double J11 = Jq[0], J21 = Jq[st], J31 = Jq[2 * st], J12 = Jq[3 * st], J22 = Jq[4 * st], J32 = Jq[5 * st], J13 = Jq[6 * st], J23 = Jq[7 * st], J33 = Jq[8 * st];
    adj[0] = J22 * J33 - J23 * J32; adj[1] = J32 * J13 - J12 * J33; adj[2] = J12 * J23 - J22 * J13;
    adj[3] = J31 * J23 - J21 * J33; adj[4] = J11 * J33 - J13 * J31; adj[5] = J21 * J13 - J11 * J23;
    adj[6] = J21 * J32 - J31 * J22; adj[7] = J31 * J12 - J11 * J32; adj[8] = J11 * J22 - J12 * J21;
@@ -34,6 +35,7 @@ __device__ __forceinline__ void b_row(int c, const double b[3], double v, double
 }
 
 // eDS(a,t,e) = sum_q W_q (G adj)(a,t) / sum_q W_q detJ ; one thread per (node, element)
+template <bool QB>
 __global__ void k_eds(const int Q, const int n, const int E, const double* __restrict__ W, const double* __restrict__ G,
                       const double* __restrict__ J, double* __restrict__ eDS) {
    extern __shared__ double sG[];
@@ -44,7 +46,8 @@ __global__ void k_eds(const int Q, const int n, const int E, const double* __res
    const int a = (int)(t % n); const int64_t e = t / n;
    double acc[3] = { 0, 0, 0 }, vol = 0;
    for (int q = 0; q < Q; q++) {
-      double adj[9], detJ; adj_det(J + 9 * (q + (int64_t)Q * e), adj, detJ);
+      const QView vJ = qview<QB>(9, Q, e, q);
+      double adj[9], detJ; adj_det(J + vJ.base, adj, detJ, vJ.stride);
       const double w = W[q]; vol += w * detJ;
       const double g0 = sG[a + n * (3 * q)], g1 = sG[a + n * (3 * q + 1)], g2 = sG[a + n * (3 * q + 2)];
       for (int c = 0; c < 3; c++) acc[c] += w * (g0 * adj[c] + g1 * adj[3 + c] + g2 * adj[6 + c]);
@@ -174,60 +177,11 @@ __global__ __launch_bounds__(PA_BLK) void k_ea_apply_gen(const int E, const doub
 // instead of an 81-double table per point (which does not fit the SGPR file and stalls a lone wave on scalar loads).
 // Software pipeline: the record of point q+1 is requested as soon as the record of point q is consumed and lands behind the two
 // long register-only passes (scatter of q, gather of q+1: 2 x 270 FMAs) - at one wave per SIMD nothing else hides it.
-constexpr int P2N = 27, P2ND = 81, P2XL = 76;
-// lexicographic (i,j,k) -> native node of the triquadratic hexahedron (host_tables.cpp native_order(2); checked at launch)
-__device__ constexpr int P2NAT[27] = { 0, 8, 1, 11, 20, 9, 3, 10, 2, 16, 21, 17, 24, 26, 22, 19, 23, 18, 4, 12, 5, 15, 25, 13, 7, 14, 6 };
-
-// one-dimensional table rows live in the constant address space: wave-uniform reads become scalar loads
-typedef const __attribute__((address_space(4))) double* cptr;
-__device__ __forceinline__ cptr as_const(const double* p) { return (cptr)(uintptr_t)p; }
-
-struct Rows1D { double bx[3], dx[3], by[3], dy[3], bz[3], dz[3]; };
+constexpr int P2N = p2::N, P2ND = p2::ND, P2XL = 76;
+using p2::cptr; using p2::as_const;
+typedef p2::Rows Rows1D;
 
 #define P2X(i_) ((i_) < P2XL ? sX[(i_) * PA_BLK] : XR[(i_) < P2XL ? 0 : (i_) - P2XL])
-
-// gx[c][d] = sum_a x_{a,c} dN_a/dxi_d at one point
-__device__ __forceinline__ void mf_gather_p2(const Rows1D& r, const double* sX, const double (&XR)[P2ND - P2XL], double (&gx)[3][3]) {
-#pragma unroll
-   for (int c = 0; c < 3; c++) {
-      double bb[3] = { 0, 0, 0 }, bd[3] = { 0, 0, 0 }, db[3] = { 0, 0, 0 };     // per k: (Bx By), (Bx Dy), (Dx By) contracted over i, j
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-#pragma unroll
-         for (int j = 0; j < 3; j++) {
-            const double x0 = P2X(P2NAT[0 + 3 * j + 9 * k] + P2N * c), x1 = P2X(P2NAT[1 + 3 * j + 9 * k] + P2N * c), x2 = P2X(P2NAT[2 + 3 * j + 9 * k] + P2N * c);
-            const double ub = fma(r.bx[2], x2, fma(r.bx[1], x1, r.bx[0] * x0));
-            const double ud = fma(r.dx[2], x2, fma(r.dx[1], x1, r.dx[0] * x0));
-            bb[k] = fma(r.by[j], ub, bb[k]); bd[k] = fma(r.dy[j], ub, bd[k]); db[k] = fma(r.by[j], ud, db[k]);
-         }
-      }
-      gx[c][0] = fma(r.bz[2], db[2], fma(r.bz[1], db[1], r.bz[0] * db[0]));
-      gx[c][1] = fma(r.bz[2], bd[2], fma(r.bz[1], bd[1], r.bz[0] * bd[0]));
-      gx[c][2] = fma(r.dz[2], bb[2], fma(r.dz[1], bb[1], r.dz[0] * bb[0]));
-      __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from fetching all 81 LDS values up front (162 VGPRs)
-   }
-}
-
-// Y_{a,c} += sum_d dN_a/dxi_d T[d][c]
-__device__ __forceinline__ void mf_scatter_p2(const Rows1D& r, const double (&T)[3][3], double (&Y)[P2ND]) {
-#pragma unroll
-   for (int c = 0; c < 3; c++) {
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-         const double a0 = r.bz[k] * T[0][c], a1 = r.bz[k] * T[1][c], a2 = r.dz[k] * T[2][c];
-#pragma unroll
-         for (int j = 0; j < 3; j++) {
-            const double pd = r.by[j] * a0;                          // multiplies Dx[i]
-            const double pb = fma(r.by[j], a2, r.dy[j] * a1);        // multiplies Bx[i]
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-               const int idx = P2NAT[i + 3 * j + 9 * k] + P2N * c;
-               Y[idx] = fma(r.bx[i], pb, fma(r.dx[i], pd, Y[idx]));
-            }
-         }
-      }
-   }
-}
 
 template <bool BBAR, bool TRANS>
 __device__ __forceinline__ void mf_point_p2(const double2 (&rec)[PA_PAIRS], const double (&gx)[3][3], const double wq, const double dbar, double& sbar, double (&T)[3][3]) {
@@ -323,14 +277,7 @@ __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const doubl
    double sbar = 0.0;
    const cptr t1 = as_const(T1);
    Rows1D r, rn;
-   auto rows = [&](Rows1D& o, int q) {
-      const int qi = q % 3, qj = (q / 3) % 3, qk = q / 9;
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-         o.bx[d] = t1[6 * qi + d]; o.dx[d] = t1[6 * qi + 3 + d]; o.by[d] = t1[6 * qj + d]; o.dy[d] = t1[6 * qj + 3 + d];
-         o.bz[d] = t1[6 * qk + d]; o.dz[d] = t1[6 * qk + 3 + d];
-      }
-   };
+   auto rows = [&](Rows1D& o, int q) { p2::load_rows(t1, q, o); };
    rows(r, 0);
    // one point: gather, point arithmetic, request of the next record into the registers just consumed, scatter.  PRE is a
    // compile-time flag and the last point is peeled: a conditional prefetch would turn the record into a loop-carried phi of old and
@@ -339,12 +286,12 @@ __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const doubl
    auto step = [&](const int q, auto pre) {
       rows(rn, q + 1 < P2N ? q + 1 : q);      // scalar loads for the next point, a whole point ahead of their use
       double gx[3][3], T[3][3];
-      mf_gather_p2(r, sX, XR, gx);
+      p2::gather(r, [&](int a, int c) { return P2X(a + P2N * c); }, gx);
       mf_point_p2<BBAR, TRANS>(rec, gx, W[q], dbar, sbar, T);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (decltype(pre)::value) load(q + 1);
       __builtin_amdgcn_sched_barrier(0);
-      mf_scatter_p2(r, T, Y);
+      p2::scatter(r, T, Y);
       r = rn;
    };
 #pragma unroll 1
@@ -366,6 +313,56 @@ __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const doubl
    }
 }
 #undef P2X
+
+// ---- residual on L-vectors for p = 2, plain or B-bar (ExaNLFIntegrator / ICExaNLFIntegrator AssemblePA + AddMultPA fused with E->L) ---
+// y_a,c += sum_q W detJ B(-bar)_a,c . sigma.  One lane per element, points in sequence, y_e (81 doubles) in registers, the node
+// contraction as three one-dimensional passes (p2::scatter); 15 doubles per point from HBM, element-blocked or reference layout.
+template <bool BBAR, bool QB>
+__global__ __launch_bounds__(PA_BLK) void k_residual_p2(const int E, const double* __restrict__ T1, const double* __restrict__ W, const double* __restrict__ J,
+                                                        const double* __restrict__ S, const double* __restrict__ eDS, double* __restrict__ y,
+                                                        const int32_t* __restrict__ conn, const int nnodes) {
+   const int lane = threadIdx.x; const int64_t e = (int64_t)blockIdx.x * PA_BLK + lane;
+   if (e >= E) return;
+   double Y[P2ND];
+#pragma unroll
+   for (int i = 0; i < P2ND; i++) Y[i] = 0.0;
+   double sbar = 0.0;
+   const cptr t1 = as_const(T1);
+#pragma unroll 1
+   for (int q = 0; q < P2N; q++) {
+      Rows1D r; p2::load_rows(t1, q, r);
+      const QView vJ = qview<QB>(9, P2N, e, q), vS = qview<QB>(6, P2N, e, q);
+      double adj[9], detJ; adj_det(J + vJ.base, adj, detJ, vJ.stride);
+      const double* sp = S + vS.base; const double w = W[q];
+      const double sg[6] = { w * sp[0], w * sp[vS.stride], w * sp[2 * vS.stride], w * sp[3 * vS.stride], w * sp[4 * vS.stride], w * sp[5 * vS.stride] };
+      const double Sm[3][3] = { { sg[0], sg[5], sg[4] }, { sg[5], sg[1], sg[3] }, { sg[4], sg[3], sg[2] } };
+      double T[3][3];
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+         for (int c = 0; c < 3; c++) T[j][c] = adj[3 * j] * Sm[0][c] + adj[3 * j + 1] * Sm[1][c] + adj[3 * j + 2] * Sm[2][c];
+      if (BBAR) {   // (gbar - b)/3 tr(sigma): the -b part folds into T, the gbar part is element-constant
+         const double tr3 = (sg[0] + sg[1] + sg[2]) * (1.0 / 3.0);
+         sbar += detJ * tr3;
+#pragma unroll
+         for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) T[j][c] -= adj[3 * j + c] * tr3;
+      }
+      p2::scatter(r, T, Y);
+   }
+#pragma unroll
+   for (int a = 0; a < P2N; a++) {
+      const int gi = conn[a + P2N * e];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+         double v = Y[a + P2N * c];
+         if (BBAR) v += eDS[eds_off(e, P2N, a, c)] * sbar;
+         atomicAdd(&y[gi + (int64_t)nnodes * c], v);
+      }
+      if (a % 9 == 8) __builtin_amdgcn_sched_barrier(0);
+   }
+}
 
 __global__ __launch_bounds__(PA_BLK) void k_ea_diag_gen(const int E, const int nd, const double* __restrict__ emat, double* __restrict__ y) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
@@ -434,9 +431,11 @@ inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); 
 }  // namespace
 
 int exa_launch_residual_apply_from(exa_ctx* ctx, const double* D, double* Y, hipStream_t s);   // pa_kernels.hip
+int exa_launch_eds(exa_ctx* ctx, const double* J, hipStream_t s);
 
 int exa_launch_eds(exa_ctx* ctx, const double* J, hipStream_t s) {
-   hipLaunchKernelGGL(k_eds, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, ctx->eDS);
+   if (ctx->qblk) hipLaunchKernelGGL(k_eds<true>, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, ctx->eDS);
+   else hipLaunchKernelGGL(k_eds<false>, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, ctx->eDS);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_residual_bbar(exa_ctx* ctx, const double* J, const double* S, double* Y, hipStream_t s) {
@@ -466,18 +465,33 @@ int exa_launch_ea_apply_gen(exa_ctx* ctx, const double* x, double* y, bool lvec,
    } else { ctx->err = "element assembly is built for p = 1 and p = 2"; return EXA_ERR_UNSUPPORTED; }
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
+// one-dimensional basis tables of the p = 2 kernels + a check of the node numbering they have compiled in
+int exa_ensure_p2_tables(exa_ctx* ctx) {
+   if (ctx->T1_dev) return EXA_OK;
+   std::vector<double> t1; std::vector<int> nat;
+   exa_build_1d_tables(2, t1, nat);
+   static const int expect[27] = { 0, 8, 1, 11, 20, 9, 3, 10, 2, 16, 21, 17, 24, 26, 22, 19, 23, 18, 4, 12, 5, 15, 25, 13, 7, 14, 6 };
+   for (int i = 0; i < 27; i++) if (nat[i] != expect[i]) { ctx->err = "p = 2 kernels: node numbering mismatch"; return EXA_ERR_STATE; }
+   EXA_HIP_CHECK(ctx, hipMalloc(&ctx->T1_dev, sizeof(double) * t1.size()));
+   EXA_HIP_CHECK(ctx, hipMemcpy(ctx->T1_dev, t1.data(), sizeof(double) * t1.size(), hipMemcpyHostToDevice));
+   return EXA_OK;
+}
+// residual on L-vectors at p = 2 (B-bar: element-average gradients refreshed from J first)
+int exa_launch_residual_p2(exa_ctx* ctx, const double* J, const double* S, double* y, hipStream_t s) {
+   if (int rc = exa_ensure_p2_tables(ctx)) return rc;
+   const bool bbar = ctx->cfg.integ == EXA_INTEG_BBAR; const unsigned nb = nblk(ctx->E, PA_BLK);
+   if (bbar) { if (int rc = exa_launch_eds(ctx, J, s)) return rc; }
+#define RES_LAUNCH(B, QBV) hipLaunchKernelGGL((k_residual_p2<B, QBV>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->T1_dev, ctx->W_dev, J, S, ctx->eDS, y, ctx->conn, ctx->nnodes)
+   if (bbar) { if (ctx->qblk) RES_LAUNCH(true, true); else RES_LAUNCH(true, false); }
+   else { if (ctx->qblk) RES_LAUNCH(false, true); else RES_LAUNCH(false, false); }
+#undef RES_LAUNCH
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
 // matrix-free p = 2 action on L-vectors; `trans` selects the operator of the assembled matrices (EA) instead of the PA one
 int exa_launch_mf_apply_p2(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, bool trans, hipStream_t s) {
    if (ctx->n != 27 || ctx->Q != 27) { ctx->err = "matrix-free action is built for p = 2 (27 nodes, 27 points)"; return EXA_ERR_UNSUPPORTED; }
    const unsigned nb = nblk(ctx->E, PA_BLK); const bool bbar = ctx->cfg.integ == EXA_INTEG_BBAR;
-   if (!ctx->T1_dev) {   // one-dimensional tables + a check of the node numbering the kernel has compiled in
-      std::vector<double> t1; std::vector<int> nat;
-      exa_build_1d_tables(2, t1, nat);
-      static const int expect[27] = { 0, 8, 1, 11, 20, 9, 3, 10, 2, 16, 21, 17, 24, 26, 22, 19, 23, 18, 4, 12, 5, 15, 25, 13, 7, 14, 6 };
-      for (int i = 0; i < 27; i++) if (nat[i] != expect[i]) { ctx->err = "matrix-free p = 2 action: node numbering mismatch"; return EXA_ERR_STATE; }
-      EXA_HIP_CHECK(ctx, hipMalloc(&ctx->T1_dev, sizeof(double) * t1.size()));
-      EXA_HIP_CHECK(ctx, hipMemcpy(ctx->T1_dev, t1.data(), sizeof(double) * t1.size(), hipMemcpyHostToDevice));
-   }
+   if (int rc = exa_ensure_p2_tables(ctx)) return rc;
 #define MF_LAUNCH(B, T) hipLaunchKernelGGL((k_mf_apply_p2<B, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, ctx->T1_dev, ctx->W_dev, ctx->eDS, x, y, ctx->conn, ctx->nnodes, mask, gate)
    if (bbar) { if (trans) MF_LAUNCH(true, true); else MF_LAUNCH(true, false); }
    else { if (trans) MF_LAUNCH(false, true); else MF_LAUNCH(false, false); }

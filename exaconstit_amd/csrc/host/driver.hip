@@ -234,9 +234,10 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    if (opt.assembly == Assembly::EA && part.p == 2 && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1"))
       abi_check(ctx_, exa_set_ea_matrix_free(ctx_, 1), "exa_set_ea_matrix_free");
    abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
-   // internal quadrature-function layout: element-blocked on the fused p = 1 path (EXA_QLAYOUT=aos switches back for A/B runs)
+   // internal quadrature-function layout: element-blocked on the fused p = 1 and p = 2 paths (EXA_QLAYOUT=aos switches back for A/B runs)
    const char* ql = std::getenv("EXA_QLAYOUT");
-   if (fast_p1_ && !(ql && std::string(ql) == "aos")) abi_check(ctx_, exa_set_quadrature_layout(ctx_, EXA_QLAYOUT_EB64), "exa_set_quadrature_layout");
+   lvec_resid_ = fast_p1_ || part.p == 2;      // fused L-vector residual kernels (p = 1 full integration; p = 2 plain and B-bar)
+   if (lvec_resid_ && !(ql && std::string(ql) == "aos")) abi_check(ctx_, exa_set_quadrature_layout(ctx_, EXA_QLAYOUT_EB64), "exa_set_quadrature_layout");
    auto qf = [&](int vdim) { return (size_t)exa_qf_size(ctx_, vdim); };
    conn.upload(part.conn); abi_check(ctx_, exa_set_connectivity(ctx_, conn.p, nn_), "exa_set_connectivity");
    x_ref.upload(part.X); x_beg.upload(part.X); x_cur.upload(part.X);
@@ -313,7 +314,7 @@ template void NonlinearMechOperator::Setup<false>(const double*);
 
 void NonlinearMechOperator::ResidualAction(double* y) {
    EXA_HC(hipMemsetAsync(y, 0, sizeof(double) * nd_, stream_));
-   if (fast_p1_) abi_check(ctx_, exa_residual_lvec(ctx_, el_jac.p, stress1.p, y, stream_), "exa_residual_lvec");
+   if (lvec_resid_) abi_check(ctx_, exa_residual_lvec(ctx_, el_jac.p, stress1.p, y, stream_), "exa_residual_lvec");
    else {   // Hform->Setup() = AssemblePA, Hform->Mult = L->E, AddMultPA, E->L
       abi_check(ctx_, exa_residual_setup(ctx_, el_jac.p, stress1.p, stream_), "exa_residual_setup");
       el_y_.zero(stream_);

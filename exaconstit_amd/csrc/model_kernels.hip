@@ -7,6 +7,7 @@
 // ModelSetup signature) or fused L-vector gathers that also write the Jacobians; reference (AOS) or element-blocked quadrature-function
 // layout; run-time tail split of long local solves into a dense second launch.
 #include "exa_internal.hpp"
+#include "p2_basis.hpp"
 
 using namespace ecmdev;
 
@@ -31,9 +32,13 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
                                                      double* __restrict__ state1, double* __restrict__ cmat, int* __restrict__ fail,
                                                      const int kcap, int* __restrict__ tail, const int tail_mode) {
    const int n = NFIX ? NFIX : n_rt;
-   extern __shared__ double sG[];   // (n,3,Q)
-   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
-   __syncthreads();
+   constexpr bool P2F = (NFIX == 27);   // triquadratic fused path: G holds the 3 x 6 one-dimensional tables, read through scalar loads
+   extern __shared__ double sG[];   // (n,3,Q) shape table (not for P2F), then the per-thread stash
+   const int tab = P2F ? 0 : n * 3 * Q;
+   if (!P2F) {
+      for (int i = threadIdx.x; i < tab; i += blockDim.x) sG[i] = G[i];
+      __syncthreads();
+   }
    int q; int64_t e;
    if (tail_mode) {   // dense pass over the points the capped launch handed over: thread t owns point tail[1 + t]
       const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,6 +58,32 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    const QView vJ = qview<QB>(9, Q, e, q), vS = qview<QB>(6, Q, e, q), vV = qview<QB>(NSTATEV, Q, e, q), vC = qview<QB>(36, Q, e, q);
    const double* Gq = sG + 3 * n * q;
    double J11, J21, J31, J12, J22, J32, J13, J23, J33;
+   double L[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+   if constexpr (P2F) {
+      static_assert(!P2F || LVEC, "the triquadratic fused path gathers from L-vectors");
+      // both node contractions as three one-dimensional passes (p2_basis.hpp); q is wave-uniform except in the tail launch
+      const int qu = (QB && !tail_mode) ? __builtin_amdgcn_readfirstlane(q) : q;
+      p2::Rows r; p2::load_rows(p2::as_const(G), qu, r);
+      const int32_t* ce = conn + (int64_t)27 * e;
+      int gn[27];
+#pragma unroll
+      for (int a = 0; a < 27; a++) gn[a] = ce[a];
+      double gx[3][3];
+      p2::gather(r, [&](int a, int c) { return xl[gn[a] + (int64_t)nnodes * c]; }, gx);
+      J11 = gx[0][0]; J21 = gx[1][0]; J31 = gx[2][0]; J12 = gx[0][1]; J22 = gx[1][1]; J32 = gx[2][1]; J13 = gx[0][2]; J23 = gx[1][2]; J33 = gx[2][2];
+      double* Jo = Jio + vJ.base;
+      Jo[0] = J11; Jo[QS] = J21; Jo[2 * QS] = J31; Jo[3 * QS] = J12; Jo[4 * QS] = J22; Jo[5 * QS] = J32; Jo[6 * QS] = J13; Jo[7 * QS] = J23; Jo[8 * QS] = J33;
+      const double detJ = J11 * (J22 * J33 - J32 * J23) - J21 * (J12 * J33 - J32 * J13) + J31 * (J12 * J23 - J22 * J13);
+      const double di = 1.0 / detJ;
+      const double Ji[3][3] = { { di * (J22 * J33 - J23 * J32), di * (J32 * J13 - J12 * J33), di * (J12 * J23 - J22 * J13) },
+                                { di * (J31 * J23 - J21 * J33), di * (J11 * J33 - J13 * J31), di * (J21 * J13 - J11 * J23) },
+                                { di * (J21 * J32 - J31 * J22), di * (J31 * J12 - J11 * J32), di * (J11 * J22 - J12 * J21) } };
+      p2::gather(r, [&](int a, int c) { return vel[gn[a] + (int64_t)nnodes * c]; }, gx);   // dv_c / dxi_s
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+         for (int t = 0; t < 3; t++) L[c + 3 * t] = gx[c][0] * Ji[0][t] + gx[c][1] * Ji[1][t] + gx[c][2] * Ji[2][t];
+   } else {
    if (LVEC) {
       // J(i,j) = sum_r x_r,i dN_r/dxi_j   (column-major 3x3 per point, like MFEM's geometric factors after the re-layout)
       J11 = J21 = J31 = J12 = J22 = J32 = J13 = J23 = J33 = 0.0;
@@ -80,7 +111,6 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
                              { di * (J31 * J23 - J21 * J33), di * (J11 * J33 - J13 * J31), di * (J21 * J13 - J11 * J23) },
                              { di * (J21 * J32 - J31 * J22), di * (J31 * J12 - J11 * J32), di * (J11 * J22 - J12 * J21) } };
    // velocity gradient L(c,t) = sum_r v(r,c) dN_r/dx_t
-   double L[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
    const double* ve = vel + (int64_t)3 * n * e;
    const int32_t* ce = conn + (int64_t)n * e;
 #pragma unroll
@@ -96,8 +126,9 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
       L[3] += v0 * b1; L[4] += v1 * b1; L[5] += v2 * b1;
       L[6] += v0 * b2; L[7] += v1 * b2; L[8] += v2 * b2;
    }
+   }
    // per-thread stash behind the shape table in LDS: slot s of this thread at stash[s * 256 + threadIdx.x]
-   double* st = sG + n * 3 * Q + threadIdx.x;
+   double* st = sG + tab + threadIdx.x;
    const int rc = point_update<KIN, QS>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, cmat + vC.base, st, kcap);
    if (rc == 2) { const int slot = atomicAdd(&tail[0], 1); tail[1 + slot] = (int)(e * Q + q); }
    else if (rc) atomicAdd(fail, 1);
@@ -168,14 +199,15 @@ static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel
    const int bs = 256;
    // QB: one wave per (64-element block, q)
    const int64_t nb = QB ? (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64) : (ctx->P + bs - 1) / bs;
-   const size_t lds = sizeof(double) * ((size_t)ctx->n * 3 * ctx->Q + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE);
+   const size_t lds = sizeof(double) * ((NFIX == 27 ? (size_t)0 : (size_t)ctx->n * 3 * ctx->Q) + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE);
+   const double* G = NFIX == 27 ? ctx->T1_dev : ctx->G_dev;
    static_assert(ECM_STASH_STRIDE == 256, "stash stride must equal the block size");
    const bool split = ctx->newton_cap > 0 && ctx->tail_dev != nullptr;
-   hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+   hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
                       ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, split ? ctx->newton_cap : (1 << 30), ctx->tail_dev, 0);
    if (split) {   // same kernel, thread = listed point, uncapped.  The grid covers the worst case; blocks beyond the list exit at once.
       const int64_t nbt = (ctx->P + bs - 1) / bs;
-      hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nbt), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+      hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nbt), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
                          ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, 1 << 30, ctx->tail_dev, 1);
    }
 }
@@ -191,6 +223,7 @@ template <int KIN, bool LVEC>
 static void launch_model(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
                          double* stress1, double* state1, double* cmat, hipStream_t s) {
    if (LVEC && ctx->n == 8) launch_model_n<KIN, LVEC, 8>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+   else if (LVEC && ctx->n == 27 && ctx->qblk) launch_model_q<KIN, true, 27, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);   // T1 uploaded by the caller
    else launch_model_n<KIN, LVEC, 0>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
 }
 
@@ -203,6 +236,7 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
       EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->tail_dev, 0, sizeof(int), s));
    }
    const bool lv = xl != nullptr;
+   if (lv && ctx->n == 27 && ctx->qblk) { if (int rc = exa_ensure_p2_tables(ctx)) return rc; }
    switch (ctx->mp.kin) {
       case KIN_VOCE:
          if (lv) launch_model<KIN_VOCE, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);

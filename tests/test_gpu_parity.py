@@ -428,9 +428,64 @@ def test_element_blocked_layout_matches_aos(oracle, model, pkey):
         for k in a:
             tol = 1e-13 if k in ("J", "vgrad", "dp") else 1e-11      # the fused kernel's thread mapping differs (same arithmetic per point)
             assert rel_l2(b[k], a[k]) < tol, (assembly, k)
-    p2 = L.Context(0, _props(orc, "voce"), 298.0, 2, 8)
-    assert L.exa_set_quadrature_layout(p2.h, L.EXA_QLAYOUT_EB64) == -4
-    p2.close()
+    p3 = L.Context(0, _props(orc, "voce"), 298.0, 3, 8)
+    assert L.exa_set_quadrature_layout(p3.h, L.EXA_QLAYOUT_EB64) == -4      # built for p = 1 full integration and p = 2
+    p3.close()
+
+
+@pytest.mark.parametrize("integ,assembly,cap", [(0, 0, 0), (1, 1, 0), (0, 1, 4)])
+def test_element_blocked_layout_p2(oracle, integ, assembly, cap):
+    """p = 2 (plain and B-bar) in the element-blocked layout: the fused constitutive launch with its sum-factorised node gathers
+    (NFIX = 27, also through the tail split), the L-vector residual kernel and the matrix-free action give the numbers of the
+    reference-layout path; the L-vector residual equals the E-vector AssemblePA/AddMultPA pair.  E = 27 (partial block)."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 3, p=2, distort=0.1)
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    props = _props(orc, "voce")
+    quats = hipref.random_quats(E)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    v_nodes = hipref.velocity_field(rve, scale=2.0)
+    res = {}
+    for layout in (L.EXA_QLAYOUT_AOS, L.EXA_QLAYOUT_EB64):
+        ctx = L.Context(L.EXA_FCC_VOCE, props, 298.0, 2, E, assembly=assembly, integ=integ)
+        ctx.check(L.exa_set_quadrature_layout(ctx.h, layout))
+        ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+        if layout == L.EXA_QLAYOUT_EB64: ctx.check(L.exa_set_newton_cap(ctx.h, cap))
+        if assembly == 1: ctx.check(L.exa_set_ea_matrix_free(ctx.h, 1))
+        sz = lambda w: int(L.exa_qf_size(ctx.h, w))
+        aos = (lambda t, w: t.view(-1, w)[:P]) if layout == L.EXA_QLAYOUT_AOS else (lambda t, w: _eb64_to_aos(t, E, Q, w))
+        sv = [dev.zeros(sz(28)), dev.zeros(sz(28))]; sg = [dev.zeros(sz(6)), dev.zeros(sz(6))]
+        cm = dev.zeros(sz(36)); J = dev.zeros(sz(9))
+        d_quats_keep = dev.up(quats.ravel())
+        ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(d_quats_keep), None))
+        d_x = dev.up(rve["X"]); d_v = dev.up(v_nodes)
+        for dt in (0.2, 0.3, 0.5):
+            d_x += dt * d_v
+            ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(sg[0]), ptr(sv[0]), ptr(sg[1]), ptr(sv[1]), ptr(cm), ptr(J), None))
+            assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+            sv.reverse(); sg.reverse()
+        if layout == L.EXA_QLAYOUT_EB64 and cap: assert L.exa_model_tail_count(ctx.h, None) > 0
+        out = dict(state=aos(sv[0], 28).cpu().numpy(), stress=aos(sg[0], 6).cpu().numpy(), cm=aos(cm, 36).cpu().numpy(), J=aos(J, 9).cpu().numpy())
+        y = dev.zeros(3 * NN); ctx.check(L.exa_residual_lvec(ctx.h, ptr(J), ptr(sg[0]), ptr(y), None)); out["resid"] = y.cpu().numpy()
+        if layout == L.EXA_QLAYOUT_AOS:   # the reference's E-vector pair gives the same residual
+            ye = dev.zeros(3 * n * E); yl = dev.zeros(3 * NN)
+            ctx.check(L.exa_residual_setup(ctx.h, ptr(J), ptr(sg[0]), None)); ctx.check(L.exa_residual_apply(ctx.h, ptr(ye), None))
+            ctx.check(L.exa_restrict_transpose_add(ctx.h, ptr(ye), ptr(yl), None))
+            assert rel_l2(out["resid"], yl.cpu().numpy()) < 1e-12
+        ctx.check(L.exa_grad_setup(ctx.h, 0.5, ptr(J), ptr(cm), None))
+        xg = dev.up(np.random.default_rng(1).standard_normal(3 * NN)); yg = dev.zeros(3 * NN)
+        ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(xg), ptr(yg), None, None)); out["apply"] = yg.cpu().numpy()
+        avg = np.zeros(7); ctx.check(L.exa_vol_avg(ctx.h, ptr(J), ptr(sg[0]), 6, 1, avg.ctypes.data_as(C.POINTER(C.c_double)), None)); out["avg"] = avg.copy()
+        res[layout] = out
+        ctx.close()
+    a, b = res[L.EXA_QLAYOUT_AOS], res[L.EXA_QLAYOUT_EB64]
+    for k in a:
+        tol = 1e-13 if k == "J" else 1e-11      # different summation order of the node gathers (sum factorisation), same arithmetic per point after that
+        assert rel_l2(b[k], a[k]) < tol, k
 
 
 @pytest.mark.parametrize("model,pkey,cap", [(0, "voce", 4), (5, "mts", 3), (4, "mts", 5)])
