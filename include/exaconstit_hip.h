@@ -64,8 +64,8 @@ int exa_shape_table(const exa_ctx* ctx, double* G_host /*(n,3,Q)*/, double* W_ho
  *   EXA_QLAYOUT_AOS  (default) the reference's QuadratureFunction layout (vdim, Q, E), first index fastest;
  *   EXA_QLAYOUT_EB64 [block of 64 elements][q][component][lane = element], exa_qf_size(ctx, vdim) doubles per field.  It is the
  *                    internal layout of the stand-alone driver (every per-value access of a wave is one contiguous 512-byte row:
- *                    the constitutive launch is 1.4x faster at 128^3); p = 1 full integration with the L-vector entry points only
- *                    (exa_residual_setup / exa_residual_apply stay AOS).  An MFEM adapter keeps AOS. */
+ *                    the constitutive launch is 1.4x faster at 128^3); p = 1 full integration and p = 2 (plain or B-bar) with
+ *                    the L-vector entry points only (exa_residual_setup / exa_residual_apply stay AOS).  An MFEM adapter keeps AOS. */
 enum { EXA_QLAYOUT_AOS = 0, EXA_QLAYOUT_EB64 = 1 };
 int exa_set_quadrature_layout(exa_ctx* ctx, int layout);
 int64_t exa_qf_size(const exa_ctx* ctx, int vdim);
@@ -143,7 +143,8 @@ int exa_grad_set_coords(exa_ctx* ctx, const double* coords_lvec_dev);
  * instead of 52 KB per element from HBM).  The matrices themselves are assembled on the first call that needs them
  * (exa_grad_apply on E-vectors, exa_grad_diagonal, exa_grad_get_ea).  No effect at p = 1.  Default: off. */
 int exa_set_ea_matrix_free(exa_ctx* ctx, int on);
-/* fused AssemblePA + AddMultPA + E->L: y_L += B^T sigma */
+/* fused AssemblePA + AddMultPA + E->L: y_L += B^T sigma (p = 1 full integration; p = 2 full integration and B-bar, where the
+ * element-average gradients are refreshed from the Jacobians first: ICExaNLFIntegrator::AssemblePA + AddMultPA) */
 int exa_residual_lvec(exa_ctx* ctx, const double* jacobian_dev, const double* stress1_dev, double* y_lvec_dev, exa_stream s);
 /* volume average  sum_q W detJ val / sum_q W detJ  (src/mechanics_kernels.hpp:19-134); out_host[vdim] (+ volume in out_host[vdim]).
  * Synchronises the stream. */
