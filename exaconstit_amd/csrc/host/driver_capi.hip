@@ -189,11 +189,8 @@ int exa_options_query(const char* toml_path, double* out, char* err, int errlen)
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }
 
-int exa_partition_query(const int* N, int rank, int nranks, int64_t* info, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
-                        int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs) {
-   Partition p; const double L[3] = { 1.0, 1.0, 1.0 };
-   const int order = (info[7] == 2) ? 2 : 1;   // info[7] is in/out: H1 order on input (0/1 -> 1), nodes per element on output
-   p.build(N, L, rank, nranks, order);
+static void export_partition(const Partition& p, int64_t* info, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
+                             int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs) {
    int64_t shared = 0; for (auto& nb : p.nbrs) shared += (int64_t)nb.dofs.size();
    info[0] = p.E; info[1] = p.NN; info[2] = (int64_t)p.nbrs.size(); info[3] = p.pg[0]; info[4] = p.pg[1]; info[5] = p.pg[2]; info[6] = shared; info[7] = p.n;
    if (conn) std::memcpy(conn, p.conn.data(), sizeof(int32_t) * p.conn.size());
@@ -207,7 +204,24 @@ int exa_partition_query(const int* N, int rank, int nranks, int64_t* info, int32
       if (nbr_dofs) std::memcpy(nbr_dofs + off, p.nbrs[i].dofs.data(), sizeof(int32_t) * p.nbrs[i].dofs.size());
       off += p.nbrs[i].dofs.size();
    }
+}
+
+int exa_partition_query(const int* N, int rank, int nranks, int64_t* info, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
+                        int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs) {
+   Partition p; const double L[3] = { 1.0, 1.0, 1.0 };
+   const int order = (info[7] == 2) ? 2 : 1;   // info[7] is in/out: H1 order on input (0/1 -> 1), nodes per element on output
+   p.build(N, L, rank, nranks, order);
+   export_partition(p, info, conn, X, elem_gid, weight, nbr_rank, nbr_count, nbr_dofs);
    return 0;
+}
+
+int exa_mesh_partition_query(const char* mesh_path, int rank, int nranks, int64_t* info, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
+                             int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs, char* err, int errlen) {
+   try {
+      Partition p; p.build_from_mfem_mesh(mesh_path, rank, nranks);
+      export_partition(p, info, conn, X, elem_gid, weight, nbr_rank, nbr_count, nbr_dofs);
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }
 
 }  // extern "C"

@@ -2,7 +2,8 @@
 //   mesh generation : what the reference gets from Mesh::MakeCartesian3D(nx,ny,nz,HEX,sx,sy,sz,sfc=false)
 //                     (reference src/mechanics_driver.cpp:247-253): vertices and elements x-fastest, p = 1 native vertex order
 //   boundary ids    : reference src/mechanics_driver.cpp:1207-1227 (1 z-min, 2 x-min, 3 y-min, 4 z-max, 5 x-max, 6 y-max)
-//   decomposition   : replaces ParMesh/METIS (reference src/mechanics_driver.cpp:312) by a structured block split; interface
+//   decomposition   : replaces ParMesh/METIS (reference src/mechanics_driver.cpp:312) by a structured block split (generated
+//                     meshes) or a recursive coordinate bisection of the element centroids (file meshes); interface
 //                     nodes are duplicated on every rank that touches them and kept consistent by a neighbour halo-sum
 //                     (equivalent to the reference's P^T followed by P, spec src/mechanics_operator_ext.cpp:149-157).
 #pragma once
@@ -116,9 +117,11 @@ struct Partition {
    // MFEM mesh v1.0 reader for trilinear hexahedra (what the reference gets from `Mesh(mesh_file, 1, 1, true)`, src/mechanics_driver.cpp:239-241;
    // format of workflows/Stage3/main_simulations/simulation.mesh): sections `dimension`, `elements` (attr geom=5 v0..v7, MFEM vertex order =
    // this repo's native order), `boundary` (attr geom=3 v0..v3), `vertices` with inline coordinates or a `nodes` grid function (H1 order 1).
-   // One rank only: there is no graph partitioner here (the reference uses METIS through ParMesh).
+   // Every rank reads the whole file; with more than one rank the elements are split by recursive coordinate bisection of their
+   // centroids (the reference uses METIS through ParMesh, src/mechanics_driver.cpp:312; any partition gives the same operator) and the
+   // rank keeps its elements, the nodes they touch, and one Neighbor per rank it shares nodes with (dofs ordered by global node id on
+   // both sides).
    void build_from_mfem_mesh(const std::string& path, int rank_, int nranks_) {
-      if (nranks_ != 1) throw std::runtime_error("Mesh.type = \"other\": file meshes run on one rank (no graph partitioner in this driver)");
       std::ifstream f(path);
       if (!f) throw std::runtime_error("Cannot open mesh file: " + path);
       auto next_token_line = [&](std::string& line) {   // next non-empty, non-comment line
@@ -169,6 +172,65 @@ struct Partition {
       bdr_nodes.assign(maxattr, std::vector<uint8_t>(NN, 0));
       for (auto& q : bdr) for (int a = 0; a < 4; a++) bdr_nodes[q[0] - 1][q[1 + a]] = 1;
       weight.assign(NN, 1.0); nbrs.clear();
+      if (nranks > 1) localize(rcb_owner(nranks));
+   }
+
+   // element -> rank by recursive coordinate bisection: split the longest extent of the centroid cloud at the element count that
+   // matches the share of ranks on each side; deterministic (ties broken by element index), so every rank computes the same map
+   std::vector<int> rcb_owner(int nr) const {
+      std::vector<std::array<double, 3>> c(E);
+      for (int e = 0; e < E; e++) for (int d = 0; d < 3; d++) { double v = 0; for (int a = 0; a < n; a++) v += X[conn[a + (size_t)n * e] + (size_t)NN * d]; c[e][d] = v / n; }
+      std::vector<int> owner(E, 0), ids(E);
+      for (int e = 0; e < E; e++) ids[e] = e;
+      struct Job { int lo, hi, r0, nr; };
+      std::vector<Job> st; st.push_back({ 0, E, 0, nr });
+      while (!st.empty()) {
+         const Job j = st.back(); st.pop_back();
+         if (j.nr == 1) { for (int i = j.lo; i < j.hi; i++) owner[ids[i]] = j.r0; continue; }
+         double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+         for (int i = j.lo; i < j.hi; i++) for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], c[ids[i]][d]); hi[d] = std::max(hi[d], c[ids[i]][d]); }
+         int ax = 0; for (int d = 1; d < 3; d++) if ((hi[d] - lo[d]) > (hi[ax] - lo[ax]) * (1.0 + 1e-12)) ax = d;
+         const int nl = j.nr / 2; const int cut = j.lo + (int)(((int64_t)(j.hi - j.lo) * nl) / j.nr);
+         std::sort(ids.begin() + j.lo, ids.begin() + j.hi, [&](int a, int b) { return c[a][ax] != c[b][ax] ? c[a][ax] < c[b][ax] : a < b; });
+         st.push_back({ j.lo, cut, j.r0, nl }); st.push_back({ cut, j.hi, j.r0 + nl, j.nr - nl });
+      }
+      return owner;
+   }
+
+   // keep this rank's elements (original order) and the nodes they touch; build weights and neighbour lists from the global picture
+   void localize(const std::vector<int>& owner) {
+      const int NNg = NN, Eg = E;
+      std::vector<std::vector<int>> sharers(NNg);   // ranks touching each global node (sorted, unique)
+      for (int e = 0; e < Eg; e++) for (int a = 0; a < n; a++) { auto& v = sharers[conn[a + (size_t)n * e]]; if (std::find(v.begin(), v.end(), owner[e]) == v.end()) v.push_back(owner[e]); }
+      for (auto& v : sharers) std::sort(v.begin(), v.end());
+      std::vector<int> l2g, g2l(NNg, -1);
+      for (int g = 0; g < NNg; g++) if (std::binary_search(sharers[g].begin(), sharers[g].end(), rank)) { g2l[g] = (int)l2g.size(); l2g.push_back(g); }
+      const int NNl = (int)l2g.size();
+      std::vector<int32_t> lconn; std::vector<int> lattr; std::vector<int64_t> lgid;
+      for (int e = 0; e < Eg; e++) if (owner[e] == rank) {
+         for (int a = 0; a < n; a++) lconn.push_back(g2l[conn[a + (size_t)n * e]]);
+         lattr.push_back(elem_attr[e]); lgid.push_back(e);
+      }
+      std::vector<double> lX((size_t)3 * NNl);
+      for (int l = 0; l < NNl; l++) for (int d = 0; d < 3; d++) lX[l + (size_t)NNl * d] = X[l2g[l] + (size_t)NNg * d];
+      std::vector<std::vector<uint8_t>> lb(bdr_nodes.size(), std::vector<uint8_t>(NNl, 0));
+      for (size_t k = 0; k < bdr_nodes.size(); k++) for (int l = 0; l < NNl; l++) lb[k][l] = bdr_nodes[k][l2g[l]];
+      weight.assign(NNl, 1.0);
+      std::vector<std::vector<int>> shared_with(nranks);   // local nodes shared with each other rank, ascending global id (l2g is ascending)
+      for (int l = 0; l < NNl; l++) {
+         const auto& v = sharers[l2g[l]];
+         weight[l] = 1.0 / (double)v.size();
+         for (int r : v) if (r != rank) shared_with[r].push_back(l);
+      }
+      nbrs.clear();
+      for (int r = 0; r < nranks; r++) if (!shared_with[r].empty()) {
+         Neighbor nb; nb.rank = r;
+         for (int c = 0; c < 3; c++) for (int l : shared_with[r]) nb.dofs.push_back(l + NNl * c);
+         nbrs.push_back(std::move(nb));
+      }
+      conn.swap(lconn); elem_attr.swap(lattr); elem_gid.swap(lgid); X.swap(lX); bdr_nodes.swap(lb);
+      E = (int)elem_gid.size(); NN = NNl;
+      if (E == 0) throw std::runtime_error("mesh: a rank received no elements (more ranks than the partitioner can serve)");
    }
 
    // is local node g on global boundary face id?

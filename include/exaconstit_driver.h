@@ -65,6 +65,11 @@ int exa_choose_newton_cap(const int* hist64, double tail_cost);
  * conn (n,E) native node order, X (NN,3 byNODES), elem_gid (E), weight (NN), nbr_rank (nneighbors), nbr_count (nneighbors), nbr_dofs (concatenated) */
 int exa_partition_query(const int* N, int rank, int nranks, int64_t* info8, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
                         int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs);
+/* the same view of the partition of an MFEM mesh v1.0 file (Mesh.type = "other"): every rank reads the file, elements are split by
+ * recursive coordinate bisection of their centroids (reference: METIS through ParMesh, src/mechanics_driver.cpp:312), elem_gid = index
+ * of the element in the file, nodes renumbered per rank in ascending global order.  Returns 0 or -1 (err). */
+int exa_mesh_partition_query(const char* mesh_path, int rank, int nranks, int64_t* info8, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
+                             int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs, char* err, int errlen);
 #ifdef __cplusplus
 }
 #endif

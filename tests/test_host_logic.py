@@ -108,3 +108,53 @@ def test_tail_split_controller():
     assert cap({3: 87029, 4: 21603, 5: 404, 6: 191, 7: 196, 8: 42, 9: 1, 10: 8, 11: 160, 12: 197, 13: 222}, 1.5) == 4
     assert cap({3: 36464, 4: 29018, 5: 16278, 6: 8254, 7: 2499, 8: 1509, 9: 2919, 10: 4377, 11: 4438, 12: 2875, 13: 1529}, 1.5) == 6
     assert cap({}, 1.5) == 0 and cap({4: 1000}, 1.5) == 0
+
+
+@pytest.mark.parametrize("mesh,nranks", [("cube5_shuffled.mesh", 2), ("cube5_shuffled.mesh", 3), ("cube5_nodes.mesh", 8)])
+def test_file_mesh_partition_invariants(mesh, nranks):
+    """Partition of an MFEM mesh file (recursive coordinate bisection, exa_mesh_partition_query): every element on exactly one rank,
+    balanced counts, weights of a node's copies sum to one, neighbour lists symmetric and in the same (global node id) order on
+    both sides, local coordinates = the file's coordinates."""
+    import ctypes as C
+    import exaconstit_amd.lib as L
+    path = os.path.join(REF, mesh).encode()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def query(rank, nr):
+        info = (C.c_int64 * 8)(); err = C.create_string_buffer(256)
+        assert L.exa_mesh_partition_query(path, rank, nr, info, None, None, None, None, None, None, None, err, 256) == 0, err.value
+        E, NN, nnb, shared, n = info[0], info[1], info[2], info[6], info[7]
+        conn = np.zeros(n * E, np.int32); X = np.zeros(3 * NN); gid = np.zeros(E, np.int64); w = np.zeros(NN)
+        nrk = np.zeros(max(nnb, 1), np.int32); ncnt = np.zeros(max(nnb, 1), np.int32); nd = np.zeros(max(shared, 1), np.int32)
+        assert L.exa_mesh_partition_query(path, rank, nr, info, vp(conn), vp(X), vp(gid), vp(w), vp(nrk), vp(ncnt), vp(nd), err, 256) == 0
+        nb = {}; off = 0
+        for i in range(nnb):
+            nb[int(nrk[i])] = nd[off:off + ncnt[i]].copy(); off += ncnt[i]
+        return dict(E=E, NN=NN, conn=conn.reshape(E, n), X=X.reshape(3, NN), gid=gid, w=w, nb=nb)
+
+    whole = query(0, 1)
+    assert whole["E"] == 125 and whole["NN"] == 216 and not whole["nb"] and np.all(whole["w"] == 1.0)
+    parts = [query(r, nranks) for r in range(nranks)]
+    gids = np.concatenate([p["gid"] for p in parts])
+    assert sorted(gids.tolist()) == list(range(125))
+    counts = [p["E"] for p in parts]
+    assert max(counts) - min(counts) <= max(1, nranks // 2)
+    key = lambda X: [tuple(np.round(X[:, i], 9)) for i in range(X.shape[1])]
+    wsum = {}
+    for p in parts:
+        # local element geometry = the file's element geometry
+        for le, ge in enumerate(p["gid"]):
+            assert np.allclose(p["X"][:, p["conn"][le]], whole["X"][:, whole["conn"][ge]], atol=0)
+        for k, w in zip(key(p["X"]), p["w"]):
+            wsum[k] = wsum.get(k, 0.0) + w
+    assert len(wsum) == 216 and all(abs(v - 1.0) < 1e-12 for v in wsum.values())
+    for r, p in enumerate(parts):
+        for r2, dofs in p["nb"].items():
+            other = parts[r2]["nb"][r]
+            assert len(dofs) == len(other) and len(dofs) % 3 == 0
+            m = len(dofs) // 3
+            a = p["X"][:, dofs[:m] % p["NN"]]; b = parts[r2]["X"][:, other[:m] % parts[r2]["NN"]]
+            assert np.array_equal(a, b)                                   # same nodes in the same order on both sides
+            assert np.array_equal(dofs[m:2 * m] - dofs[:m], np.full(m, p["NN"]))
+    err = C.create_string_buffer(256); info = (C.c_int64 * 8)()
+    assert L.exa_mesh_partition_query(b"/nonexistent.mesh", 0, 2, info, None, None, None, None, None, None, None, err, 256) == -1 and b"Cannot open" in err.value
