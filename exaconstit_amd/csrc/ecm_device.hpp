@@ -350,8 +350,8 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
             gw += tail ? temp * at0[a] : 0.0;
             dgw += tail ? temp * mp.xnn * g_i : 0.0;
             const bool valid = inwin[a] && (gw > 0.0);
-            const double r1 = 1.0 / gw, r2 = 1.0 / gr[a];
-            const double gd = 1.0 / (r1 + r2);
+            const double r1 = frcp(gw), r2 = frcp(gr[a]);   // series combination of the two branches; lanes that are not `valid` may hold junk here
+            const double gd = frcp(r1 + r2);
             if (valid) { gdot[a] = copysign(gd, tau[a]); if (WITHD) dg[a] = gd * gd * (dgw * r1 * r1 + dgr[a] * r2 * r2); }
          }
       }
