@@ -28,6 +28,7 @@ int exa_launch_assemble_ea_gen(exa_ctx*, hipStream_t);
 int exa_launch_ea_apply_gen(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t);
 int exa_launch_mf_apply_p2(exa_ctx*, const double*, double*, const uint8_t*, const double*, bool, hipStream_t);
 int exa_launch_residual_p2(exa_ctx*, const double*, const double*, double*, hipStream_t);
+int exa_launch_tangent_defect(exa_ctx*, const double*, unsigned long long*, hipStream_t);
 int exa_launch_ea_diag_gen(exa_ctx*, double*, hipStream_t);
 int exa_launch_ea_export_gen(exa_ctx*, double*, hipStream_t);
 int exa_launch_pa_apply_gen(exa_ctx*, const double*, double*, hipStream_t);
@@ -74,7 +75,7 @@ exa_ctx* exa_create(const exa_config* cfg, int* err) {
 void exa_destroy(exa_ctx* ctx) {
    if (!ctx) return;
    (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->tail_dev); (void)hipFree(ctx->scratch_dev);
-   (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->T1_dev); (void)hipFree(ctx->tbuf);
+   (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->T1_dev); (void)hipFree(ctx->pa_c); (void)hipFree(ctx->tbuf);
    delete ctx;
 }
 
@@ -196,6 +197,25 @@ static int assemble_ea(exa_ctx* ctx, hipStream_t s) {
    return rc;
 }
 
+int exa_set_tangent_form(exa_ctx* ctx, int form) {
+   if (!ctx || (form != EXA_TANGENT_FULL && form != EXA_TANGENT_DEV5_BULK)) return fail(ctx, EXA_ERR_ARG, "exa_set_tangent_form: bad argument");
+   ctx->tangent_form = form;
+   if (form == EXA_TANGENT_FULL && ctx->pa_c) { (void)hipFree(ctx->pa_c); ctx->pa_c = nullptr; }
+   return EXA_OK;
+}
+
+int exa_grad_tangent_defect(exa_ctx* ctx, const double* C, double* defect_host, exa_stream s) {
+   if (!ctx || !C || !defect_host) return fail(ctx, EXA_ERR_ARG, "exa_grad_tangent_defect: null pointer");
+   unsigned long long* slot = reinterpret_cast<unsigned long long*>(ctx->scratch_dev);
+   int rc = exa_launch_tangent_defect(ctx, C, slot, S(s));
+   if (rc) return rc;
+   unsigned long long bits = 0;
+   EXA_HIP_CHECK(ctx, hipMemcpyAsync(&bits, slot, sizeof(bits), hipMemcpyDeviceToHost, S(s)));
+   EXA_HIP_CHECK(ctx, hipStreamSynchronize(S(s)));
+   std::memcpy(defect_host, &bits, sizeof(double));
+   return EXA_OK;
+}
+
 int exa_set_ea_matrix_free(exa_ctx* ctx, int on) {
    if (!ctx) return EXA_ERR_ARG;
    ctx->ea_matfree = on != 0; return EXA_OK;
@@ -204,6 +224,8 @@ int exa_set_ea_matrix_free(exa_ctx* ctx, int on) {
 int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, exa_stream s) {
    if (!ctx || !J || !C) return fail(ctx, EXA_ERR_ARG, "exa_grad_setup: null pointer");
    if (!ctx->pa) { EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa, pa_bytes(ctx->E, ctx->Q))); EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa, 0, pa_bytes(ctx->E, ctx->Q), S(s))); }
+   if (ctx->tangent_form == EXA_TANGENT_DEV5_BULK && ctx->p == 1 && ctx->cfg.assembly == EXA_ASSEMBLY_PA && ctx->cfg.integ == EXA_INTEG_FULL && !ctx->pa_c)
+      EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa_c, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 26 * PA_BLK * sizeof(double)));
    int rc = exa_launch_grad_setup_pa(ctx, dt, J, C, S(s));
    if (rc) return rc;
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {

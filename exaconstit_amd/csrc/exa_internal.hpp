@@ -47,6 +47,8 @@ struct exa_ctx {
    bool have_resid = false, have_grad = false;
    // L-vector support
    const int32_t* conn = nullptr; int nnodes = 0;
+   double* pa_c = nullptr;                  // compact tangent records (25 + 1 per point) of the geometry-recomputing p = 1 action; allocated when the form is selected
+   int tangent_form = 0;                    // EXA_TANGENT_*
    const double* coords_lvec = nullptr;     // optional: nodal coordinates the Jacobians of exa_grad_setup came from (geometry recomputed in the apply)
    // status
    int* fail_count_dev = nullptr;

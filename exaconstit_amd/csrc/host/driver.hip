@@ -233,6 +233,9 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    // the records and the matrices only exist if somebody asks for them (diagonal, export); EXA_EA_ASSEMBLED=1 streams them instead
    if (opt.assembly == Assembly::EA && part.p == 2 && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1"))
       abi_check(ctx_, exa_set_ea_matrix_free(ctx_, 1), "exa_set_ea_matrix_free");
+   compact_tangent_ = fast_p1_ && opt.assembly == Assembly::PA && !(std::getenv("EXA_APPLY_GEO") && std::string(std::getenv("EXA_APPLY_GEO")) == "off")
+                      && !(std::getenv("EXA_TANGENT_FORM") && std::string(std::getenv("EXA_TANGENT_FORM")) == "full");
+   if (compact_tangent_) abi_check(ctx_, exa_set_tangent_form(ctx_, EXA_TANGENT_DEV5_BULK), "exa_set_tangent_form");
    abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 and p = 2 paths (EXA_QLAYOUT=aos switches back for A/B runs)
    const char* ql = std::getenv("EXA_QLAYOUT");
@@ -328,6 +331,17 @@ void NonlinearMechOperator::ResidualAction(double* y) {
 void NonlinearMechOperator::Mult(const double* k, double* y) { Setup<true>(k); ResidualAction(y); }
 
 void NonlinearMechOperator::GetGradient() {
+   // compact tangent form of the p = 1 PA action (include/exaconstit_hip.h): valid for ExaCMech tangents; verified on the data of
+   // every call (one pass over the tangent field, one 8-byte read-back per Newton iteration) and dropped for good if it ever fails
+   if (compact_tangent_) {
+      double defect = 0.0;
+      abi_check(ctx_, exa_grad_tangent_defect(ctx_, matGrad.p, &defect, stream_), "exa_grad_tangent_defect");
+      if (!(defect < 1e-11)) {
+         compact_tangent_ = false;
+         abi_check(ctx_, exa_set_tangent_form(ctx_, EXA_TANGENT_FULL), "exa_set_tangent_form");
+         if (comm_.rank == 0) std::cerr << "tangent is not of the deviatoric-block + bulk form (defect " << defect << "): streaming the full tangent\n";
+      }
+   }
    abi_check(ctx_, exa_grad_setup(ctx_, dt_, el_jac.p, matGrad.p, stream_), "exa_grad_setup");
    // geometry of the action recomputed from x_cur (unchanged until the next residual evaluation); EXA_APPLY_GEO=off streams it instead
    if (fast_p1_ && opt_.assembly == Assembly::PA && !(std::getenv("EXA_APPLY_GEO") && std::string(std::getenv("EXA_APPLY_GEO")) == "off"))

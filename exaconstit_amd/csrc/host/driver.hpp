@@ -115,7 +115,7 @@ class NonlinearMechOperator {
    exa_ctx* ctx_ = nullptr; std::unique_ptr<ExaCMechModel> model_;
    hipStream_t stream_ = nullptr; hipEvent_t ev0_, ev1_;
    int nn_, nd_, E_, npe_ = 8; double dt_ = 1.0;
-   bool fast_p1_ = true, lvec_grad_ = true, fused_setup_ = true; bool lvec_resid_ = false;
+   bool fast_p1_ = true, lvec_grad_ = true, fused_setup_ = true; bool lvec_resid_ = false; bool compact_tangent_ = false;
    bool cap_auto_ = true; int newton_cap_ = 0; double tail_cost_ = 4.0;
    DevBuf<double> tmp_l_, tmp_r_, el_y_, el_x2_;
 };

@@ -138,6 +138,16 @@ int exa_grad_apply_lvec(exa_ctx* ctx, const double* x_lvec_dev, double* y_lvec_d
  * were computed from.  When set, exa_grad_apply_lvec recomputes adj(J) from them instead of streaming it from its per-point record
  * (36 instead of 46 doubles per point from HBM); the array must stay unchanged until the next exa_grad_setup.  NULL switches it off. */
 int exa_grad_set_coords(exa_ctx* ctx, const double* coords_lvec_dev);
+/* Form of the tangent the p = 1 partial-assembly action streams when the geometry is recomputed (exa_grad_set_coords):
+ *   EXA_TANGENT_FULL       (default) the 36 entries of ddsdde;
+ *   EXA_TANGENT_DEV5_BULK  ddsdde = V65 D V65^T + K m m^T, m = (1,1,1,0,0,0): a 5 x 5 block in the deviatoric vector basis of ExaCMech
+ *                          plus a bulk term - what every ExaCMech evptn model returns (26 numbers, 13 instead of 18 16-byte loads per point).
+ *                          exa_grad_setup projects ddsdde onto that form; the projection is exact only if the tangent has the form, which
+ *                          exa_grad_tangent_defect measures (max over the points of |C - projection|_max / |C|_max; ~1e-16 for ExaCMech
+ *                          tangents).  The caller is responsible for checking it; the stand-alone driver does on every GetGradient. */
+enum { EXA_TANGENT_FULL = 0, EXA_TANGENT_DEV5_BULK = 1 };
+int exa_set_tangent_form(exa_ctx* ctx, int form);
+int exa_grad_tangent_defect(exa_ctx* ctx, const double* ddsdde_dev, double* defect_host, exa_stream s);
 /* Element assembly at p = 2: with `on` != 0 exa_grad_setup stops after the per-point records (and the element-average gradients
  * of the B-bar integrator) and exa_grad_apply_lvec computes the action of the element matrices from them (same operator, 10 KB
  * instead of 52 KB per element from HBM).  The matrices themselves are assembled on the first call that needs them

@@ -563,3 +563,49 @@ def test_abi_error_behaviour(oracle):
     assert ctx.check(L.exa_model_status(ctx.h, None)) == 0 and nf == 0
     assert rel_l2(o[0].cpu().numpy(), s1) < 1e-9 and rel_l2(o[2].cpu().numpy(), cm) < 1e-7
     ctx.close()
+
+
+@pytest.mark.parametrize("model,pkey", [(0, "voce"), (2, "voce"), (5, "mts")])
+def test_compact_tangent_form(oracle, model, pkey):
+    """EXA_TANGENT_DEV5_BULK: the tangents the constitutive kernel returns have the deviatoric-block + bulk form to round-off
+    (exa_grad_tangent_defect), so the geometry-recomputing p = 1 action may stream 26 instead of 36 numbers per point: same action
+    as the full form.  A generic 6 x 6 tangent does not have the form and the defect says so."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 5, distort=0.15)
+    E, Q, NN = rve["E"], rve["Q"], rve["NN"]
+    P = E * Q
+    props = _props(orc, pkey)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    v_nodes = hipref.velocity_field(rve, scale=2.0)
+    for layout in (L.EXA_QLAYOUT_AOS, L.EXA_QLAYOUT_EB64):
+        ctx = L.Context(model, props, 298.0, 1, E)
+        ctx.check(L.exa_set_quadrature_layout(ctx.h, layout)); ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+        sz = lambda w: int(L.exa_qf_size(ctx.h, w))
+        sv = [dev.zeros(sz(28)), dev.zeros(sz(28))]; sg = [dev.zeros(sz(6)), dev.zeros(sz(6))]; cm = dev.zeros(sz(36)); J = dev.zeros(sz(9))
+        d_q = dev.up(hipref.random_quats(E).ravel())
+        ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(d_q), None))
+        d_x = dev.up(rve["X"]); d_v = dev.up(v_nodes)
+        xg = dev.up(np.random.default_rng(2).standard_normal(3 * NN)); mask = torch.zeros(3 * NN, dtype=torch.uint8, device=dev.dev)
+        for dt in (0.05, 0.3, 0.5):     # elastic, transition, plastic tangents
+            d_x += dt * d_v
+            ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(sg[0]), ptr(sv[0]), ptr(sg[1]), ptr(sv[1]), ptr(cm), ptr(J), None))
+            assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+            sv.reverse(); sg.reverse()
+            defect = C.c_double(1.0)
+            ctx.check(L.exa_grad_tangent_defect(ctx.h, ptr(cm), C.byref(defect), None))
+            assert defect.value < 1e-13, defect.value
+            ys = []
+            for form in (L.EXA_TANGENT_FULL, L.EXA_TANGENT_DEV5_BULK):
+                ctx.check(L.exa_set_tangent_form(ctx.h, form))
+                ctx.check(L.exa_grad_setup(ctx.h, dt, ptr(J), ptr(cm), None))
+                ctx.check(L.exa_grad_set_coords(ctx.h, ptr(d_x)))
+                y = dev.zeros(3 * NN); ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(xg), ptr(y), ptr(mask), None)); ys.append(y.cpu().numpy())
+            assert rel_l2(ys[1], ys[0]) < 1e-13
+        if layout == L.EXA_QLAYOUT_AOS:
+            d_r = dev.up(_spd_tangent(P)); defect = C.c_double(0.0)
+            ctx.check(L.exa_grad_tangent_defect(ctx.h, ptr(d_r), C.byref(defect), None))
+            assert defect.value > 1e-3
+        ctx.close()
