@@ -200,7 +200,7 @@ static int assemble_ea(exa_ctx* ctx, hipStream_t s) {
 int exa_set_tangent_form(exa_ctx* ctx, int form) {
    if (!ctx || (form != EXA_TANGENT_FULL && form != EXA_TANGENT_DEV5_BULK)) return fail(ctx, EXA_ERR_ARG, "exa_set_tangent_form: bad argument");
    ctx->tangent_form = form;
-   if (form == EXA_TANGENT_FULL && ctx->pa_c) { (void)hipFree(ctx->pa_c); ctx->pa_c = nullptr; }
+   if (form == EXA_TANGENT_FULL && ctx->pa_c) { (void)hipFree(ctx->pa_c); ctx->pa_c = nullptr; ctx->pac_pairs = 0; }
    return EXA_OK;
 }
 
@@ -224,8 +224,14 @@ int exa_set_ea_matrix_free(exa_ctx* ctx, int on) {
 int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, exa_stream s) {
    if (!ctx || !J || !C) return fail(ctx, EXA_ERR_ARG, "exa_grad_setup: null pointer");
    if (!ctx->pa) { EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa, pa_bytes(ctx->E, ctx->Q))); EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa, 0, pa_bytes(ctx->E, ctx->Q), S(s))); }
-   if (ctx->tangent_form == EXA_TANGENT_DEV5_BULK && ctx->p == 1 && ctx->cfg.assembly == EXA_ASSEMBLY_PA && ctx->cfg.integ == EXA_INTEG_FULL && !ctx->pa_c)
-      EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa_c, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 26 * PA_BLK * sizeof(double)));
+   if (ctx->tangent_form == EXA_TANGENT_DEV5_BULK && !ctx->pa_c) {   // compact records for the actions that can stream them
+      const bool p1 = ctx->p == 1 && ctx->cfg.assembly == EXA_ASSEMBLY_PA && ctx->cfg.integ == EXA_INTEG_FULL;   // k_grad_apply_p1<.., GEO, CMP>
+      const bool p2 = ctx->n == 27 && (ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree);               // k_mf_apply_p2<.., CMP>
+      if (p1 || p2) {
+         ctx->pac_pairs = p1 ? PAC_PAIRS : PAC_PAIRS_GEO;
+         EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa_c, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 2 * ctx->pac_pairs * PA_BLK * sizeof(double)));
+      }
+   }
    int rc = exa_launch_grad_setup_pa(ctx, dt, J, C, S(s));
    if (rc) return rc;
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {

@@ -49,6 +49,7 @@ struct exa_ctx {
    const int32_t* conn = nullptr; int nnodes = 0;
    double* pa_c = nullptr;                  // compact tangent records (25 + 1 per point) of the geometry-recomputing p = 1 action; allocated when the form is selected
    int tangent_form = 0;                    // EXA_TANGENT_*
+   int pac_pairs = 0;                       // 16-byte pairs per point of the compact record: 13 (D, K) at p = 1, 18 (+ geometry) at p = 2
    const double* coords_lvec = nullptr;     // optional: nodal coordinates the Jacobians of exa_grad_setup came from (geometry recomputed in the apply)
    // status
    int* fail_count_dev = nullptr;
@@ -77,5 +78,58 @@ __device__ __forceinline__ QView qview(int W, int Q, int64_t e, int q) {
 static inline size_t exa_qf_doubles(const exa_ctx* ctx, int vdim) {
    return ctx->qblk ? (size_t)vdim * 64 * ctx->Q * ((ctx->E + 63) / 64) : (size_t)vdim * ctx->P;
 }
+
+#ifdef __HIPCC__
+// ---- compact tangent form (include/exaconstit_hip.h, EXA_TANGENT_DEV5_BULK) ----------------------------------------------------
+// d sigma / d eps = V65 D V65^T + K m m^T: a 5 x 5 block in ExaCMech's deviatoric vector basis plus the bulk term, m = (1,1,1,0,0,0).
+constexpr int PAC_PAIRS = 13;       // compact record of the p = 1 action: 25 D entries + K, scaled by dt W / detJ
+constexpr int PAC_PAIRS_GEO = 18;   // compact record of the p = 2 action: the same + adj(J) (9) + W detJ
+template <int NP>
+__device__ __forceinline__ int64_t pac_off(int64_t blk, int Q, int q, int pair) { return (((blk * Q + q) * NP + pair) * PA_BLK) * 2; }
+constexpr double C_SQR2I = 0.70710678118654752440, C_SQR6I = 0.40824829046386301637;
+__device__ __forceinline__ void v65t(const double c0, const double c1, const double c2, const double c3, const double c4, const double c5, double o[5]) {
+   o[0] = C_SQR2I * (c0 - c1); o[1] = C_SQR6I * (2.0 * c2 - c0 - c1); o[2] = C_SQR2I * c5; o[3] = C_SQR2I * c4; o[4] = C_SQR2I * c3;
+}
+// D = L^-1 V65^T C V65 L^-1 with L = V65^T V65 = diag(1,1,1/2,1/2,1/2), K = m^T C m / 9 (exact when C has the form above)
+__device__ __forceinline__ void tangent_to_d55(const double* c, const int64_t st, double D[25], double& K) {
+   double T[5][6];
+#pragma unroll
+   for (int j = 0; j < 6; j++) {
+      double o[5]; v65t(c[(0 + 6 * j) * st], c[(1 + 6 * j) * st], c[(2 + 6 * j) * st], c[(3 + 6 * j) * st], c[(4 + 6 * j) * st], c[(5 + 6 * j) * st], o);
+#pragma unroll
+      for (int k = 0; k < 5; k++) T[k][j] = o[k];
+   }
+#pragma unroll
+   for (int k = 0; k < 5; k++) {
+      double o[5]; v65t(T[k][0], T[k][1], T[k][2], T[k][3], T[k][4], T[k][5], o);
+#pragma unroll
+      for (int l = 0; l < 5; l++) D[k + 5 * l] = o[l] * ((k < 2 ? 1.0 : 2.0) * (l < 2 ? 1.0 : 2.0));
+   }
+   double t = 0;
+#pragma unroll
+   for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) t += c[(i + 6 * j) * st];
+   K = t * (1.0 / 9.0);
+}
+// s = (V65 D V65^T + K m m^T) eps
+__device__ __forceinline__ void d55_apply(const double D[25], const double K, const double eps[6], double sg[6]) {
+   double e5[5], s5[5];
+   v65t(eps[0], eps[1], eps[2], eps[3], eps[4], eps[5], e5);
+#pragma unroll
+   for (int k = 0; k < 5; k++) s5[k] = D[k] * e5[0] + D[k + 5] * e5[1] + D[k + 10] * e5[2] + D[k + 15] * e5[3] + D[k + 20] * e5[4];
+   const double t1 = C_SQR2I * s5[0], t2 = C_SQR6I * s5[1], bk = K * (eps[0] + eps[1] + eps[2]);
+   sg[0] = t1 - t2 + bk; sg[1] = -t1 - t2 + bk; sg[2] = 2.0 * C_SQR6I * s5[1] + bk; sg[3] = C_SQR2I * s5[4]; sg[4] = C_SQR2I * s5[3]; sg[5] = C_SQR2I * s5[2];
+}
+// s = (V65 D^T V65^T + K m m^T) eps: the operator the assembled element matrices apply (k_ea_apply_gen)
+__device__ __forceinline__ void d55_apply_T(const double D[25], const double K, const double eps[6], double sg[6]) {
+   double e5[5], s5[5];
+   v65t(eps[0], eps[1], eps[2], eps[3], eps[4], eps[5], e5);
+#pragma unroll
+   for (int k = 0; k < 5; k++) s5[k] = D[5 * k] * e5[0] + D[5 * k + 1] * e5[1] + D[5 * k + 2] * e5[2] + D[5 * k + 3] * e5[3] + D[5 * k + 4] * e5[4];
+   const double t1 = C_SQR2I * s5[0], t2 = C_SQR6I * s5[1], bk = K * (eps[0] + eps[1] + eps[2]);
+   sg[0] = t1 - t2 + bk; sg[1] = -t1 - t2 + bk; sg[2] = 2.0 * C_SQR6I * s5[1] + bk; sg[3] = C_SQR2I * s5[4]; sg[4] = C_SQR2I * s5[3]; sg[5] = C_SQR2I * s5[2];
+}
+#endif
 
 static inline size_t pa_bytes(int E, int Q) { return (size_t)((E + PA_BLK - 1) / PA_BLK) * Q * PA_SLOTS * PA_BLK * sizeof(double); }

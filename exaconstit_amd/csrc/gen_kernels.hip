@@ -183,12 +183,15 @@ typedef p2::Rows Rows1D;
 
 #define P2X(i_) ((i_) < P2XL ? sX[(i_) * PA_BLK] : XR[(i_) < P2XL ? 0 : (i_) - P2XL])
 
-template <bool BBAR, bool TRANS>
-__device__ __forceinline__ void mf_point_p2(const double2 (&rec)[PA_PAIRS], const double (&gx)[3][3], const double wq, const double dbar, double& sbar, double (&T)[3][3]) {
-   double v[PA_SLOTS];
+// CMP: the record is the compact one (D 25, K, adj 9, W detJ: 18 pairs instead of 23)
+template <bool BBAR, bool TRANS, bool CMP>
+__device__ __forceinline__ void mf_point_p2(const double2 (&rec)[CMP ? PAC_PAIRS_GEO : PA_PAIRS], const double (&gx)[3][3], const double wq, const double dbar, double& sbar, double (&T)[3][3]) {
+   constexpr int NPR = CMP ? PAC_PAIRS_GEO : PA_PAIRS;
+   double v[2 * NPR];
 #pragma unroll
-   for (int pr = 0; pr < PA_PAIRS; pr++) { v[2 * pr] = rec[pr].x; v[2 * pr + 1] = rec[pr].y; }
-   const double* Ct = v; const double* adj = v + 36;
+   for (int pr = 0; pr < NPR; pr++) { v[2 * pr] = rec[pr].x; v[2 * pr + 1] = rec[pr].y; }
+   const double* Ct = v; const double* adj = v + (CMP ? 26 : 36);
+   const double wdet = v[CMP ? 35 : 45];
    double h[3][3];
 #pragma unroll
    for (int c = 0; c < 3; c++)
@@ -197,16 +200,19 @@ __device__ __forceinline__ void mf_point_p2(const double2 (&rec)[PA_PAIRS], cons
    double eps[6] = { h[0][0], h[1][1], h[2][2], h[1][2] + h[2][1], h[0][2] + h[2][0], h[0][1] + h[1][0] };
    double detJ = 0.0;
    if (BBAR) {   // volumetric part replaced by the element average: sum_dofs (detJ gbar - b)/3 x
-      detJ = v[45] / wq;
+      detJ = wdet / wq;
       const double vol = (detJ * dbar - (h[0][0] + h[1][1] + h[2][2])) * (1.0 / 3.0);
       eps[0] += vol; eps[1] += vol; eps[2] += vol;
    }
    double sg[6];
+   if (CMP) { if (TRANS) d55_apply_T(v, v[25], eps, sg); else d55_apply(v, v[25], eps, sg); }
+   else {
 #pragma unroll
-   for (int i = 0; i < 6; i++) { double t = 0;
+      for (int i = 0; i < 6; i++) { double t = 0;
 #pragma unroll
-      for (int j = 0; j < 6; j++) t += (TRANS ? Ct[j + 6 * i] : Ct[i + 6 * j]) * eps[j];
-      sg[i] = t; }
+         for (int j = 0; j < 6; j++) t += (TRANS ? Ct[j + 6 * i] : Ct[i + 6 * j]) * eps[j];
+         sg[i] = t; }
+   }
    const double Sm[3][3] = { { sg[0], sg[5], sg[4] }, { sg[5], sg[1], sg[3] }, { sg[4], sg[3], sg[2] } };
 #pragma unroll
    for (int j = 0; j < 3; j++)
@@ -223,7 +229,7 @@ __device__ __forceinline__ void mf_point_p2(const double2 (&rec)[PA_PAIRS], cons
 }
 
 // T1 = one-dimensional tables [1D point][B0 B1 B2 D0 D1 D2]
-template <bool BBAR, bool TRANS>
+template <bool BBAR, bool TRANS, bool CMP>
 __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const double* __restrict__ pa, const double* __restrict__ T1, const double* __restrict__ W,
                                                         const double* __restrict__ eDS, const double* __restrict__ x, double* __restrict__ y,
                                                         const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
@@ -234,11 +240,12 @@ __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const doubl
    if (gate != nullptr && gate[0] != 0.0) return;
    double* sX = sXall + lane;
    double XR[P2ND - P2XL]; double dbar = 0.0;
-   double2 rec[PA_PAIRS];
+   constexpr int NPR = CMP ? PAC_PAIRS_GEO : PA_PAIRS;
+   double2 rec[NPR];
    auto load = [&](int q) {
-      const double2* r = reinterpret_cast<const double2*>(pa + pa_off(blk, P2N, q, 0)) + lane;
+      const double2* r = reinterpret_cast<const double2*>(pa + (CMP ? pac_off<PAC_PAIRS_GEO>(blk, P2N, q, 0) : pa_off(blk, P2N, q, 0))) + lane;
 #pragma unroll
-      for (int pr = 0; pr < PA_PAIRS; pr++) rec[pr] = r[pr * PA_BLK];
+      for (int pr = 0; pr < NPR; pr++) rec[pr] = r[pr * PA_BLK];
    };
    load(0);
    int gidx[P2N];
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const doubl
       rows(rn, q + 1 < P2N ? q + 1 : q);      // scalar loads for the next point, a whole point ahead of their use
       double gx[3][3], T[3][3];
       p2::gather(r, [&](int a, int c) { return P2X(a + P2N * c); }, gx);
-      mf_point_p2<BBAR, TRANS>(rec, gx, W[q], dbar, sbar, T);
+      mf_point_p2<BBAR, TRANS, CMP>(rec, gx, W[q], dbar, sbar, T);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (decltype(pre)::value) load(q + 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -492,9 +499,15 @@ int exa_launch_mf_apply_p2(exa_ctx* ctx, const double* x, double* y, const uint8
    if (ctx->n != 27 || ctx->Q != 27) { ctx->err = "matrix-free action is built for p = 2 (27 nodes, 27 points)"; return EXA_ERR_UNSUPPORTED; }
    const unsigned nb = nblk(ctx->E, PA_BLK); const bool bbar = ctx->cfg.integ == EXA_INTEG_BBAR;
    if (int rc = exa_ensure_p2_tables(ctx)) return rc;
-#define MF_LAUNCH(B, T) hipLaunchKernelGGL((k_mf_apply_p2<B, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, ctx->T1_dev, ctx->W_dev, ctx->eDS, x, y, ctx->conn, ctx->nnodes, mask, gate)
-   if (bbar) { if (trans) MF_LAUNCH(true, true); else MF_LAUNCH(true, false); }
-   else { if (trans) MF_LAUNCH(false, true); else MF_LAUNCH(false, false); }
+#define MF_LAUNCH(B, T, CM) hipLaunchKernelGGL((k_mf_apply_p2<B, T, CM>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, CM ? ctx->pa_c : ctx->pa, ctx->T1_dev, ctx->W_dev, ctx->eDS, x, y, ctx->conn, ctx->nnodes, mask, gate)
+   const bool cm = ctx->pa_c != nullptr && ctx->pac_pairs == PAC_PAIRS_GEO;
+   if (cm) {
+      if (bbar) { if (trans) MF_LAUNCH(true, true, true); else MF_LAUNCH(true, false, true); }
+      else { if (trans) MF_LAUNCH(false, true, true); else MF_LAUNCH(false, false, true); }
+   } else {
+      if (bbar) { if (trans) MF_LAUNCH(true, true, false); else MF_LAUNCH(true, false, false); }
+      else { if (trans) MF_LAUNCH(false, true, false); else MF_LAUNCH(false, false, false); }
+   }
 #undef MF_LAUNCH
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }

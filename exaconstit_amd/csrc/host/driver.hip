@@ -233,7 +233,8 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    // the records and the matrices only exist if somebody asks for them (diagonal, export); EXA_EA_ASSEMBLED=1 streams them instead
    if (opt.assembly == Assembly::EA && part.p == 2 && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1"))
       abi_check(ctx_, exa_set_ea_matrix_free(ctx_, 1), "exa_set_ea_matrix_free");
-   compact_tangent_ = fast_p1_ && opt.assembly == Assembly::PA && !(std::getenv("EXA_APPLY_GEO") && std::string(std::getenv("EXA_APPLY_GEO")) == "off")
+   compact_tangent_ = ((fast_p1_ && opt.assembly == Assembly::PA && !(std::getenv("EXA_APPLY_GEO") && std::string(std::getenv("EXA_APPLY_GEO")) == "off"))
+                       || (part.p == 2 && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1")))
                       && !(std::getenv("EXA_TANGENT_FORM") && std::string(std::getenv("EXA_TANGENT_FORM")) == "full");
    if (compact_tangent_) abi_check(ctx_, exa_set_tangent_form(ctx_, EXA_TANGENT_DEV5_BULK), "exa_set_tangent_form");
    abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path

@@ -122,46 +122,9 @@ __global__ void k_residual_apply(const int Q, const int n, const int E, const do
 // Every ExaCMech evptn model returns d sigma / d eps = V65 D V65^T + K m m^T (a 5 x 5 deviatoric block in the (vecd) basis the
 // library works in, plus the bulk term; m = (1,1,1,0,0,0); ecm_device.hpp, end of point_update): 26 numbers instead of 36.  The
 // geometry-recomputing action can stream those: 13 instead of 18 16-byte pairs per point.  V65^T of a Voigt 6-vector:
-constexpr double C_SQR2I = 0.70710678118654752440, C_SQR6I = 0.40824829046386301637;
-__device__ __forceinline__ void v65t(const double c0, const double c1, const double c2, const double c3, const double c4, const double c5, double o[5]) {
-   o[0] = C_SQR2I * (c0 - c1); o[1] = C_SQR6I * (2.0 * c2 - c0 - c1); o[2] = C_SQR2I * c5; o[3] = C_SQR2I * c4; o[4] = C_SQR2I * c3;
-}
-// D = L^-1 V65^T C V65 L^-1 with L = V65^T V65 = diag(1,1,1/2,1/2,1/2), K = m^T C m / 9 (exact when C has the form above)
-__device__ __forceinline__ void tangent_to_d55(const double* c, const int64_t st, double D[25], double& K) {
-   double T[5][6];
-#pragma unroll
-   for (int j = 0; j < 6; j++) {
-      double o[5]; v65t(c[(0 + 6 * j) * st], c[(1 + 6 * j) * st], c[(2 + 6 * j) * st], c[(3 + 6 * j) * st], c[(4 + 6 * j) * st], c[(5 + 6 * j) * st], o);
-#pragma unroll
-      for (int k = 0; k < 5; k++) T[k][j] = o[k];
-   }
-#pragma unroll
-   for (int k = 0; k < 5; k++) {
-      double o[5]; v65t(T[k][0], T[k][1], T[k][2], T[k][3], T[k][4], T[k][5], o);
-#pragma unroll
-      for (int l = 0; l < 5; l++) D[k + 5 * l] = o[l] * ((k < 2 ? 1.0 : 2.0) * (l < 2 ? 1.0 : 2.0));
-   }
-   double t = 0;
-#pragma unroll
-   for (int j = 0; j < 3; j++)
-#pragma unroll
-      for (int i = 0; i < 3; i++) t += c[(i + 6 * j) * st];
-   K = t * (1.0 / 9.0);
-}
-// s = (V65 D V65^T + K m m^T) eps
-__device__ __forceinline__ void d55_apply(const double D[25], const double K, const double eps[6], double sg[6]) {
-   double e5[5], s5[5];
-   v65t(eps[0], eps[1], eps[2], eps[3], eps[4], eps[5], e5);
-#pragma unroll
-   for (int k = 0; k < 5; k++) s5[k] = D[k] * e5[0] + D[k + 5] * e5[1] + D[k + 10] * e5[2] + D[k + 15] * e5[3] + D[k + 20] * e5[4];
-   const double t1 = C_SQR2I * s5[0], t2 = C_SQR6I * s5[1], bk = K * (eps[0] + eps[1] + eps[2]);
-   sg[0] = t1 - t2 + bk; sg[1] = -t1 - t2 + bk; sg[2] = 2.0 * C_SQR6I * s5[1] + bk; sg[3] = C_SQR2I * s5[4]; sg[4] = C_SQR2I * s5[3]; sg[5] = C_SQR2I * s5[2];
-}
-constexpr int PAC_PAIRS = 13;   // compact record: 25 D entries + K, scaled by dt W / detJ
-__device__ __forceinline__ int64_t pac_off(int64_t blk, int Q, int q, int pair) { return (((blk * Q + q) * PAC_PAIRS + pair) * PA_BLK) * 2; }
 
 // pa record for every point of an element; one lane per element (coalesced 16-byte stores).  CMP: also the compact record.
-template <bool QB, bool CMP>
+template <bool QB, int CMP>
 __global__ __launch_bounds__(PA_BLK) void k_grad_setup_pa(const int Q, const int E, const double dt, const double* __restrict__ W,
                                                           const double* __restrict__ J, const double* __restrict__ C, double* __restrict__ pa, double* __restrict__ pac) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
@@ -177,11 +140,14 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_setup_pa(const int Q, const int
 #pragma unroll
       for (int pr = 0; pr < 4; pr++) rec[(18 + pr) * PA_BLK] = make_double2(adj[2 * pr], adj[2 * pr + 1]);
       rec[22 * PA_BLK] = make_double2(adj[8], W[q] * detJ);
-      if (CMP) {
-         double D[26]; tangent_to_d55(c, vc.stride, D, D[25]);
-         double2* rc = reinterpret_cast<double2*>(pac + pac_off(blk, Q, q, 0)) + lane;
+      if (CMP) {   // 13 pairs: D, K;  18 pairs: D, K, adj(J), W detJ
+         double D[36]; tangent_to_d55(c, vc.stride, D, D[25]);
 #pragma unroll
-         for (int pr = 0; pr < PAC_PAIRS; pr++) rc[pr * PA_BLK] = make_double2(D[2 * pr] * sc, D[2 * pr + 1] * sc);
+         for (int i = 0; i < 26; i++) D[i] *= sc;
+         if (CMP == PAC_PAIRS_GEO) { for (int i = 0; i < 9; i++) D[26 + i] = adj[i]; D[35] = W[q] * detJ; }
+         double2* rc = reinterpret_cast<double2*>(pac + pac_off<CMP ? CMP : 1>(blk, Q, q, 0)) + lane;
+#pragma unroll
+         for (int pr = 0; pr < CMP; pr++) rc[pr * PA_BLK] = make_double2(D[2 * pr], D[2 * pr + 1]);
       }
    }
 }
@@ -253,7 +219,7 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
 #pragma unroll
    for (int q = 0; q < 8; q++) {
       static_assert(!CMP || GEO, "the compact record carries no geometry");
-      const double2* rec = reinterpret_cast<const double2*>(pa + (CMP ? pac_off(blk, 8, q, 0) : pa_off(blk, 8, q, 0))) + lane;
+      const double2* rec = reinterpret_cast<const double2*>(pa + (CMP ? pac_off<PAC_PAIRS>(blk, 8, q, 0) : pa_off(blk, 8, q, 0))) + lane;
       double v[PA_SLOTS];
 #pragma unroll
       for (int pr = 0; pr < (CMP ? PAC_PAIRS : (GEO ? 18 : PA_PAIRS)); pr++) { const double2 t = rec[pr * PA_BLK]; v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
@@ -563,13 +529,11 @@ int exa_launch_residual_p1(exa_ctx* ctx, const double* J, const double* S, doubl
 }
 int exa_launch_grad_setup_pa(exa_ctx* ctx, double dt, const double* J, const double* C, hipStream_t s) {
    const dim3 grid(nblk(ctx->E, PA_BLK));
-   if (ctx->pa_c) {
-      if (ctx->qblk) hipLaunchKernelGGL((k_grad_setup_pa<true, true>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c);
-      else hipLaunchKernelGGL((k_grad_setup_pa<false, true>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c);
-   } else {
-      if (ctx->qblk) hipLaunchKernelGGL((k_grad_setup_pa<true, false>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, (double*)nullptr);
-      else hipLaunchKernelGGL((k_grad_setup_pa<false, false>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, (double*)nullptr);
-   }
+#define GS_LAUNCH(QBV, NP) hipLaunchKernelGGL((k_grad_setup_pa<QBV, NP>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c)
+   if (ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) { if (ctx->qblk) GS_LAUNCH(true, PAC_PAIRS); else GS_LAUNCH(false, PAC_PAIRS); }
+   else if (ctx->pa_c) { if (ctx->qblk) GS_LAUNCH(true, PAC_PAIRS_GEO); else GS_LAUNCH(false, PAC_PAIRS_GEO); }
+   else { if (ctx->qblk) GS_LAUNCH(true, 0); else GS_LAUNCH(false, 0); }
+#undef GS_LAUNCH
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s) {

@@ -479,6 +479,12 @@ def test_element_blocked_layout_p2(oracle, integ, assembly, cap):
         ctx.check(L.exa_grad_setup(ctx.h, 0.5, ptr(J), ptr(cm), None))
         xg = dev.up(np.random.default_rng(1).standard_normal(3 * NN)); yg = dev.zeros(3 * NN)
         ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(xg), ptr(yg), None, None)); out["apply"] = yg.cpu().numpy()
+        # the same action from the compact records (deviatoric block + bulk + geometry, 18 instead of 23 pairs per point)
+        defect = C.c_double(1.0); ctx.check(L.exa_grad_tangent_defect(ctx.h, ptr(cm), C.byref(defect), None)); assert defect.value < 1e-13
+        ctx.check(L.exa_set_tangent_form(ctx.h, L.EXA_TANGENT_DEV5_BULK))
+        ctx.check(L.exa_grad_setup(ctx.h, 0.5, ptr(J), ptr(cm), None))
+        yc = dev.zeros(3 * NN); ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(xg), ptr(yc), None, None))
+        assert rel_l2(yc.cpu().numpy(), out["apply"]) < 1e-13
         avg = np.zeros(7); ctx.check(L.exa_vol_avg(ctx.h, ptr(J), ptr(sg[0]), 6, 1, avg.ctypes.data_as(C.POINTER(C.c_double)), None)); out["avg"] = avg.copy()
         res[layout] = out
         ctx.close()
