@@ -221,9 +221,10 @@ def main():
         except Exception:
             flops = None
         model_gbs = MODEL_BYTES_PER_QPT * P_local / (kern_ms * 1e-3) / 1e9
-        geo = os.environ.get("EXA_APPLY_GEO", "on") != "off" and args.assembly.upper() == "PA"
+        ea_streamed = args.assembly.upper() == "EA" and os.environ.get("EXA_EA_ASSEMBLED") == "1"   # 24 x 24 matrices from HBM
+        geo = os.environ.get("EXA_APPLY_GEO", "on") != "off" and not ea_streamed
         compact = geo and os.environ.get("EXA_TANGENT_FORM", "compact") != "full"
-        moved = APPLY_MOVED_BYTES_COMPACT if compact else (APPLY_MOVED_BYTES_PER_QPT if geo else APPLY_BYTES_PER_QPT)
+        moved = 616.0 if ea_streamed else (APPLY_MOVED_BYTES_COMPACT if compact else (APPLY_MOVED_BYTES_PER_QPT if geo else APPLY_BYTES_PER_QPT))
         apply_gbs = APPLY_BYTES_PER_QPT * P_local / (apply_ms * 1e-3) / 1e9
         iter_bytes = APPLY_BYTES_PER_QPT * P_local + PCG_VEC_BYTES_PER_DOF * ndof_local
         out = {
@@ -246,7 +247,7 @@ def main():
                          "note": "FP64-VALU-bound kernel (78 % VALU-busy, SURVEY 8(d)): the HBM fraction of the ALGORITHMIC bytes is reported as the "
                                  "contract asks; measured traffic (PMC) is ~2x the algorithmic bytes (parking + spills, DESIGN 4.1); "
                                  "see roofline_pcg_apply for the HBM-bound half of the metric"},
-            "roofline_pcg_apply": {"kernel": "k_grad_apply_p1<LVEC,GEO,CMP> (AddMultGradPA + gather/scatter)", "bound": "hbm",
+            "roofline_pcg_apply": {"kernel": ("k_ea_apply_p1 (element mat-vec)" if ea_streamed else "k_grad_apply_p1<LVEC,GEO,CMP> (AddMultGradPA / matrix-free element-assembly action + gather/scatter)"), "bound": "hbm",
                                    "achieved": moved * P_local / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": moved * P_local / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "traffic": traffic["k_grad_apply_p1"] * P_local if "k_grad_apply_p1" in traffic else None,

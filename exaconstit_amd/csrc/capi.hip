@@ -13,7 +13,7 @@ int exa_launch_residual_setup(exa_ctx*, const double*, const double*, hipStream_
 int exa_launch_residual_apply(exa_ctx*, double*, hipStream_t);
 int exa_launch_residual_p1(exa_ctx*, const double*, const double*, double*, bool, hipStream_t);
 int exa_launch_grad_setup_pa(exa_ctx*, double, const double*, const double*, hipStream_t);
-int exa_launch_grad_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t);
+int exa_launch_grad_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t, bool trans = false);
 int exa_launch_grad_diag_p1(exa_ctx*, double*, hipStream_t);
 int exa_launch_assemble_ea_p1(exa_ctx*, hipStream_t);
 int exa_launch_ea_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t);
@@ -187,6 +187,11 @@ int exa_residual_apply(exa_ctx* ctx, double* y, exa_stream s) {
    return exa_launch_residual_apply(ctx, y, S(s));
 }
 
+// element-assembly contexts whose L-vector action is computed from the point records (exa_set_ea_matrix_free)
+static bool ea_from_records(const exa_ctx* ctx) {
+   return ctx->ea_matfree && (ctx->n == 27 || (ctx->p == 1 && ctx->cfg.integ == EXA_INTEG_FULL));
+}
+
 // element matrices from the point records (and eDS) of the last exa_grad_setup
 static int assemble_ea(exa_ctx* ctx, hipStream_t s) {
    if (ctx->emat_valid) return EXA_OK;
@@ -225,7 +230,7 @@ int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, ex
    if (!ctx || !J || !C) return fail(ctx, EXA_ERR_ARG, "exa_grad_setup: null pointer");
    if (!ctx->pa) { EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa, pa_bytes(ctx->E, ctx->Q))); EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa, 0, pa_bytes(ctx->E, ctx->Q), S(s))); }
    if (ctx->tangent_form == EXA_TANGENT_DEV5_BULK && !ctx->pa_c) {   // compact records for the actions that can stream them
-      const bool p1 = ctx->p == 1 && ctx->cfg.assembly == EXA_ASSEMBLY_PA && ctx->cfg.integ == EXA_INTEG_FULL;   // k_grad_apply_p1<.., GEO, CMP>
+      const bool p1 = ctx->p == 1 && ctx->cfg.integ == EXA_INTEG_FULL && (ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree);   // k_grad_apply_p1<.., GEO, CMP>
       const bool p2 = ctx->n == 27 && (ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree);               // k_mf_apply_p2<.., CMP>
       if (p1 || p2) {
          ctx->pac_pairs = p1 ? PAC_PAIRS : PAC_PAIRS_GEO;
@@ -243,7 +248,7 @@ int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, ex
          if (rc) return rc;
       }
       ctx->emat_valid = false;
-      if (!(ctx->ea_matfree && ctx->n == 27)) rc = assemble_ea(ctx, S(s));   // matrix-free: assembled on demand only
+      if (!ea_from_records(ctx)) rc = assemble_ea(ctx, S(s));   // matrix-free: assembled on demand only
    } else if (ctx->p != 1) {
       if (!ctx->tbuf) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tbuf, sizeof(double) * 9 * ctx->P));
    }
@@ -306,6 +311,7 @@ int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const ui
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec called before exa_grad_setup");
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
       if (ctx->ea_matfree && ctx->n == 27) return exa_launch_mf_apply_p2(ctx, x, y, mask, gate, true, S(s));
+      if (ea_from_records(ctx)) return exa_launch_grad_apply_p1(ctx, x, y, true, mask, gate, S(s), true);
       if (int rc = assemble_ea(ctx, S(s))) return rc;
       return ctx->ea_generic ? exa_launch_ea_apply_gen(ctx, x, y, true, mask, gate, S(s)) : exa_launch_ea_apply_p1(ctx, x, y, true, mask, gate, S(s));
    }

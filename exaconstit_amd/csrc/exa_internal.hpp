@@ -121,15 +121,6 @@ __device__ __forceinline__ void d55_apply(const double D[25], const double K, co
    const double t1 = C_SQR2I * s5[0], t2 = C_SQR6I * s5[1], bk = K * (eps[0] + eps[1] + eps[2]);
    sg[0] = t1 - t2 + bk; sg[1] = -t1 - t2 + bk; sg[2] = 2.0 * C_SQR6I * s5[1] + bk; sg[3] = C_SQR2I * s5[4]; sg[4] = C_SQR2I * s5[3]; sg[5] = C_SQR2I * s5[2];
 }
-// s = (V65 D^T V65^T + K m m^T) eps: the operator the assembled element matrices apply (k_ea_apply_gen)
-__device__ __forceinline__ void d55_apply_T(const double D[25], const double K, const double eps[6], double sg[6]) {
-   double e5[5], s5[5];
-   v65t(eps[0], eps[1], eps[2], eps[3], eps[4], eps[5], e5);
-#pragma unroll
-   for (int k = 0; k < 5; k++) s5[k] = D[5 * k] * e5[0] + D[5 * k + 1] * e5[1] + D[5 * k + 2] * e5[2] + D[5 * k + 3] * e5[3] + D[5 * k + 4] * e5[4];
-   const double t1 = C_SQR2I * s5[0], t2 = C_SQR6I * s5[1], bk = K * (eps[0] + eps[1] + eps[2]);
-   sg[0] = t1 - t2 + bk; sg[1] = -t1 - t2 + bk; sg[2] = 2.0 * C_SQR6I * s5[1] + bk; sg[3] = C_SQR2I * s5[4]; sg[4] = C_SQR2I * s5[3]; sg[5] = C_SQR2I * s5[2];
-}
 #endif
 
 static inline size_t pa_bytes(int E, int Q) { return (size_t)((E + PA_BLK - 1) / PA_BLK) * Q * PA_SLOTS * PA_BLK * sizeof(double); }

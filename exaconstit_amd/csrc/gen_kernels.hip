@@ -205,7 +205,7 @@ __device__ __forceinline__ void mf_point_p2(const double2 (&rec)[CMP ? PAC_PAIRS
       eps[0] += vol; eps[1] += vol; eps[2] += vol;
    }
    double sg[6];
-   if (CMP) { if (TRANS) d55_apply_T(v, v[25], eps, sg); else d55_apply(v, v[25], eps, sg); }
+   if (CMP) d55_apply(v, v[25], eps, sg);   // the compact record holds D or D^T as the context needs (k_grad_setup_pa<.., TRD>)
    else {
 #pragma unroll
       for (int i = 0; i < 6; i++) { double t = 0;

@@ -229,13 +229,15 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
       else { cap_auto_ = false; newton_cap_ = (std::string(nc) == "off") ? 0 : std::atoi(nc); }
    }
    tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.5 : 4.0;
-   // p = 2 element assembly: the 81 x 81 matrices are 5x the bytes of the records they are built from, so the action is computed from
-   // the records and the matrices only exist if somebody asks for them (diagonal, export); EXA_EA_ASSEMBLED=1 streams them instead
-   if (opt.assembly == Assembly::EA && part.p == 2 && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1"))
+   // element assembly: the element matrices are 2x (p = 1) to 5x (p = 2) the bytes of the records they are built from, so the action is
+   // computed from the records and the matrices only exist if somebody asks for them (diagonal, export); EXA_EA_ASSEMBLED=1 streams them instead
+   if (opt.assembly == Assembly::EA && (part.p == 2 || fast_p1_) && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1"))
       abi_check(ctx_, exa_set_ea_matrix_free(ctx_, 1), "exa_set_ea_matrix_free");
-   compact_tangent_ = ((fast_p1_ && opt.assembly == Assembly::PA && !(std::getenv("EXA_APPLY_GEO") && std::string(std::getenv("EXA_APPLY_GEO")) == "off"))
-                       || (part.p == 2 && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1")))
-                      && !(std::getenv("EXA_TANGENT_FORM") && std::string(std::getenv("EXA_TANGENT_FORM")) == "full");
+   {  // compact tangent records wherever a record-based action runs: p = 1 PA / matrix-free EA with the geometry recomputed, p = 2 matrix-free
+      auto env_is = [](const char* k, const char* v) { const char* e = std::getenv(k); return e && std::string(e) == v; };
+      const bool ea_streamed = opt.assembly == Assembly::EA && env_is("EXA_EA_ASSEMBLED", "1");
+      compact_tangent_ = !env_is("EXA_TANGENT_FORM", "full") && !ea_streamed && ((fast_p1_ && !env_is("EXA_APPLY_GEO", "off")) || part.p == 2);
+   }
    if (compact_tangent_) abi_check(ctx_, exa_set_tangent_form(ctx_, EXA_TANGENT_DEV5_BULK), "exa_set_tangent_form");
    abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 and p = 2 paths (EXA_QLAYOUT=aos switches back for A/B runs)
@@ -345,8 +347,8 @@ void NonlinearMechOperator::GetGradient() {
    }
    abi_check(ctx_, exa_grad_setup(ctx_, dt_, el_jac.p, matGrad.p, stream_), "exa_grad_setup");
    // geometry of the action recomputed from x_cur (unchanged until the next residual evaluation); EXA_APPLY_GEO=off streams it instead
-   if (fast_p1_ && opt_.assembly == Assembly::PA && !(std::getenv("EXA_APPLY_GEO") && std::string(std::getenv("EXA_APPLY_GEO")) == "off"))
-      abi_check(ctx_, exa_grad_set_coords(ctx_, x_cur.p), "exa_grad_set_coords");
+   if (fast_p1_ && !(std::getenv("EXA_APPLY_GEO") && std::string(std::getenv("EXA_APPLY_GEO")) == "off"))
+      abi_check(ctx_, exa_grad_set_coords(ctx_, x_cur.p), "exa_grad_set_coords");   // read by the record-based actions (PA, matrix-free EA) only
    // The reference assembles the operator diagonal here on every call, but its Jacobi smoother never reads it (dinv is built once
    // from diag = 1).  With that default the assembly is skipped: no result depends on it, and for p = 2 element
    // assembly it would be the only consumer of the 81 x 81 matrices.

@@ -124,7 +124,8 @@ __global__ void k_residual_apply(const int Q, const int n, const int E, const do
 // geometry-recomputing action can stream those: 13 instead of 18 16-byte pairs per point.  V65^T of a Voigt 6-vector:
 
 // pa record for every point of an element; one lane per element (coalesced 16-byte stores).  CMP: also the compact record.
-template <bool QB, int CMP>
+// TRD: the compact record holds D^T (element-assembly contexts: their action applies C^T, and the kernels then run the same code)
+template <bool QB, int CMP, bool TRD>
 __global__ __launch_bounds__(PA_BLK) void k_grad_setup_pa(const int Q, const int E, const double dt, const double* __restrict__ W,
                                                           const double* __restrict__ J, const double* __restrict__ C, double* __restrict__ pa, double* __restrict__ pac) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
@@ -141,9 +142,12 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_setup_pa(const int Q, const int
       for (int pr = 0; pr < 4; pr++) rec[(18 + pr) * PA_BLK] = make_double2(adj[2 * pr], adj[2 * pr + 1]);
       rec[22 * PA_BLK] = make_double2(adj[8], W[q] * detJ);
       if (CMP) {   // 13 pairs: D, K;  18 pairs: D, K, adj(J), W detJ
-         double D[36]; tangent_to_d55(c, vc.stride, D, D[25]);
+         double D[36], Dn[25]; tangent_to_d55(c, vc.stride, Dn, D[25]);
 #pragma unroll
-         for (int i = 0; i < 26; i++) D[i] *= sc;
+         for (int l = 0; l < 5; l++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) D[k + 5 * l] = (TRD ? Dn[l + 5 * k] : Dn[k + 5 * l]) * sc;
+         D[25] *= sc;
          if (CMP == PAC_PAIRS_GEO) { for (int i = 0; i < 9; i++) D[26 + i] = adj[i]; D[35] = W[q] * detJ; }
          double2* rc = reinterpret_cast<double2*>(pac + pac_off<CMP ? CMP : 1>(blk, Q, q, 0)) + lane;
 #pragma unroll
@@ -180,7 +184,9 @@ __global__ void k_tangent_defect(const int Q, const int64_t P, const double* __r
 // GEO: adj(J) is recomputed per point from the nodal coordinates of the element (24 doubles gathered once per element, L2-resident)
 // instead of being streamed from the record: 36 instead of 46 doubles per point from HBM for ~90 more FMAs per point.
 // CMP (with GEO): the tangent arrives in its compact form (13 pairs per point, k_grad_setup_pa<.., true>).
-template <bool LVEC, bool GEO, bool CMP = false>
+// TRANS: C^T instead of C, i.e. the operator of the assembled element matrices (y_j += sum_i A_ij x_i with A = B^T C B, k_ea_apply_p1):
+// the element-assembly action without the 24 x 24 matrices.
+template <bool LVEC, bool GEO, bool CMP = false, bool TRANS = false>
 __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const double* __restrict__ pa, const double* __restrict__ x, double* __restrict__ y,
                                                           const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
                                                           const double* __restrict__ gate, const double* __restrict__ coords) {
@@ -246,10 +252,11 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
          for (int t = 0; t < 3; t++) h[c][t] = gx[c][0] * adj[t] + gx[c][1] * adj[3 + t] + gx[c][2] * adj[6 + t];
       const double eps[6] = { h[0][0], h[1][1], h[2][2], h[1][2] + h[2][1], h[0][2] + h[2][0], h[0][1] + h[1][0] };
       double sg[6];
+      static_assert(!(CMP && TRANS), "compact records are stored in the orientation the action needs");
       if (CMP) d55_apply(v, v[25], eps, sg);
       else {
 #pragma unroll
-         for (int i = 0; i < 6; i++) { double s = 0; for (int j = 0; j < 6; j++) s += Ct[i + 6 * j] * eps[j]; sg[i] = s; }
+         for (int i = 0; i < 6; i++) { double s = 0; for (int j = 0; j < 6; j++) s += (TRANS ? Ct[j + 6 * i] : Ct[i + 6 * j]) * eps[j]; sg[i] = s; }
       }
       const double S[3][3] = { { sg[0], sg[5], sg[4] }, { sg[5], sg[1], sg[3] }, { sg[4], sg[3], sg[2] } };
       // T[j][c] = sum_t adj(j,t) S(t,c)
@@ -529,19 +536,25 @@ int exa_launch_residual_p1(exa_ctx* ctx, const double* J, const double* S, doubl
 }
 int exa_launch_grad_setup_pa(exa_ctx* ctx, double dt, const double* J, const double* C, hipStream_t s) {
    const dim3 grid(nblk(ctx->E, PA_BLK));
-#define GS_LAUNCH(QBV, NP) hipLaunchKernelGGL((k_grad_setup_pa<QBV, NP>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c)
-   if (ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) { if (ctx->qblk) GS_LAUNCH(true, PAC_PAIRS); else GS_LAUNCH(false, PAC_PAIRS); }
-   else if (ctx->pa_c) { if (ctx->qblk) GS_LAUNCH(true, PAC_PAIRS_GEO); else GS_LAUNCH(false, PAC_PAIRS_GEO); }
-   else { if (ctx->qblk) GS_LAUNCH(true, 0); else GS_LAUNCH(false, 0); }
+#define GS_LAUNCH(QBV, NP, TR) hipLaunchKernelGGL((k_grad_setup_pa<QBV, NP, TR>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c)
+#define GS_LAUNCH2(NP, TR) do { if (ctx->qblk) GS_LAUNCH(true, NP, TR); else GS_LAUNCH(false, NP, TR); } while (0)
+   const bool trd = ctx->cfg.assembly == EXA_ASSEMBLY_EA;
+   if (ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) { if (trd) GS_LAUNCH2(PAC_PAIRS, true); else GS_LAUNCH2(PAC_PAIRS, false); }
+   else if (ctx->pa_c) { if (trd) GS_LAUNCH2(PAC_PAIRS_GEO, true); else GS_LAUNCH2(PAC_PAIRS_GEO, false); }
+   else GS_LAUNCH2(0, false);
+#undef GS_LAUNCH2
 #undef GS_LAUNCH
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
-int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s) {
+int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s, bool trans) {
    const unsigned nb = nblk(ctx->E, PA_BLK);
-   if (lvec && ctx->coords_lvec && ctx->pa_c) hipLaunchKernelGGL((k_grad_apply_p1<true, true, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa_c, x, y, ctx->conn, ctx->nnodes, mask, gate, ctx->coords_lvec);
-   else if (lvec && ctx->coords_lvec) hipLaunchKernelGGL((k_grad_apply_p1<true, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask, gate, ctx->coords_lvec);
-   else if (lvec) hipLaunchKernelGGL((k_grad_apply_p1<true, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask, gate, (const double*)nullptr);
-   else hipLaunchKernelGGL((k_grad_apply_p1<false, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask, gate, (const double*)nullptr);
+#define GA_LAUNCH(G, CM, T, REC, CRD) hipLaunchKernelGGL((k_grad_apply_p1<true, G, CM, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, REC, x, y, ctx->conn, ctx->nnodes, mask, gate, CRD)
+   const double* none = nullptr;
+   if (lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) GA_LAUNCH(true, true, false, ctx->pa_c, ctx->coords_lvec);   // D or D^T in the record
+   else if (lvec && ctx->coords_lvec) { if (trans) GA_LAUNCH(true, false, true, ctx->pa, ctx->coords_lvec); else GA_LAUNCH(true, false, false, ctx->pa, ctx->coords_lvec); }
+   else if (lvec) { if (trans) GA_LAUNCH(false, false, true, ctx->pa, none); else GA_LAUNCH(false, false, false, ctx->pa, none); }
+   else hipLaunchKernelGGL((k_grad_apply_p1<false, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask, gate, none);
+#undef GA_LAUNCH
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 // max over the points of the relative deviation of C from the compact tangent form; result as the bit pattern of a double in *out_dev

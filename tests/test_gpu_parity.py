@@ -209,6 +209,18 @@ def test_integrators_match_oracle(oracle, assembly):
     d_xL = dev.up(xL); d_mask = dev.up(mask); d_yL = dev.zeros(3 * NN)
     ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xL), ptr(d_yL), ptr(d_mask), None))
     assert rel_l2(d_yL.cpu().numpy(), yL_ref) < 1e-12
+    if assembly == 1:
+        # element assembly without the matrices: the action of B^T C^T B from the point records, geometry streamed / recomputed
+        ctx.check(L.exa_set_ea_matrix_free(ctx.h, 1))
+        ctx.check(L.exa_grad_setup(ctx.h, dt, ptr(d_J), ptr(d_C), None))
+        d_X = dev.up(rve["X"])
+        for coords in (None, d_X):
+            ctx.check(L.exa_grad_set_coords(ctx.h, ptr(coords) if coords is not None else None))
+            d_yL2 = dev.zeros(3 * NN)
+            ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xL), ptr(d_yL2), ptr(d_mask), None))
+            assert rel_l2(d_yL2.cpu().numpy(), yL_ref) < 1e-12
+        d_em2 = dev.zeros(9 * n * n * E); ctx.check(L.exa_grad_get_ea(ctx.h, ptr(d_em2), None))      # still there on demand
+        assert rel_l2(d_em2.cpu().numpy(), emat) < 1e-12
     if assembly == 0:
         # same action with adj(J) recomputed in the kernel from the nodal coordinates the Jacobians came from
         d_X = dev.up(rve["X"]); d_yL2 = dev.zeros(3 * NN)
@@ -586,8 +598,8 @@ def test_compact_tangent_form(oracle, model, pkey):
     props = _props(orc, pkey)
     d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
     v_nodes = hipref.velocity_field(rve, scale=2.0)
-    for layout in (L.EXA_QLAYOUT_AOS, L.EXA_QLAYOUT_EB64):
-        ctx = L.Context(model, props, 298.0, 1, E)
+    for layout, assembly in ((L.EXA_QLAYOUT_AOS, 0), (L.EXA_QLAYOUT_EB64, 0), (L.EXA_QLAYOUT_EB64, 1)):
+        ctx = L.Context(model, props, 298.0, 1, E, assembly=assembly)
         ctx.check(L.exa_set_quadrature_layout(ctx.h, layout)); ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
         sz = lambda w: int(L.exa_qf_size(ctx.h, w))
         sv = [dev.zeros(sz(28)), dev.zeros(sz(28))]; sg = [dev.zeros(sz(6)), dev.zeros(sz(6))]; cm = dev.zeros(sz(36)); J = dev.zeros(sz(9))
@@ -605,6 +617,8 @@ def test_compact_tangent_form(oracle, model, pkey):
             assert defect.value < 1e-13, defect.value
             ys = []
             for form in (L.EXA_TANGENT_FULL, L.EXA_TANGENT_DEV5_BULK):
+                # element assembly: assembled 24 x 24 matrices (form 0) vs the matrix-free action on the compact records (form 1)
+                if assembly == 1: ctx.check(L.exa_set_ea_matrix_free(ctx.h, 1 if form else 0))
                 ctx.check(L.exa_set_tangent_form(ctx.h, form))
                 ctx.check(L.exa_grad_setup(ctx.h, dt, ptr(J), ptr(cm), None))
                 ctx.check(L.exa_grad_set_coords(ctx.h, ptr(d_x)))
