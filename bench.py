@@ -20,6 +20,10 @@ import time
 
 import numpy as np
 
+# the host driver of this pool only supports dmabuf IPC: without this RCCL fails across processes (hipIpcGetMemHandle); must be set
+# before the HIP runtime comes up
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
