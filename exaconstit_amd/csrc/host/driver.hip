@@ -516,11 +516,13 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    const bool fused = std::getenv("EXA_PCG_UNFUSED") == nullptr;   // A/B switch for measurements
    while (!done) {
       for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) {
-         vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, s);
+         // identity preconditioner + fused loop: z == r is never materialised (the un-fused path reads z in k_cg_step2)
+         const bool ident = fused && op.precond == Precond::IDENTITY;
+         vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, ident, s);
          comm.allreduce_sum(S + 8, 1, s);
          vk_cg_beta(S, opt_.krylov_iter, s);
          if (fused) {
-            vk_cg_step2z(nd, S, cg_z_.p, cg_d_.p, s);                    // d = z + beta d; z = 0
+            vk_cg_step2z(nd, S, cg_z_.p, cg_r_.p, cg_d_.p, ident, s);      // d = z + beta d; z = 0
             op.GradMult(cg_d_.p, cg_z_.p, true, S + 6, true, true);       // z += K d (input masked in the kernel, output mask folded into the dot)
             vk_mask_dot(nd, nn, op.weight.p, op.ess_mask.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s);
          } else {

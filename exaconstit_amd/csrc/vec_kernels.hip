@@ -95,6 +95,9 @@ __global__ void k_cg_beta(double* S, double max_iter) {                // betano
 }
 
 // x += alpha d; r -= alpha z; z = dinv r; partial of (r, z)_w
+// IDENT: the preconditioner is the identity (the reference's Jacobi smoother with its never-refreshed dinv = 1): z == r, so dinv is
+// not read and z is not written (k_cg_step2z<true> takes r instead)
+template <bool IDENT>
 __global__ void k_cg_step1(int64_t n, int64_t nn, const double* __restrict__ S, const double* __restrict__ w, const double* __restrict__ dinv,
                            const double* __restrict__ d, double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial) {
    __shared__ double sm[RBLK];
@@ -105,8 +108,8 @@ __global__ void k_cg_step1(int64_t n, int64_t nn, const double* __restrict__ S, 
       x[i] += alpha * d[i];
       const double ri = r[i] - alpha * z[i];
       r[i] = ri;
-      const double zi = dinv[i] * ri;
-      z[i] = zi;
+      const double zi = IDENT ? ri : dinv[i] * ri;
+      if (!IDENT) z[i] = zi;
       acc += w[i % nn] * ri * zi;
    }
    const double s = block_sum(acc, sm);
@@ -121,10 +124,11 @@ __global__ void k_cg_step2(int64_t n, const double* __restrict__ S, const double
 }
 
 // d = z + beta d, then z = 0: the operator action that follows accumulates into z with atomics, so the separate fill pass is folded in
-__global__ void k_cg_step2z(int64_t n, const double* __restrict__ S, double* __restrict__ z, double* __restrict__ d) {
+template <bool IDENT>
+__global__ void k_cg_step2z(int64_t n, const double* __restrict__ S, double* __restrict__ z, const double* __restrict__ r, double* __restrict__ d) {
    if (S[6] != 0.0) return;
    const double beta = S[5];
-   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { d[i] = z[i] + beta * d[i]; z[i] = 0.0; }
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { d[i] = (IDENT ? r[i] : z[i]) + beta * d[i]; z[i] = 0.0; }
 }
 
 // essential rows of b zeroed in place + partial weighted dot (a, b): the operator's output mask and the PCG denominator in one pass
@@ -224,7 +228,10 @@ void vk_vgrad_velocity(int64_t nn, const uint8_t* m, const double* x, const doub
    double9 L; for (int i = 0; i < 9; i++) L.a[i] = L9[i];
    hipLaunchKernelGGL(k_vgrad_velocity, dim3(nblk(nn)), dim3(256), 0, s, nn, m, x, org, L, v);
 }
-void vk_cg_step2z(int64_t n, const double* S, double* z, double* d, hipStream_t s) { hipLaunchKernelGGL(k_cg_step2z, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, d); }
+void vk_cg_step2z(int64_t n, const double* S, double* z, const double* r, double* d, bool ident, hipStream_t s) {
+   if (ident) hipLaunchKernelGGL(k_cg_step2z<true>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, r, d);
+   else hipLaunchKernelGGL(k_cg_step2z<false>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, r, d);
+}
 void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* a, double* b, const double* flag, double* partial, double* out, hipStream_t s) {
    const unsigned nb = gblk(n);
    hipLaunchKernelGGL(k_mask_dot_partial, dim3(nb), dim3(RBLK), 0, s, n, nn, w, m, a, b, flag, partial);
@@ -233,9 +240,10 @@ void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const
 void vk_cg_init(double* S, double rel, double abs_, hipStream_t s) { hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1), 0, s, S, rel, abs_); }
 void vk_cg_den(double* S, hipStream_t s) { hipLaunchKernelGGL(k_cg_den, dim3(1), dim3(1), 0, s, S); }
 void vk_cg_beta(double* S, int max_iter, hipStream_t s) { hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1), 0, s, S, (double)max_iter); }
-void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, hipStream_t s) {
+void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, bool ident, hipStream_t s) {
    const unsigned nb = gblk(n);
-   hipLaunchKernelGGL(k_cg_step1, dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial);
+   if (ident) hipLaunchKernelGGL(k_cg_step1<true>, dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial);
+   else hipLaunchKernelGGL(k_cg_step1<false>, dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial);
    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S + 6, S + 8);
 }
 void vk_cg_step2(int64_t n, const double* S, const double* z, double* d, hipStream_t s) { hipLaunchKernelGGL(k_cg_step2, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, d); }
