@@ -103,7 +103,18 @@ def test_full_size_properties(oracle, N):
     z1 = apply(ea, x1)
     assert float((z1 - y1).norm() / y1.norm()) < 1e-12
     ea.check(L.exa_grad_setup(ea.h, dts[-1], ptr(d_J), ptr(d_cm), None))
-    assert float((apply(ea, x1) - y1).norm() / y1.norm()) < 1e-3
+    z_asm = apply(ea, x1)
+    assert float((z_asm - y1).norm() / y1.norm()) < 1e-3
+    # ---- (4) the byte-saving variants of the driver's default path give the action of the streamed records / assembled matrices:
+    #      adj(J) recomputed from the nodal coordinates, tangent in its deviatoric-block + bulk form, element assembly without matrices
+    defect = C.c_double(1.0); ctx.check(L.exa_grad_tangent_defect(ctx.h, ptr(d_cm), C.byref(defect), None)); assert defect.value < 1e-13
+    ctx.check(L.exa_grad_set_coords(ctx.h, ptr(d_x)))
+    assert float((apply(ctx, x1) - y1).norm() / y1.norm()) < 1e-13
+    ctx.check(L.exa_set_tangent_form(ctx.h, L.EXA_TANGENT_DEV5_BULK)); ctx.check(L.exa_grad_setup(ctx.h, dts[-1], ptr(d_J), ptr(d_cm), None))
+    assert float((apply(ctx, x1) - y1).norm() / y1.norm()) < 1e-13
+    ea.check(L.exa_set_ea_matrix_free(ea.h, 1)); ea.check(L.exa_set_tangent_form(ea.h, L.EXA_TANGENT_DEV5_BULK))
+    ea.check(L.exa_grad_setup(ea.h, dts[-1], ptr(d_J), ptr(d_cm), None)); ea.check(L.exa_grad_set_coords(ea.h, ptr(d_x)))
+    assert float((apply(ea, x1) - z_asm).norm() / z_asm.norm()) < 1e-13
     ea.close(); ctx.close()
 
 
