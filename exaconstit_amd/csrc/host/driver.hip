@@ -141,45 +141,52 @@ double Comm::max_over_ranks(double v) {
    return v;
 }
 
+// One pack and one unpack launch per exchange: the neighbours' dof lists are concatenated (segment i = neighbour i), the send /
+// receive buffers are one allocation each.  (A launch per neighbour is 14 tiny kernels per operator action on a 2 x 2 x 2 grid -
+// more than the exchange itself.)  A dof shared with several neighbours appears in several segments: the unpack adds atomically.
 void Comm::setup_halo(const Partition& part) {
-   idx_.clear(); sbuf_.clear(); rbuf_.clear();
-   for (const Neighbor& nb : part.nbrs) {
-      idx_.emplace_back(nb.dofs.size()); idx_.back().upload(nb.dofs);
-      sbuf_.emplace_back(nb.dofs.size()); rbuf_.emplace_back(nb.dofs.size());
-   }
+   seg_off_.assign(1, 0);
+   std::vector<int32_t> all;
+   for (const Neighbor& nb : part.nbrs) { all.insert(all.end(), nb.dofs.begin(), nb.dofs.end()); seg_off_.push_back(all.size()); }
+   idx_all_.release(); sbuf_all_.release(); rbuf_all_.release();
+   if (!all.empty()) { idx_all_.alloc(all.size()); idx_all_.upload(all); sbuf_all_.alloc(all.size()); rbuf_all_.alloc(all.size()); }
 }
 
 void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
    if (nranks == 1 && !force_) return;
    const size_t nb = part.nbrs.size();
-   for (size_t i = 0; i < nb; i++) vk_pack((int64_t)idx_[i].n, idx_[i].p, y, sbuf_[i].p, s);
+   const int64_t ntot = (int64_t)seg_off_.back();
+   auto sb = [&](size_t i) { return sbuf_all_.p + seg_off_[i]; };
+   auto rb = [&](size_t i) { return rbuf_all_.p + seg_off_[i]; };
+   auto cnt = [&](size_t i) { return seg_off_[i + 1] - seg_off_[i]; };
+   vk_pack(ntot, idx_all_.p, y, sbuf_all_.p, s);
    if (loop_) {
       LoopbackGroup* g = (LoopbackGroup*)loop_;
       g->sendbuf[rank].resize(nb); g->nbr_rank[rank].resize(nb);
-      for (size_t i = 0; i < nb; i++) { g->sendbuf[rank][i] = sbuf_[i].p; g->nbr_rank[rank][i] = part.nbrs[i].rank; }
+      for (size_t i = 0; i < nb; i++) { g->sendbuf[rank][i] = sb(i); g->nbr_rank[rank][i] = part.nbrs[i].rank; }
       EXA_HC(hipStreamSynchronize(s));
       g->barrier();
       for (size_t i = 0; i < nb; i++) {   // my slot i talks to rank r; r's slot that talks to me holds what I receive (same dof order on both sides)
          const int r = part.nbrs[i].rank; const double* src = nullptr;
          for (size_t k = 0; k < g->nbr_rank[r].size(); k++) if (g->nbr_rank[r][k] == rank) {
-            // a pair of ranks can be neighbours through exactly one (dx,dy,dz) offset in a block decomposition
+            // a pair of ranks is connected by exactly one neighbour entry on each side
             src = g->sendbuf[r][k]; break;
          }
          if (!src) throw std::runtime_error("loopback halo: asymmetric neighbour lists");
-         EXA_HC(hipMemcpyAsync(rbuf_[i].p, src, sizeof(double) * rbuf_[i].n, hipMemcpyDeviceToDevice, s));
+         EXA_HC(hipMemcpyAsync(rb(i), src, sizeof(double) * cnt(i), hipMemcpyDeviceToDevice, s));
       }
       EXA_HC(hipStreamSynchronize(s));
       g->barrier();
-      for (size_t i = 0; i < nb; i++) vk_unpack_add((int64_t)idx_[i].n, idx_[i].p, rbuf_[i].p, y, s);
+      vk_unpack_add(ntot, idx_all_.p, rbuf_all_.p, y, s);
       return;
    }
    nccl_check(rccl().GroupStart(), "ncclGroupStart");
    for (size_t i = 0; i < nb; i++) {
-      nccl_check(rccl().Send(sbuf_[i].p, sbuf_[i].n, ncclDouble, part.nbrs[i].rank, (ncclComm_t)comm_, s), "ncclSend");
-      nccl_check(rccl().Recv(rbuf_[i].p, rbuf_[i].n, ncclDouble, part.nbrs[i].rank, (ncclComm_t)comm_, s), "ncclRecv");
+      nccl_check(rccl().Send(sb(i), cnt(i), ncclDouble, part.nbrs[i].rank, (ncclComm_t)comm_, s), "ncclSend");
+      nccl_check(rccl().Recv(rb(i), cnt(i), ncclDouble, part.nbrs[i].rank, (ncclComm_t)comm_, s), "ncclRecv");
    }
    nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
-   for (size_t i = 0; i < nb; i++) vk_unpack_add((int64_t)idx_[i].n, idx_[i].p, rbuf_[i].p, y, s);
+   vk_unpack_add(ntot, idx_all_.p, rbuf_all_.p, y, s);
 }
 
 // =====================================================================================================================

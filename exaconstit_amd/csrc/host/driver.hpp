@@ -38,7 +38,7 @@ class Comm {
  private:
    void loopback_reduce(double* dev, int n, int op, hipStream_t s);
    void* comm_ = nullptr; void* loop_ = nullptr; bool force_ = false;
-   std::vector<DevBuf<int32_t>> idx_; std::vector<DevBuf<double>> sbuf_, rbuf_;
+   DevBuf<int32_t> idx_all_; DevBuf<double> sbuf_all_, rbuf_all_; std::vector<size_t> seg_off_{ 0 };   // concatenated neighbour segments
    DevBuf<double> tmp_;
 };
 

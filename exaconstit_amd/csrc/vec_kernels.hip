@@ -162,7 +162,7 @@ __global__ void k_pack(int64_t n, const int32_t* __restrict__ idx, const double*
 }
 __global__ void k_unpack_add(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ buf, double* __restrict__ y) {
    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-   if (i < n) y[idx[i]] += buf[i];
+   if (i < n) atomicAdd(&y[idx[i]], buf[i]);   // a dof shared with several neighbours occurs once per neighbour segment
 }
 
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
