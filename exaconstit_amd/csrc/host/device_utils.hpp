@@ -49,10 +49,12 @@ void vk_dot(int64_t n, int64_t nn, const double* w, const double* a, const doubl
 void vk_cg_init(double* S, double rel, double abs_, hipStream_t s);
 void vk_cg_den(double* S, hipStream_t s);
 void vk_cg_beta(double* S, int max_iter, hipStream_t s);
-void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, bool ident, hipStream_t s);
+void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, bool ident,
+                 bool fuse_beta, int max_iter, hipStream_t s);
 void vk_cg_step2(int64_t n, const double* S, const double* z, double* d, hipStream_t s);
 void vk_cg_step2z(int64_t n, const double* S, double* z, const double* r, double* d, bool ident, hipStream_t s);   // ... and z = 0 for the accumulating operator action
-void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* a, double* b, const double* flag, double* partial, double* out, hipStream_t s);
+void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* a, double* b, const double* flag, double* partial, double* out, hipStream_t s,
+                 double* fuse_den_S = nullptr);
 void vk_min3(int64_t nn, const double* x, double* partial /*>= DOT_BLOCKS*/, double* out3, hipStream_t s);
 void vk_vgrad_velocity(int64_t nn, const uint8_t* m, const double* x, const double* org3_dev, const double* L9_host, double* v, hipStream_t s);
 void vk_pack(int64_t n, const int32_t* idx, const double* y, double* buf, hipStream_t s);

@@ -14,6 +14,7 @@
 
 extern "C" int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, exa_stream s);
 
+
 namespace exa_host {
 
 // =====================================================================================================================
@@ -521,24 +522,28 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    vk_cg_den(S, s);
    double hS[9]; int launched = 0; bool done = false;
    const bool fused = std::getenv("EXA_PCG_UNFUSED") == nullptr;   // A/B switch for measurements
+   // One rank: the scalar updates ride in the reductions (no all-reduce in between).  (Summing the denominator d.(K d) element-wise
+   // inside the action, with its scatter skipping the essential rows, was measured too: the pass it saves costs what it adds to the
+   // action kernel, +0.8 %.)
+   const bool one = comm.nranks == 1;
    while (!done) {
       for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) {
          // identity preconditioner + fused loop: z == r is never materialised (the un-fused path reads z in k_cg_step2)
          const bool ident = fused && op.precond == Precond::IDENTITY;
-         vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, ident, s);
-         comm.allreduce_sum(S + 8, 1, s);
-         vk_cg_beta(S, opt_.krylov_iter, s);
+         vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, ident, fused && one, opt_.krylov_iter, s);
+         if (!(fused && one)) { comm.allreduce_sum(S + 8, 1, s); vk_cg_beta(S, opt_.krylov_iter, s); }
          if (fused) {
             vk_cg_step2z(nd, S, cg_z_.p, cg_r_.p, cg_d_.p, ident, s);      // d = z + beta d; z = 0
             op.GradMult(cg_d_.p, cg_z_.p, true, S + 6, true, true);       // z += K d (input masked in the kernel, output mask folded into the dot)
-            vk_mask_dot(nd, nn, op.weight.p, op.ess_mask.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s);
+            vk_mask_dot(nd, nn, op.weight.p, op.ess_mask.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s, one ? S : nullptr);
+            if (!one) { comm.allreduce_sum(S + 8, 1, s); vk_cg_den(S, s); }
          } else {
             vk_cg_step2(nd, S, cg_z_.p, cg_d_.p, s);
             op.GradMult(cg_d_.p, cg_z_.p, true, S + 6);
             vk_dot(nd, nn, op.weight.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s);
+            comm.allreduce_sum(S + 8, 1, s);
+            vk_cg_den(S, s);
          }
-         comm.allreduce_sum(S + 8, 1, s);
-         vk_cg_den(S, s);
       }
       EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 9, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
       done = (hS[6] != 0.0) || launched >= opt_.krylov_iter;

@@ -78,20 +78,31 @@ __global__ void k_cg_init(double* S, double rel, double abs_) {       // after n
    S[0] = nom; S[3] = fmax(nom * rel * rel, abs_ * abs_); S[7] = 0.0;
    S[6] = (nom < 0.0) ? -1.0 : ((nom <= S[3]) ? 1.0 : 0.0);
 }
-__global__ void k_cg_den(double* S) {                                  // den reduced into S[8]
-   if (S[6] != 0.0) return;
+__device__ __forceinline__ void cg_den_update(double* S) {            // den reduced into S[8]
    const double den = S[8];
    S[1] = den;
    if (den <= 0.0) { S[6] = -1.0; return; }
    S[4] = S[0] / den;
 }
-__global__ void k_cg_beta(double* S, double max_iter) {                // betanom reduced into S[8]
-   if (S[6] != 0.0) return;
+__device__ __forceinline__ void cg_beta_update(double* S, double max_iter) {   // betanom reduced into S[8]
    const double bn = S[8];
    S[2] = bn; S[7] += 1.0;
    if (bn <= S[3]) { S[6] = 1.0; return; }
    if (S[7] >= max_iter) { S[6] = 2.0; return; }
    S[5] = bn / S[0]; S[0] = bn;
+}
+__global__ void k_cg_den(double* S) { if (S[6] == 0.0) cg_den_update(S); }
+__global__ void k_cg_beta(double* S, double max_iter) { if (S[6] == 0.0) cg_beta_update(S, max_iter); }
+// one rank: no all-reduce between the reduction of the partial sums and the scalar update, so they are one launch
+// (MODE 1: betanom -> beta, MODE 2: den -> alpha)
+template <int MODE>
+__global__ void k_reduce_cg(int nb, const double* __restrict__ partial, double* __restrict__ S, double max_iter) {
+   __shared__ double sm[RBLK];
+   if (S[6] != 0.0) return;
+   double acc = 0;
+   for (int i = threadIdx.x; i < nb; i += RBLK) acc += partial[i];
+   const double s = block_sum(acc, sm);
+   if (threadIdx.x == 0) { S[8] = s; if (MODE == 1) cg_beta_update(S, max_iter); else cg_den_update(S); }
 }
 
 // x += alpha d; r -= alpha z; z = dinv r; partial of (r, z)_w
@@ -232,19 +243,23 @@ void vk_cg_step2z(int64_t n, const double* S, double* z, const double* r, double
    if (ident) hipLaunchKernelGGL(k_cg_step2z<true>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, r, d);
    else hipLaunchKernelGGL(k_cg_step2z<false>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, r, d);
 }
-void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* a, double* b, const double* flag, double* partial, double* out, hipStream_t s) {
+void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* a, double* b, const double* flag, double* partial, double* out, hipStream_t s, double* fuse_den_S) {
    const unsigned nb = gblk(n);
    hipLaunchKernelGGL(k_mask_dot_partial, dim3(nb), dim3(RBLK), 0, s, n, nn, w, m, a, b, flag, partial);
-   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out);
+   if (fuse_den_S) hipLaunchKernelGGL(k_reduce_cg<2>, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, fuse_den_S, 0.0);
+   else hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out);
 }
 void vk_cg_init(double* S, double rel, double abs_, hipStream_t s) { hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1), 0, s, S, rel, abs_); }
 void vk_cg_den(double* S, hipStream_t s) { hipLaunchKernelGGL(k_cg_den, dim3(1), dim3(1), 0, s, S); }
 void vk_cg_beta(double* S, int max_iter, hipStream_t s) { hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1), 0, s, S, (double)max_iter); }
-void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, bool ident, hipStream_t s) {
+// fuse_beta: one rank, the reduction also performs the beta update (no vk_cg_beta launch afterwards)
+void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, bool ident,
+                 bool fuse_beta, int max_iter, hipStream_t s) {
    const unsigned nb = gblk(n);
    if (ident) hipLaunchKernelGGL(k_cg_step1<true>, dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial);
    else hipLaunchKernelGGL(k_cg_step1<false>, dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial);
-   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S + 6, S + 8);
+   if (fuse_beta) hipLaunchKernelGGL(k_reduce_cg<1>, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S, (double)max_iter);
+   else hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S + 6, S + 8);
 }
 void vk_cg_step2(int64_t n, const double* S, const double* z, double* d, hipStream_t s) { hipLaunchKernelGGL(k_cg_step2, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, d); }
 void vk_pack(int64_t n, const int32_t* idx, const double* y, double* buf, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_pack, dim3(nblk(n)), dim3(256), 0, s, n, idx, y, buf); }
