@@ -444,7 +444,13 @@ inline int kin_update_h(const Model& m, double* hs_u, const double* hs_o, double
 struct Problem {
    const Model* m;
    double dt, dt_ri, detV, detV_ri, p_EOS, tK;
-   double e_n[NTV], Cn_quat[4], d_sm[NTV], w_sm[NWV];
+   // a_V = detV^(1/3).  The library's strain state e ("e_vecd" in the history) is a_V times the lattice-frame deviatoric
+   // elastic strain E that enters the elastic law (Kirchhoff' = K_diag E, E = e / a_V), and BOTH ends of the step are
+   // converted with the END-of-step a_V:  R_e = (e_f - e_n) / (a_V dt) + D^p - D'.  Pinned by the golden curves: the
+   // Kocks-Mecking cases (long elastic-plastic transients) and the elastic unloading branches of the cyclic cases fix
+   // the factor on e_n to a_V(old)/a_V(new) (least-squares exponent 1.00 +- 0.01, tests/golden/README).
+   double a_V, a_V_ri, e_sc;   // e_sc = e_scale / a_V: the unknowns x[0..4] are increments of the state e
+   double e_n[NTV] /* e_n(hist) / a_V */, Cn_quat[4], d_sm[NTV], w_sm[NWV];
    KinVals kv;
    double epsdot_scale_inv, rotincr_scale_inv;
    // by-products of the last evaluation
@@ -457,7 +463,8 @@ inline void problem_init(Problem& pb, const Model& m, double dt, double detV, do
                          const double* h_state, const double* e_n, const double* Cn_quat,
                          const double* d_sm, const double* w_sm) {
    pb.m = &m; pb.dt = dt; pb.dt_ri = 1.0 / dt; pb.detV = detV; pb.detV_ri = 1.0 / detV; pb.p_EOS = p_EOS; pb.tK = tK;
-   for (int i = 0; i < NTV; i++) { pb.e_n[i] = e_n[i]; pb.d_sm[i] = d_sm[i]; }
+   pb.a_V = std::cbrt(detV); pb.a_V_ri = 1.0 / pb.a_V; pb.e_sc = e_scale * pb.a_V_ri;
+   for (int i = 0; i < NTV; i++) { pb.e_n[i] = e_n[i] * pb.a_V_ri; pb.d_sm[i] = d_sm[i]; }
    for (int i = 0; i < 4; i++) pb.Cn_quat[i] = Cn_quat[i];
    for (int i = 0; i < NWV; i++) pb.w_sm[i] = w_sm[i];
    kin_get_vals(m, tK, h_state, pb.kv);
@@ -471,7 +478,7 @@ inline void problem_init(Problem& pb, const Model& m, double dt, double detV, do
 }
 
 inline void problem_state_from_x(const Problem& pb, const double* x, double* e_f, double* quat_f) {
-   for (int i = 0; i < NTV; i++) e_f[i] = pb.e_n[i] + x[i] * e_scale;
+   for (int i = 0; i < NTV; i++) e_f[i] = pb.e_n[i] + x[i] * pb.e_sc;   // E_f = e_f / a_V
    double xi[3] = { x[5] * r_scale, x[6] * r_scale, x[7] * r_scale };
    double A[4]; emap_to_quat(xi, A);
    quat_prod(pb.Cn_quat, A, quat_f);
@@ -487,7 +494,7 @@ inline void problem_cauchy_lat(const Problem& pb, const double* e_f, double* s_l
 inline bool problem_rj(Problem& pb, const double* x, double* R, double* Jac) {
    const Model& m = *pb.m;
    double e_f[NTV], edot[NTV], xi[3];
-   for (int i = 0; i < NTV; i++) { e_f[i] = pb.e_n[i] + x[i] * e_scale; edot[i] = x[i] * e_scale * pb.dt_ri; }
+   for (int i = 0; i < NTV; i++) { e_f[i] = pb.e_n[i] + x[i] * pb.e_sc; edot[i] = x[i] * pb.e_sc * pb.dt_ri; }
    for (int i = 0; i < 3; i++) xi[i] = x[5 + i] * r_scale;
    double A[4], Cq[4], C[3][3], Q5[5][5];
    emap_to_quat(xi, A); quat_prod(pb.Cn_quat, A, Cq); quat_to_tensor(Cq, C); rot_mat_vecd(C, Q5);
@@ -555,7 +562,7 @@ inline bool problem_rj(Problem& pb, const double* x, double* R, double* Jac) {
       double s = 0; for (int k = 0; k < 3; k++) s += Wl[i][k] * Tr[k][j];
       Jrr[i][j] = (i == j ? pb.dt_ri : 0.0) - s;
    }
-   const double se = pb.epsdot_scale_inv * e_scale, sr = pb.epsdot_scale_inv * r_scale;
+   const double se = pb.epsdot_scale_inv * pb.e_sc, sr = pb.epsdot_scale_inv * r_scale;
    for (int k = 0; k < 5; k++) { for (int l = 0; l < 5; l++) Jac[k * 8 + l] = Jee[k][l] * se; for (int j = 0; j < 3; j++) Jac[k * 8 + 5 + j] = Jer[k][j] * sr; }
    for (int i = 0; i < 3; i++) { for (int l = 0; l < 5; l++) Jac[(5 + i) * 8 + l] = Jre[i][l] * se; for (int j = 0; j < 3; j++) Jac[(5 + i) * 8 + 5 + j] = Jrr[i][j] * sr; }
    return true;
@@ -648,7 +655,7 @@ inline void problem_tangent(Problem& pb, const double* x, double bulkNew, const 
    problem_rj(pb, x, r, J);
    // un-scale: J_unscaled(row i, col j) = J / epsdot_scale_inv / (e_scale | r_scale)
    double LU[NSYS * NSYS]; int piv[NSYS];
-   for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) LU[i * 8 + j] = J[i * 8 + j] / pb.epsdot_scale_inv / (j < 5 ? e_scale : r_scale);
+   for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) LU[i * 8 + j] = J[i * 8 + j] / pb.epsdot_scale_inv / (j < 5 ? pb.e_sc : r_scale);
    double e_f[NTV], quat_f[4]; problem_state_from_x(pb, x, e_f, quat_f);
    double xi[3] = { x[5] * r_scale, x[6] * r_scale, x[7] * r_scale };
    double C[3][3], Q5[5][5]; quat_to_tensor(quat_f, C); rot_mat_vecd(C, Q5);
@@ -746,7 +753,7 @@ inline int get_response_sngl(const Model& m, double dt, const double* d_svec_kk_
       hist[iHistA_flowStr] = flow_strength;
    }
    hist[iHistA_nFEval] = st.nfev;
-   for (int i = 0; i < NTV; i++) hist[iHistLbE + i] = e_vecd_u[i];
+   for (int i = 0; i < NTV; i++) hist[iHistLbE + i] = e_vecd_u[i] * pb.a_V;   // state e = a_V E
    double dotq = 0; for (int i = 0; i < 4; i++) dotq += quat_u[i] * quat_n[i];
    for (int i = 0; i < 4; i++) hist[iHistLbQ + i] = (dotq < 0 ? -quat_u[i] : quat_u[i]);
    h_state[0] = h_state_u[0];

@@ -1,12 +1,13 @@
 """Pins the CPU oracle to the reference's own golden vectors (reference test/data/*_stress.txt etc., 6 printed digits;
-the reference's own check is test/test_mechanics.py:22-30 on the printed text).
+the reference's own check is equality of the printed text, test/test_mechanics.py:22-30).
+
+Bar: every printed number of every golden file is reproduced to within ONE unit of its last printed digit (most rows
+are identical text), and sigma_33 within 3e-6 rel-L2 (the 6-digit quantisation floor is 4e-7 ... 2.4e-6).
 
 Two layers so that the CPU suite stays within minutes:
   * live: the first steps of every regression case are re-run on the oracle and compared with the golden rows;
   * stored: full-length oracle runs (tests/golden/oracle_curves/*.npz, produced by tests/golden/make_oracle_curves.py) are
     compared with the complete golden files, and the live rows must reproduce the stored rows.
-Tolerances: Voce cases agree to the golden files' print precision (<= 3e-6 relative on sigma_33); the Kocks-Mecking cases agree
-to <= 2e-5 (an unexplained transient of ~1e-5 in the elastic-plastic transition; see DESIGN.md "oracle pinning").
 """
 import os
 
@@ -15,31 +16,60 @@ import pytest
 
 CURVES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_curves")
 
-LIVE = [("voce_pa", "voce_pa", 4, 3e-6), ("voce_ea_cs", "voce_ea_cs", 3, 3e-6), ("voce_bcc", "voce_bcc", 3, 3e-6), ("voce_nl_full", "voce_full", 3, 3e-6),
-        ("mtsdd_full", "mtsdd_full", 5, 2e-5), ("mtsdd_bcc", "mtsdd_bcc", 5, 2e-5)]
+
+def printed_ulps(orc, s, g, floor=1e-6):
+    """|round6(s) - g| in units of g's last printed digit, for the entries that are not round-off noise
+    (|g| > floor * max|g| of the file); returns (ulps of those entries, max abs difference of the rest)."""
+    s = np.asarray(s, dtype=np.float64).reshape(np.shape(g))
+    big = np.abs(g) > floor * np.abs(g).max()
+    unit = 10.0 ** (np.floor(np.log10(np.abs(np.where(big, g, 1.0)))) - 5)
+    u = np.abs(orc.fmt6(s) - g) / unit
+    rest = np.abs(s - g)[~big].max() if (~big).any() else 0.0
+    return u[big], rest
 
 
-@pytest.mark.parametrize("name,gold,nsteps,tol", LIVE)
-def test_live_steps_match_golden(oracle, name, gold, nsteps, tol):
+def col_unit(col):
+    """One unit of the last printed digit of the column's largest entry."""
+    return 10.0 ** (np.floor(np.log10(np.abs(col).max())) - 5)
+
+
+def check_file(orc, s, gold_name, max_ulp=1.0, rest_tol=2e-8):
+    g = orc.golden(gold_name)
+    u, rest = printed_ulps(orc, s, g)
+    assert u.max() <= max_ulp + 1e-6, (gold_name, u.max(), int((u > 0).sum()), u.size)
+    assert rest < rest_tol * max(np.abs(g).max(), 1e-30) + 1e-300, (gold_name, rest)
+    return u
+
+
+LIVE = [("voce_pa", "voce_pa", 4), ("voce_ea_cs", "voce_ea_cs", 3), ("voce_bcc", "voce_bcc", 3), ("voce_nl_full", "voce_full", 3),
+        ("mtsdd_full", "mtsdd_full", 5), ("mtsdd_bcc", "mtsdd_bcc", 5)]
+
+
+@pytest.mark.parametrize("name,gold,nsteps", LIVE)
+def test_live_steps_match_golden(oracle, name, gold, nsteps):
     orc = oracle
     out = orc.run_case(orc.load_case(name + ".toml"), nsteps=nsteps)
     assert out["failed"] == 0
     g = orc.golden(gold + "_stress.txt")[:nsteps]
     s = out["avg_stress"]
-    assert np.max(np.abs(s[:, 2] / g[:, 2] - 1.0)) < tol
-    assert np.max(np.abs(s[:, 3:] - g[:, 3:])) < max(tol, 3e-6) * np.abs(g[:, 2]).max()
+    u, _ = printed_ulps(orc, s[:, 2], g[:, 2])
+    assert u.max() <= 1.0 + 1e-6
+    gfull = orc.golden(gold + "_stress.txt")
+    for c in (3, 4, 5):     # shear averages cross zero: measure against the column's own scale
+        assert np.max(np.abs(orc.fmt6(s[:, c]) - g[:, c])) <= 1.001 * col_unit(gfull[:, c])
     f = os.path.join(CURVES, name + ".npz")
     if os.path.exists(f):
         st = np.load(f)["avg_stress"][:nsteps]
         assert np.allclose(s, st, rtol=1e-9, atol=1e-16)
 
 
-STORED = [("voce_pa", "voce_pa", 3e-6), ("voce_bcc", "voce_bcc", 3e-6), ("voce_nl_full", "voce_full", 3e-6), ("voce_ea", "voce_ea", 3e-6), ("voce_ea_cs", "voce_ea_cs", 3e-6),
-          ("mtsdd_full", "mtsdd_full", 2e-5), ("mtsdd_bcc", "mtsdd_bcc", 2e-5)]
+STORED = [("voce_pa", "voce_pa"), ("voce_bcc", "voce_bcc"), ("voce_nl_full", "voce_full"), ("voce_ea", "voce_ea"), ("voce_ea_cs", "voce_ea_cs"),
+          ("mtsdd_full", "mtsdd_full"), ("mtsdd_bcc", "mtsdd_bcc"),
+          ("voce_full_cyclic", "voce_full_cyclic"), ("voce_full_cyclic_cs", "voce_full_cyclic_cs"), ("voce_full_cyclic_csm", "voce_full_cyclic_csm")]
 
 
-@pytest.mark.parametrize("name,gold,tol", STORED)
-def test_stored_full_curves_match_golden(oracle, name, gold, tol):
+@pytest.mark.parametrize("name,gold", STORED)
+def test_stored_full_curves_match_golden(oracle, name, gold):
     orc = oracle
     f = os.path.join(CURVES, name + ".npz")
     if not os.path.exists(f):
@@ -47,61 +77,46 @@ def test_stored_full_curves_match_golden(oracle, name, gold, tol):
     s = np.load(f)["avg_stress"]
     g = orc.golden(gold + "_stress.txt")
     assert s.shape == g.shape
-    assert np.max(np.abs(s[:, 2] / g[:, 2] - 1.0)) < tol
-    assert np.max(np.abs(s[:, 3:] - g[:, 3:])) < max(tol, 3e-6) * np.abs(g[:, 2]).max()
+    # sigma_33: the north-star bar (1e-6 of the CPU reference is below the files' own 6-digit resolution; 3e-6 rel-L2)
+    assert np.linalg.norm(s[:, 2] - g[:, 2]) / np.linalg.norm(g[:, 2]) < 3e-6
+    u, _ = printed_ulps(orc, s[:, 2], g[:, 2])
+    assert u.max() <= 1.0 + 1e-6, (name, u.max())
+    # monotonic cases: the printed sigma_33 column is reproduced digit for digit
+    if "cyclic" not in name:
+        assert int((u > 0).sum()) == 0, (name, int((u > 0).sum()))
+    else:
+        assert int((u > 0).sum()) <= 3
+    # shear averages (1e-4 of sigma_33; they cross zero, so measure against the column's own scale)
+    for c in (3, 4, 5):
+        assert np.max(np.abs(orc.fmt6(s[:, c]) - g[:, c])) <= 1.001 * col_unit(g[:, c]), (name, c)
+    # sigma_11, sigma_22 are solver noise around zero in both
+    assert np.abs(s[:, :2]).max() < 1e-6 * np.abs(g[:, 2]).max() and np.abs(g[:, :2]).max() < 1e-6 * np.abs(g[:, 2]).max()
 
 
-def test_stored_voce_ea_extra_outputs(oracle):
-    """def_grad / pl_work / dp_tensor files of the EA case (reference src/system_driver.cpp:470-553)."""
+@pytest.mark.parametrize("name", ["voce_ea", "voce_ea_cs"])
+def test_stored_extra_outputs(oracle, name):
+    """def_grad / pl_work / dp_tensor files of the EA cases (reference src/system_driver.cpp:470-553), velocity- and
+    velocity-gradient-driven: every printed number within one unit of its last digit."""
     orc = oracle
-    f = os.path.join(CURVES, "voce_ea.npz")
+    f = os.path.join(CURVES, name + ".npz")
     if not os.path.exists(f):
         pytest.skip("stored curve not generated")
     z = np.load(f)
-    assert np.max(np.abs(z["avg_def_grad"] - orc.golden("voce_ea_def_grad.txt"))) < 6e-6
-    gw = orc.golden("voce_ea_pl_work.txt").ravel()
-    assert np.max(np.abs(z["avg_pl_work"][1:] / gw[1:] - 1.0)) < 5e-5
-    gd = orc.golden("voce_ea_dp_tensor.txt")
-    assert np.max(np.abs(z["avg_dp_tensor"] - gd)) < 5e-5 * np.abs(gd).max()
+    check_file(orc, z["avg_def_grad"], name + "_def_grad.txt")
+    check_file(orc, z["avg_pl_work"], name + "_pl_work.txt")
+    check_file(orc, z["avg_dp_tensor"], name + "_dp_tensor.txt")
 
 
-def test_stored_cyclic_curve(oracle):
-    """Load reversals (BC-change corrector, reference src/system_driver.cpp:293-319): after each reversal the answer is only
-    defined to the case's Newton tolerance (rel 5e-5 of a large initial residual)."""
+def test_cyclic_reversal_branches(oracle):
+    """Load reversals (BC-change corrector, reference src/system_driver.cpp:293-319).  The elastic unloading branches and the
+    re-yield transients are what pins the strain state's a_V scaling (oracle/ecmech_port.hpp, struct Problem): with the
+    begin-of-step strain converted by the END-of-step a_V every branch is reproduced to the printed digits."""
     orc = oracle
     f = os.path.join(CURVES, "voce_full_cyclic.npz")
     if not os.path.exists(f):
         pytest.skip("stored curve not generated")
     s = np.load(f)["avg_stress"]
     g = orc.golden("voce_full_cyclic_stress.txt")
-    assert s.shape == g.shape
-    assert np.max(np.abs(s[:, 2] - g[:, 2])) < 5e-5 * np.abs(g[:, 2]).max()
-    assert np.max(np.abs(s[:10, 2] / g[:10, 2] - 1.0)) < 6e-6
-
-
-@pytest.mark.parametrize("name", ["voce_full_cyclic_cs", "voce_full_cyclic_csm"])
-def test_stored_cyclic_velocity_gradient_curves(oracle, name):
-    """Constant-true-strain-rate (velocity-gradient) boundary conditions with load reversals
-    (reference src/system_driver.cpp:338-426); same Newton-tolerance caveat as the velocity-driven cyclic case."""
-    orc = oracle
-    f = os.path.join(CURVES, name + ".npz")
-    if not os.path.exists(f):
-        pytest.skip("stored curve not generated")
-    s = np.load(f)["avg_stress"]
-    g = orc.golden(name + "_stress.txt")
-    assert s.shape == g.shape
-    assert np.max(np.abs(s[:, 2] - g[:, 2])) < 5e-5 * np.abs(g[:, 2]).max()
-    assert np.max(np.abs(s[:10, 2] / g[:10, 2] - 1.0)) < 6e-6
-
-
-def test_stored_voce_ea_cs_extra_outputs(oracle):
-    orc = oracle
-    f = os.path.join(CURVES, "voce_ea_cs.npz")
-    if not os.path.exists(f):
-        pytest.skip("stored curve not generated")
-    z = np.load(f)
-    assert np.max(np.abs(z["avg_def_grad"] - orc.golden("voce_ea_cs_def_grad.txt"))) < 6e-6
-    gw = orc.golden("voce_ea_cs_pl_work.txt").ravel()
-    assert np.max(np.abs(z["avg_pl_work"][1:] / gw[1:] - 1.0)) < 5e-5
-    gd = orc.golden("voce_ea_cs_dp_tensor.txt")
-    assert np.max(np.abs(z["avg_dp_tensor"] - gd)) < 5e-5 * np.abs(gd).max()
+    assert np.max(np.abs(s[:, 2] - g[:, 2])) < 3e-6 * np.abs(g[:, 2]).max()
+    for lo, hi in ((10, 14), (30, 34), (50, 54)):      # elastic unloading branches
+        assert np.max(np.abs(s[lo:hi, 2] - g[lo:hi, 2])) < 1e-6 * np.abs(g[:, 2]).max()
