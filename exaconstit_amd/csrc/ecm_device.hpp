@@ -420,10 +420,13 @@ constexpr int CD_DSM = 0, CD_SOLD = 5, CD_QN = 10, CD_VOLD = 14, CD_VNEW = 15, C
 #define ECM_CD(c) (*(((c) < ST_NCD) ? &ECM_ST(st, ST_CD + (((c) < ST_NCD) ? (c) : 0)) : &cold[(c) * QS]))
 
 // ------------------------------------------------------------------------------------------------------------
-// the point problem: unknowns x = (delta e' / E_SCALE, xi / R_SCALE)
+// the point problem: unknowns x = (delta e / E_SCALE, xi / R_SCALE).  e is the library's strain STATE = a_V * E with a_V = detV^(1/3)
+// (end of step) and E the lattice-frame deviatoric elastic strain of the elastic law; the stash holds E_n = e_n / a_V, so that inside the
+// solve everything is in terms of E and x only needs the factor esc = E_SCALE / a_V (oracle/ecmech_port.hpp, struct Problem)
 // ------------------------------------------------------------------------------------------------------------
 struct Prob {
    double dt_ri, detV_ri, sc, sc_i, g_i;   // sc = epsdot_scale_inv, sc_i = 1/sc, g_i = 1/g
+   double esc, esc_i;                      // E_SCALE / a_V and its inverse
    double* st;                             // per-thread stash
    int gs;                                 // stride of the slip-rate outputs (1 or 64, see point_update's QS)
    KinVals kv;
@@ -446,7 +449,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
    double k[5];
    { double e_f[5];
 #pragma unroll
-     for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(pb.st, ST_EN + i) + x[i] * E_SCALE;
+     for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(pb.st, ST_EN + i) + x[i] * pb.esc;
      k[0] = mp.kd0 * e_f[0]; k[1] = mp.kd0 * e_f[1]; k[2] = mp.kd2 * e_f[2]; k[3] = mp.kd2 * e_f[3]; k[4] = mp.kd2 * e_f[4]; }
    const double g_i = pb.g_i;
    double dis = 0.0, shr = 0.0;
@@ -572,7 +575,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       rot_vecd_T(A, dn, d_lat);
 #pragma unroll
       for (int c = 0; c < 5; c++) {
-         r[c] = (x[c] * (E_SCALE * pb.dt_ri) + dp[c] - d_lat[c]) * pb.sc;
+         r[c] = (x[c] * (pb.esc * pb.dt_ri) + dp[c] - d_lat[c]) * pb.sc;
          if (WITHJ) jac.dl[c] = d_lat[c];
       }
    }
@@ -823,10 +826,12 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       const double h_u = kin_update_h<KIN>(mp, sv0[(H_H) * QS], dt, shrate_o);
       // ---- point problem set-up
       pb.detV_ri = 1.0 / vNew;
+      const double a_V_ri = 1.0 / cbrt(vNew);
+      pb.esc = E_SCALE * a_V_ri; pb.esc_i = 1.0 / pb.esc;
       double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += sv0[(H_Q + i) * QS] * sv0[(H_Q + i) * QS]; const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = sv0[(H_Q + i) * QS] * ni; }
       double Cn[9]; quat_to_mat(qn, Cn);
       double dn[5]; rot_vecd_T(Cn, d_sm, dn);
-      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = sv0[(H_E + i) * QS]; ECM_CD(CD_DSM + i) = d_sm[i]; ECM_CD(CD_SOLD + i) = s_old[i]; }
+      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = sv0[(H_E + i) * QS] * a_V_ri; ECM_CD(CD_DSM + i) = d_sm[i]; ECM_CD(CD_SOLD + i) = s_old[i]; }
       for (int i = 0; i < 3; i++) ECM_ST(st, ST_WN + i) = Cn[i] * w_sm[0] + Cn[3 + i] * w_sm[1] + Cn[6 + i] * w_sm[2];
       for (int i = 0; i < 4; i++) ECM_CD(CD_QN + i) = qn[i];
       ECM_CD(CD_VOLD) = vOld; ECM_CD(CD_VNEW) = vNew; ECM_CD(CD_ENEW) = eNew; ECM_CD(CD_DEFF) = dEff; ECM_CD(CD_BULK) = bulkNew; ECM_CD(CD_HU) = h_u;
@@ -866,7 +871,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          if (F.ok) {
             double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i] * pb.sc_i;
             jac_solve<false, 2>(mp, pb, J, F, rhs, t);
-            for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? (1.0 / E_SCALE) : (1.0 / R_SCALE));
+            for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? pb.esc_i : (1.0 / R_SCALE));
             nr2norm = norm8(nr);
          } else { nr2norm = 1e300; for (int i = 0; i < 8; i++) nr[i] = 0; }
          double delx[8], pred_resid; bool use_nr = false;
@@ -874,7 +879,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          else {
             double grad[8], u[8];
             jac_mult_T(mp, pb, J, r, t);
-            for (int i = 0; i < 8; i++) { const double cs = (i < 5) ? E_SCALE : R_SCALE; grad[i] = pb.sc * cs * t[i]; u[i] = cs * grad[i]; }
+            for (int i = 0; i < 8; i++) { const double cs = (i < 5) ? pb.esc : R_SCALE; grad[i] = pb.sc * cs * t[i]; u[i] = cs * grad[i]; }
             jac_mult(mp, pb, J, u, t);
             double Jg_2 = 0, norm2_grad = 0;
             for (int i = 0; i < 8; i++) { const double jg = pb.sc * t[i]; Jg_2 += jg * jg; norm2_grad += grad[i] * grad[i]; }
@@ -923,7 +928,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    }
    // ---- converged state: stress, energy, history (getResponseSngl tail + reference kernel_postprocessing src/mechanics_ecmech.cpp:116-152)
    double e_f[5], xi[3];
-   for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(st, ST_EN + i) + x[i] * E_SCALE;
+   for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(st, ST_EN + i) + x[i] * pb.esc;
    for (int i = 0; i < 3; i++) xi[i] = x[5 + i] * R_SCALE;
    double Cf[9];
    {
@@ -956,7 +961,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       sv1[(H_SHR) * QS] = sv0[(H_SHR) * QS] + shrate * dt;
       sv1[(H_FLOW) * QS] = ((ECM_CD(CD_DEFF) > TINY_SQRT) ? dis_rate * dt : 0.0) + sv0[(H_FLOW) * QS];   // accumulated plastic work
       sv1[(H_NFEV) * QS] = (double)nfev;
-      for (int i = 0; i < 5; i++) sv1[(H_E + i) * QS] = e_f[i];
+      { const double a_V = E_SCALE * pb.esc_i; for (int i = 0; i < 5; i++) sv1[(H_E + i) * QS] = e_f[i] * a_V; }   // state e = a_V E
       if constexpr (!kin_is_km(KIN)) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS);
       sv1[(H_H) * QS] = ECM_CD(CD_HU);
       sv1[(IND_VOL) * QS] = vNew; sv1[(IND_EINT) * QS] = eNew;

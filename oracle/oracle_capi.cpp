@@ -26,8 +26,7 @@ struct orc_result {
    int steps_done; double* dts_used;   // auto time stepping: rows actually produced, dt per row (may be null)
 };
 
-int orc_run_case(const orc_case* c, orc_result* r) {
-   drv::Config cfg;
+static void fill_config(const orc_case* c, drv::Config& cfg) {
    cfg.nx = c->nx; cfg.ny = c->ny; cfg.nz = c->nz; cfg.p = c->p; cfg.sx = c->sx; cfg.sy = c->sy; cfg.sz = c->sz;
    cfg.xtal = c->xtal; cfg.kin = c->kin; cfg.props.assign(c->props, c->props + c->nprops); cfg.temp_k = c->temp_k;
    const int E = c->nx * c->ny * c->nz;
@@ -51,6 +50,10 @@ int orc_run_case(const orc_case* c, orc_result* r) {
    cfg.krylov_rel = c->krylov_rel; cfg.krylov_abs = c->krylov_abs; cfg.krylov_iter = c->krylov_iter;
    cfg.additional_avgs = c->additional_avgs != 0; cfg.second_order_terms = c->second_order_terms != 0;
    cfg.use_input_temperature = c->use_input_temperature != 0; cfg.verbose = c->verbose;
+}
+
+int orc_run_case(const orc_case* c, orc_result* r) {
+   drv::Config cfg; fill_config(c, cfg);
    drv::Result res;
    drv::run_case(cfg, res);
    const int ns = (int)(res.avg_stress.size() / 6);   // completed steps (== c->nsteps unless auto time stepping stopped early)
@@ -135,6 +138,20 @@ void orc_vol_avg(int Q, int E, int vdim, const double* W, const double* J, const
 void orc_calc_dp_mat(int xtal, int64_t P, int nstatev, const double* state1, double* dp) {
    ecm::Model mdl; std::memset(&mdl, 0, sizeof(mdl)); mdl.xtal = xtal; ecm::slip_geom_init(mdl);
    fem::calc_dp_mat(mdl, (size_t)P, nstatev, state1, dp);
+}
+
+
+// Time.Auto replay guided by a golden sigma_33 column (driver_port.hpp: run_case_replay).  ks_out: chosen Newton count per row.
+int orc_run_case_replay(const orc_case* c, const double* target33, int nrows, orc_result* r, int* ks_out, int increments) {
+   drv::Config cfg; fill_config(c, cfg);
+   drv::Result res; std::vector<int> ks;
+   drv::run_case_replay(cfg, std::vector<double>(target33, target33 + nrows), res, ks, increments != 0);
+   const int ns = (int)(res.avg_stress.size() / 6);
+   r->steps_done = ns;
+   for (int i = 0; i < 6 * ns; i++) r->avg_stress[i] = res.avg_stress[i];
+   for (int i = 0; i < ns; i++) { if (r->dts_used) r->dts_used[i] = res.dts_used[i]; ks_out[i] = ks[i]; }
+   r->failed = res.failed;
+   return res.failed;
 }
 
 }  // extern "C"

@@ -131,8 +131,10 @@ def load_case(toml_name, datadir=REFDATA):
     )
 
 
-def run_case(case, nsteps=None, precond=0, second_order_terms=False, use_input_temperature=False, verbose=0):
-    """Run a regression case on the oracle; returns dict of arrays."""
+def run_case(case, nsteps=None, precond=0, second_order_terms=False, use_input_temperature=False, verbose=0, replay_target33=None, replay_increments=False):
+    """Run a regression case on the oracle; returns dict of arrays.
+    replay_target33 (Time.Auto cases only): golden sigma_33 column; the step sizes are then chosen among the reference's admissible
+    candidates so as to follow it (oracle/driver_port.hpp run_case_replay) and out["ks"] holds the Newton counts this implies."""
     L = lib()
     auto = case.get("auto") if case.get("dts") is None else None
     if auto is not None:      # Time.Auto: nsteps = row capacity (reference: ceil(t_final / dt_min), src/mechanics_driver.cpp:212)
@@ -167,7 +169,13 @@ def run_case(case, nsteps=None, precond=0, second_order_terms=False, use_input_t
     dts_used = np.zeros(ns)
     r = OrcResult(_p(out["avg_stress"]), _p(out["avg_def_grad"]), _p(out["avg_pl_work"]), _p(out["avg_dp_tensor"]),
                   _ip(out["newton_iters"]), _ip(out["krylov_iters"]), _ip(out["model_calls"]), 0, 0, 0, 0, 0, 0, _p(dts_used))
-    L.orc_run_case(C.byref(c), C.byref(r))
+    if replay_target33 is not None:
+        tgt = np.ascontiguousarray(replay_target33, dtype=np.float64)
+        ks = np.zeros(ns, np.int32)
+        L.orc_run_case_replay(C.byref(c), _p(tgt), len(tgt), C.byref(r), _ip(ks), int(replay_increments))
+        out["ks"] = ks[: r.steps_done]
+    else:
+        L.orc_run_case(C.byref(c), C.byref(r))
     if auto is not None:
         for k in list(out):
             out[k] = out[k][: r.steps_done]
