@@ -1,4 +1,5 @@
 // C ABI of libexaconstit_hip.so — see include/exaconstit_hip.h for the reference interfaces each entry replaces.
+#include <climits>
 #include "exa_internal.hpp"
 #include <cstring>
 #include <cstdio>
@@ -44,7 +45,9 @@ extern "C" {
 
 exa_ctx* exa_create(const exa_config* cfg, int* err) {
    auto set = [&](int e) { if (err) *err = e; };
-   if (!cfg || cfg->nelems <= 0 || cfg->order < 1 || cfg->order > 3) { set(EXA_ERR_ARG); return nullptr; }
+   // p = 1 and p = 2 are the orders every entry point is built and tested for; point ids of the tail-split list are 32-bit
+   if (!cfg || cfg->nelems <= 0 || cfg->order < 1 || cfg->order > 2) { set(EXA_ERR_ARG); return nullptr; }
+   { const int64_t np1 = cfg->order + 1; if ((int64_t)cfg->nelems * np1 * np1 * np1 >= (int64_t)INT32_MAX) { set(EXA_ERR_ARG); return nullptr; } }
    exa_ctx* ctx = new exa_ctx();
    ctx->cfg = *cfg; ctx->cfg.props = nullptr;
    if (!exa_fill_mat_params(*cfg, ctx->mp, ctx->hist_init, ctx->err)) { std::fprintf(stderr, "exa_create: %s\n", ctx->err.c_str()); delete ctx; set(EXA_ERR_ARG); return nullptr; }

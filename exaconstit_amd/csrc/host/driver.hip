@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <cmath>
+#include <limits>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -317,6 +318,9 @@ void NonlinearMechOperator::Setup(const double* k) {
    EXA_HC(hipEventSynchronize(ev1_));
    float ms = 0; EXA_HC(hipEventElapsedTime(&ms, ev0_, ev1_));
    timers.t_model_ms += ms; timers.qpt_updates += (int64_t)E_ * npe_; model_calls++;
+   model_fail = exa_model_status(ctx_, stream_);   // the launch has completed (ev1_): one 4-byte read-back
+   if (model_fail < 0) abi_check(ctx_, model_fail, "exa_model_status");
+   model_fail_total += model_fail;
    if (cap_auto_ && (model_calls <= 4 || model_calls % 4 == 0)) {   // tail split: next cap from the evaluation counts of this launch (the distribution drifts slowly)
       int h[64]; abi_check(ctx_, exa_model_nfev_hist(ctx_, matVars1.p, h, stream_), "exa_model_nfev_hist");
       newton_cap_ = choose_newton_cap(h, tail_cost_);
@@ -402,6 +406,15 @@ double NonlinearMechOperator::dot(const double* a, const double* b) {
    return h;
 }
 
+// ||r|| over all ranks; +inf everywhere if any rank saw an unconverged constitutive point in the launch that produced r
+double NonlinearMechOperator::ResidualNorm(const double* r) {
+   vk_dot(nd_, nn_, weight.p, r, r, nullptr, partial.p, scal.p + 9, stream_);
+   if (model_fail > 0) { const double inf = std::numeric_limits<double>::infinity(); EXA_HC(hipMemcpyAsync(scal.p + 9, &inf, sizeof(double), hipMemcpyHostToDevice, stream_)); EXA_HC(hipStreamSynchronize(stream_)); }
+   comm_.allreduce_sum(scal.p + 9, 1, stream_);
+   double h; EXA_HC(hipMemcpyAsync(&h, scal.p + 9, sizeof(double), hipMemcpyDeviceToHost, stream_)); EXA_HC(hipStreamSynchronize(stream_));
+   return std::sqrt(h);
+}
+
 void NonlinearMechOperator::UpdateModel() { model_->UpdateModelVars(); model_->UpdateStress(); model_->UpdateStateVars(); }
 void NonlinearMechOperator::SwapCoords() { x_beg.copy_from(x_cur, stream_); }
 
@@ -474,6 +487,9 @@ void SystemDriver::UpdateEssBdr(const BCEntry& bc) {
    for (size_t b = 0; b < bc.ids.size(); b++) {
       bool c[3] = { false, false, false };
       const bool is_vg = bc.comps[b] < 0;
+      if (bc.ids[b] < 1 || bc.ids[b] > part.num_bdr_attr())
+         throw std::runtime_error("BCs.essential_ids: boundary attribute " + std::to_string(bc.ids[b]) + " does not exist (the mesh has " + std::to_string(part.num_bdr_attr()) + ")");
+      if (std::abs(bc.comps[b]) > 7) throw std::runtime_error("BCs.essential_comps: component code " + std::to_string(bc.comps[b]) + " is not one of 0..7 (negative: velocity gradient)");
       switch (std::abs(bc.comps[b])) { case 1: c[0] = true; break; case 2: c[1] = true; break; case 3: c[2] = true; break; case 4: c[0] = c[1] = true; break;
                                        case 5: c[1] = c[2] = true; break; case 6: c[0] = c[2] = true; break; case 7: c[0] = c[1] = c[2] = true; break; default: break; }
       for (int g = 0; g < nn; g++) if (part.on_face(g, bc.ids[b])) for (int k = 0; k < 3; k++) if (c[k]) {
@@ -512,7 +528,7 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    EXA_HC(hipMemcpyAsync(cg_r_.p, b, sizeof(double) * nd, hipMemcpyDeviceToDevice, s));
    vk_pointwise(nd, op.dinv.p, cg_r_.p, cg_z_.p, s);
    EXA_HC(hipMemcpyAsync(cg_d_.p, cg_z_.p, sizeof(double) * nd, hipMemcpyDeviceToDevice, s));
-   EXA_HC(hipMemsetAsync(S, 0, sizeof(double) * 9, s));
+   EXA_HC(hipMemsetAsync(S, 0, sizeof(double) * 11, s));
    vk_dot(nd, nn, op.weight.p, cg_d_.p, cg_r_.p, nullptr, op.partial.p, S + 8, s);
    comm.allreduce_sum(S + 8, 1, s);
    vk_cg_init(S, opt_.krylov_rel, opt_.krylov_abs, s);
@@ -520,7 +536,7 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    vk_dot(nd, nn, op.weight.p, cg_z_.p, cg_d_.p, S + 6, op.partial.p, S + 8, s);
    comm.allreduce_sum(S + 8, 1, s);
    vk_cg_den(S, s);
-   double hS[9]; int launched = 0; bool done = false;
+   double hS[11]; int launched = 0; bool done = false;
    const bool fused = std::getenv("EXA_PCG_UNFUSED") == nullptr;   // A/B switch for measurements
    // One rank: the scalar updates ride in the reductions (no all-reduce in between).  (Summing the denominator d.(K d) element-wise
    // inside the action, with its scatter skipping the essential rows, was measured too: the pass it saves costs what it adds to the
@@ -545,13 +561,21 @@ int SystemDriver::CGSolve(const double* b, double* x) {
             vk_cg_den(S, s);
          }
       }
-      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 9, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 11, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
       done = (hS[6] != 0.0) || launched >= opt_.krylov_iter;
    }
    EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
    float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
    const int iters = (hS[6] == 1.0 && hS[7] == 0.0) ? 0 : (int)hS[7];
    op.timers.t_krylov_ms += ms; op.timers.krylov_iters += iters;
+   // what MFEM prints (CGSolver::Mult): breakdown, indefinite operator, no convergence within max_iter
+   last_cg_flag = (int)hS[6]; cg_indefinite_iters += (int64_t)hS[10];
+   if (hS[6] != 1.0) cg_not_converged++;
+   if (comm.rank == 0 && (verbose || std::getenv("EXA_VERBOSE"))) {
+      if (hS[10] > 0.0) std::cerr << "PCG: The operator is not positive definite. (Ad, d) < 0 in " << (int)hS[10] << " iteration(s)\n";
+      if (hS[6] == -1.0) std::cerr << "PCG: (Ad, d) = 0, stopping after " << iters << " iterations\n";
+      else if (hS[6] != 1.0) std::cerr << "PCG: No convergence! (" << iters << " iterations)\n";
+   }
    return iters;
 }
 
@@ -562,7 +586,7 @@ bool SystemDriver::NewtonSolve(double* x, SolverStats& st) {
    const int64_t nd = op.Height();
    const int calls0 = op.model_calls;
    op.Mult(x, r_.p);
-   double norm = std::sqrt(op.dot(r_.p, r_.p)), norm_prev;
+   double norm = op.ResidualNorm(r_.p), norm_prev;
    const double norm_max = std::max(opt_.newton_rel * norm, opt_.newton_abs);
    double scale = 1.0; bool converged = false; int it;
    for (it = 0; true; it++) {
@@ -574,16 +598,16 @@ bool SystemDriver::NewtonSolve(double* x, SolverStats& st) {
       if (opt_.nl_solver == NLSolver::NRLS) {
          const double q1 = norm;
          EXA_HC(hipMemcpyAsync(xt_.p, x, sizeof(double) * nd, hipMemcpyDeviceToDevice, s)); vk_axpby(nd, -1.0, c_.p, 1.0, xt_.p, s);
-         op.Mult(xt_.p, r_.p); const double q3 = std::sqrt(op.dot(r_.p, r_.p));
+         op.Mult(xt_.p, r_.p); const double q3 = op.ResidualNorm(r_.p);
          EXA_HC(hipMemcpyAsync(xt_.p, x, sizeof(double) * nd, hipMemcpyDeviceToDevice, s)); vk_axpby(nd, -0.5, c_.p, 1.0, xt_.p, s);
-         op.Mult(xt_.p, r_.p); const double q2 = std::sqrt(op.dot(r_.p, r_.p));
+         op.Mult(xt_.p, r_.p); const double q2 = op.ResidualNorm(r_.p);
          const double eps = (3.0 * q1 - 4.0 * q2 + q3) / (4.0 * (q1 - 2.0 * q2 + q3));
          if ((q1 - 2.0 * q2 + q3) > 0 && eps > 0 && eps < 1) scale = eps; else if (q3 < q1) scale = 1.0; else scale = 0.05;
       }
       if (scale == 0.0) { converged = false; break; }
       vk_axpby(nd, -scale, c_.p, 1.0, x, s);
       op.Mult(x, r_.p);
-      norm_prev = norm; norm = std::sqrt(op.dot(r_.p, r_.p));
+      norm_prev = norm; norm = op.ResidualNorm(r_.p);
       if (opt_.nl_solver == NLSolver::NR) scale = (norm / norm_prev > 0.5) ? 0.5 : 1.0;
    }
    st.newton_iters = it; st.converged = converged; st.model_calls += op.model_calls - calls0;
@@ -707,7 +731,10 @@ bool SystemDriver::Step(int ti) {
 
 int SystemDriver::RunAll() {
    for (int ti = 1; ti <= opt_.nsteps; ti++) {
-      if (!Step(ti)) { if (comm.rank == 0) std::cerr << "Newton Solver did not converge.\n"; return -ti; }
+      if (!Step(ti)) {
+         if (comm.rank == 0) std::cerr << "Newton Solver did not converge" << (oper_->model_fail > 0 ? " (the constitutive update failed at quadrature points of the last evaluation)" : "") << ".\n";
+         return -ti;
+      }
       if (!opt_.dt_cust) { const double dtl = opt_.dt_auto ? last_dt_ : opt_.dt; if (std::fabs(time - opt_.t_final) <= std::fabs(1e-3 * dtl)) break; }
    }
    return steps_done;

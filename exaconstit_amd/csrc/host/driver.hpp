@@ -108,6 +108,11 @@ class NonlinearMechOperator {
    Precond precond = Precond::IDENTITY;
    Timers timers;
    int model_calls = 0;
+   // quadrature points whose local (ExaCMech) solve did not converge in the last constitutive launch.  The library fails the run
+   // in that case (ECMECH_FAIL in getResponseSngl); here a non-zero count poisons the next residual norm on every rank, so that
+   // Newton reports non-convergence: Time.Auto then cuts dt, otherwise the run stops.
+   int model_fail = 0; int64_t model_fail_total = 0;
+   double ResidualNorm(const double* r);
    double dot(const double* a, const double* b);   // weighted, all-reduced, synchronising
    DevBuf<double> partial, scal;
  private:
@@ -144,6 +149,10 @@ class SystemDriver {
    bool write_files = true; std::string out_dir = ".";
    Precond precond = Precond::IDENTITY;
    int cg_check_every = 16;
+   // linear-solver diagnostics (MFEM's CGSolver prints these): flag of the last solve (1 converged, 2 max_iter, -1 den == 0),
+   // number of solves that did not converge, iterations that saw (Ad, d) < 0
+   int last_cg_flag = 1; int64_t cg_not_converged = 0, cg_indefinite_iters = 0;
+   bool verbose = false;
    Partition part;
    Comm comm;
  private:

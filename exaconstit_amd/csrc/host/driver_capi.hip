@@ -100,6 +100,11 @@ void exa_driver_get_timers(exa_driver* d, double* out) {
    out[0] = t.t_model_ms; out[1] = t.t_krylov_ms; out[2] = t.t_solve_ms; out[3] = (double)t.qpt_updates; out[4] = (double)t.krylov_iters;
 }
 void exa_driver_reset_timers(exa_driver* d) { d->sd->oper().timers = Timers(); }
+// out[0] quadrature points whose local solve failed (sum over all constitutive launches, this rank), out[1] linear solves that
+// did not converge, out[2] PCG iterations that saw (Ad, d) < 0, out[3] flag of the last PCG solve (1 converged, 2 max_iter, -1 den == 0)
+void exa_driver_get_diagnostics(exa_driver* d, int64_t* out) {
+   out[0] = d->sd->oper().model_fail_total; out[1] = d->sd->cg_not_converged; out[2] = d->sd->cg_indefinite_iters; out[3] = d->sd->last_cg_flag;
+}
 
 // ---- benchmark hooks --------------------------------------------------------------------------------------------------
 // Kinematically drive the RVE into the plastic regime: nodal velocity v = L0 x (+ seeded perturbation), `nsteps` constitutive

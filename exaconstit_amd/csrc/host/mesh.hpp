@@ -233,11 +233,13 @@ struct Partition {
       if (E == 0) throw std::runtime_error("mesh: a rank received no elements (more ranks than the partitioner can serve)");
    }
 
+   // number of boundary attributes (generated meshes: the six faces, reference src/mechanics_driver.cpp:1207-1227)
+   int num_bdr_attr() const { return from_file ? (int)bdr_nodes.size() : 6; }
    // is local node g on global boundary face id?
    bool on_face(int g, int id) const {
       if (from_file) return id >= 1 && id <= (int)bdr_nodes.size() && bdr_nodes[id - 1][g] != 0;
       const int i = g % nn[0] + e0[0] * p, j = (g / nn[0]) % nn[1] + e0[1] * p, k = g / (nn[0] * nn[1]) + e0[2] * p;
-      switch (id) { case 1: return k == 0; case 2: return i == 0; case 3: return j == 0; case 4: return k == N[2] * p; case 5: return i == N[0] * p; default: return j == N[1] * p; }
+      switch (id) { case 1: return k == 0; case 2: return i == 0; case 3: return j == 0; case 4: return k == N[2] * p; case 5: return i == N[0] * p; case 6: return j == N[1] * p; default: return false; }
    }
 };
 

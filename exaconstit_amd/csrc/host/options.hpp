@@ -175,6 +175,8 @@ struct ExaOptions {
       } else if (d.has_table("Time.Auto")) {
          dt_auto = true; dt = d.num("Time.Auto.dt_start", 1.0); dt_min = d.num("Time.Auto.dt_min", 1.0); dt_scale = d.num("Time.Auto.dt_scale", 0.25); t_final = d.num("Time.Auto.t_final", 1.0);
          auto_dt_fname = d.str("Time.Auto.auto_dt_file", "auto_dt_out.txt");
+         if (changing) throw std::runtime_error("Automatic time stepping is currently not compatible with changing boundary conditions");   // src/option_parser.cpp:509-511
+         if (dt_scale < 0.0 || dt_scale > 1.0) throw std::runtime_error("dt_scale for auto time stepping needs to be between 0 and 1.");
          if (dt_scale < 0.0 || dt_scale > 1.0) throw std::runtime_error("dt_scale for auto time stepping needs to be between 0 and 1.");
          nsteps = (int)std::ceil(t_final / dt_min);   // reference src/mechanics_driver.cpp:212
       } else { dt = d.num("Time.Fixed.dt", 1.0); t_final = d.num("Time.Fixed.t_final", 1.0); nsteps = (int)std::ceil(t_final / dt - 1e-9); }
@@ -189,9 +191,17 @@ struct ExaOptions {
       if (lower(integ_model) != "full" && lower(integ_model) != "bbar") throw std::runtime_error("Solvers.integ_model was not provided a valid type.");
       if (lower(integ_model) == "bbar" && assembly == Assembly::PA) throw std::runtime_error("integ_model = \"BBAR\" has no partial-assembly gradient (use EA or FULL), as in the reference");
       newton_iter = (int)d.num("Solvers.NR.iter", 25); newton_rel = d.num("Solvers.NR.rel_tol", 1e-5); newton_abs = d.num("Solvers.NR.abs_tol", 1e-10);
-      nl_solver = lower(d.str("Solvers.NR.nl_solver", "NR")) == "nrls" ? NLSolver::NRLS : NLSolver::NR;
+      { const std::string nl = lower(d.str("Solvers.NR.nl_solver", "NR"));   // reference src/option_parser.cpp:616-627 aborts on anything else
+        if (nl == "nr") nl_solver = NLSolver::NR; else if (nl == "nrls") nl_solver = NLSolver::NRLS;
+        else throw std::runtime_error("Solvers.NR.nl_solver was not provided a valid type."); }
       krylov_iter = (int)d.num("Solvers.Krylov.iter", 200); krylov_rel = d.num("Solvers.Krylov.rel_tol", 1e-10); krylov_abs = d.num("Solvers.Krylov.abs_tol", 1e-30);
-      krylov_solver = d.str("Solvers.Krylov.solver", "PCG");
+      // reference src/option_parser.cpp:647-662: GMRES (its default), PCG or MINRES, anything else aborts.  Only PCG is built here (the
+      // north-star path; the ExaCMech tangents the driver sees are symmetric to round-off, exa_grad_tangent_defect).  A file that asks
+      // for - or defaults to - one of the other two is refused instead of silently running CG.
+      krylov_solver = lower(d.str("Solvers.Krylov.solver", "GMRES"));
+      if (krylov_solver == "gmres" || krylov_solver == "minres")
+         throw std::runtime_error("Solvers.Krylov.solver = \"" + krylov_solver + "\" (the reference's default is GMRES) is not built in this driver: set Solvers.Krylov.solver = \"PCG\"");
+      if (krylov_solver != "pcg") throw std::runtime_error("Solvers.Krylov.solver was not provided a valid type.");
       ref_ser = (int)d.num("Mesh.ref_ser", 0); order = (int)d.num("Mesh.p_refinement", 1);   // tests write "prefinement": ignored like the reference (src/option_parser.cpp:677)
       mesh_type = lower(d.str("Mesh.type", "other"));
       mesh_file = d.str("Mesh.floc", "");

@@ -72,7 +72,7 @@ __global__ void k_reduce(int nb, const double* __restrict__ partial, const doubl
 }
 
 // PCG scalars: S[0]=nom S[1]=den S[2]=betanom S[3]=r0 S[4]=alpha S[5]=beta S[6]=done flag (0 run, 1 converged, -1 breakdown) S[7]=iterations
-// S[8]=scratch for reductions
+// S[8]=scratch for reductions  S[9]=scratch of the operator's dot  S[10]=number of iterations with (Ad, d) < 0
 __global__ void k_cg_init(double* S, double rel, double abs_) {       // after nom was reduced into S[8]
    const double nom = S[8];
    S[0] = nom; S[3] = fmax(nom * rel * rel, abs_ * abs_); S[7] = 0.0;
@@ -81,7 +81,9 @@ __global__ void k_cg_init(double* S, double rel, double abs_) {       // after n
 __device__ __forceinline__ void cg_den_update(double* S) {            // den reduced into S[8]
    const double den = S[8];
    S[1] = den;
-   if (den <= 0.0) { S[6] = -1.0; return; }
+   // MFEM's CGSolver only warns when (Ad, d) < 0 ("The operator is not positive definite") and keeps iterating; it stops on den == 0
+   if (den == 0.0) { S[6] = -1.0; return; }
+   if (den < 0.0) S[10] += 1.0;      // S[10]: iterations with a negative denominator (reported by the driver)
    S[4] = S[0] / den;
 }
 __device__ __forceinline__ void cg_beta_update(double* S, double max_iter) {   // betanom reduced into S[8]

@@ -151,6 +151,7 @@ exa_driver_get_avgs = _sig("exa_driver_get_avgs", C.c_int, C.c_void_p, C.c_int, 
 exa_driver_get_stats = _sig("exa_driver_get_stats", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
 exa_driver_get_timers = _sig("exa_driver_get_timers", None, C.c_void_p, C.POINTER(C.c_double))
 exa_driver_reset_timers = _sig("exa_driver_reset_timers", None, C.c_void_p)
+exa_driver_get_diagnostics = _sig("exa_driver_get_diagnostics", None, C.c_void_p, C.POINTER(C.c_int64))
 exa_driver_bench_prepare = _sig("exa_driver_bench_prepare", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_char_p, C.c_int)
 exa_driver_bench_model = _sig("exa_driver_bench_model", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_driver_bench_pcg = _sig("exa_driver_bench_pcg", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
@@ -224,6 +225,12 @@ class Driver:
         t = np.zeros(5)
         exa_driver_get_timers(self.h, t.ctypes.data_as(C.POINTER(C.c_double)))
         return dict(model_ms=t[0], krylov_ms=t[1], solve_ms=t[2], qpt_updates=int(t[3]), krylov_iters=int(t[4]))
+
+    def diagnostics(self):
+        import numpy as np
+        o = np.zeros(4, np.int64)
+        exa_driver_get_diagnostics(self.h, o.ctypes.data_as(C.POINTER(C.c_int64)))
+        return dict(model_failed_points=int(o[0]), pcg_not_converged=int(o[1]), pcg_indefinite_iters=int(o[2]), pcg_last_flag=int(o[3]))
 
     def bench_prepare(self, dts, perturb=1.0, advance=True):
         """Kinematic drive to the state the timed passes start from; advance=False keeps the virgin state (elastic first step, dt = dts[0])."""

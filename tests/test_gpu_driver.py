@@ -17,36 +17,40 @@ def _run(name, nsteps, tmp_path, jacobi=False):
     return d
 
 
-@pytest.mark.parametrize("name,nsteps,tol", [("voce_pa", 12, 3e-6), ("voce_bcc", 8, 3e-6), ("mtsdd_full", 8, 2e-5), ("mtsdd_bcc", 8, 3e-5)])
-def test_regression_case_matches_golden(oracle, tmp_path, name, nsteps, tol):
+@pytest.mark.parametrize("name,nsteps", [("voce_pa", 12), ("voce_bcc", 8), ("mtsdd_full", 12), ("mtsdd_bcc", 12)])
+def test_regression_case_matches_golden(oracle, tmp_path, name, nsteps):
+    """The reference's acceptance test is equality of the printed text (test/test_mechanics.py:22-30): every printed sigma_33 within one
+    unit of its last digit, the Kocks-Mecking cases included (they carry the long elastic-plastic transient that pins the a_V scaling)."""
+    from test_oracle_golden import printed_ulps, col_unit
     orc = oracle
     d = _run(name, nsteps, tmp_path)
     s = d.avgs(0, 6)
-    g = orc.golden(name + "_stress.txt")[:nsteps]
-    # tolerance: print precision of the golden files (6 significant digits) for Voce; ~1e-5 for KM-DD (oracle pinning)
-    assert np.max(np.abs(s[:, 2] / g[:, 2] - 1.0)) < tol
-    scale = np.abs(g[:, 2:]).max()
-    assert np.max(np.abs(s[:, 2:] - g[:, 2:])) < 3e-6 * scale + (tol * scale if tol > 3e-6 else 0)
+    g = orc.golden(name + "_stress.txt")
+    u, _ = printed_ulps(orc, s[:, 2], g[:nsteps, 2])
+    assert u.max() <= 1.0 + 1e-6, (name, u)
+    assert np.linalg.norm(s[:, 2] - g[:nsteps, 2]) / np.linalg.norm(g[:nsteps, 2]) < 3e-6
+    for c in (3, 4, 5):
+        assert np.max(np.abs(orc.fmt6(s[:, c]) - g[:nsteps, c])) <= 1.001 * col_unit(g[:, c])
     # the text file written by rank 0 has the reference's format (6 columns, default ostream precision)
     rows = np.loadtxt(os.path.join(str(tmp_path), "test_" + name + "_stress.txt"), ndmin=2)
     assert rows.shape == (nsteps, 6)
     assert np.allclose(rows, orc.fmt6(s), rtol=2e-6, atol=1e-18)
+    assert d.diagnostics()["model_failed_points"] == 0
 
 
 def test_voce_ea_extra_outputs(oracle, tmp_path):
+    from test_oracle_golden import check_file
     orc = oracle
     n = 8
     d = _run("voce_ea", n, tmp_path)
-    g_s = orc.golden("voce_ea_stress.txt")[:n]
-    assert np.max(np.abs(d.avgs(0, 6)[:, 2] / g_s[:, 2] - 1.0)) < 3e-6
-    g_f = orc.golden("voce_ea_def_grad.txt")[:n]
-    assert np.max(np.abs(d.avgs(1, 9) - g_f)) < 6e-6          # F_ii ~ 1 printed with 6 digits
-    g_w = orc.golden("voce_ea_pl_work.txt")[:n].ravel()
-    w = d.avgs(2, 1).ravel()
-    assert np.max(np.abs(w[1:] / g_w[1:] - 1.0)) < 5e-5
-    g_d = orc.golden("voce_ea_dp_tensor.txt")[:n]
-    dp = d.avgs(3, 6)
-    assert np.max(np.abs(dp - g_d)) < 5e-5 * np.abs(g_d).max()
+    for which, width, fn in ((0, 6, "stress"), (1, 9, "def_grad"), (2, 1, "pl_work"), (3, 6, "dp_tensor")):
+        g = orc.golden("voce_ea_%s.txt" % fn)
+        a = d.avgs(which, width).reshape(n, -1)
+        # one printed unit; entries that are round-off noise in both (|g| < 1e-6 max) compared absolutely
+        big = np.abs(g[:n]) > 1e-6 * np.abs(g).max()
+        unit = 10.0 ** (np.floor(np.log10(np.abs(np.where(big, g[:n], 1.0)))) - 5)
+        assert np.max((np.abs(orc.fmt6(a) - g[:n]) / unit)[big]) <= 1.0 + 1e-6, fn
+        assert np.abs(a - g[:n])[~big].max(initial=0.0) < 2e-8 * np.abs(g).max(), fn
 
 
 def test_gpu_driver_matches_oracle_driver(oracle, tmp_path):
@@ -63,13 +67,33 @@ def test_gpu_driver_matches_oracle_driver(oracle, tmp_path):
 
 
 def test_cyclic_bc_change(oracle, tmp_path):
+    from test_oracle_golden import printed_ulps
     orc = oracle
-    n = 14                        # load reversal at step 11 exercises the BC-change corrector
+    n = 18                        # load reversal at step 11 exercises the BC-change corrector; re-yield in compression from step 15
     d = _run("voce_full_cyclic", n, tmp_path)
     g = orc.golden("voce_full_cyclic_stress.txt")[:n]
     s = d.avgs(0, 6)
-    # after the reversal the answer is only defined to the Newton tolerance of the case (rel 5e-5 of a large initial residual)
-    assert np.max(np.abs(s[:, 2] - g[:, 2])) < 5e-5 * np.abs(g[:, 2]).max()
+    u, _ = printed_ulps(orc, s[:, 2], g[:, 2])
+    assert u.max() <= 1.0 + 1e-6
+    assert np.max(np.abs(s[:, 2] - g[:, 2])) < 3e-6 * np.abs(g[:, 2]).max()
+
+
+def test_true_jacobi_preconditioner(oracle, tmp_path):
+    """BASELINE config 2 says PCG + Jacobi.  The reference's smoother is effectively the identity (its dinv is built from diag = 1 and never
+    refreshed) - the default here; `jacobi` switches on the diagonal of the current tangent (AssembleGradDiagonalPA,
+    src/mechanics_operator_ext.cpp:11-55).  Same answers as the oracle with precond = 1, same Newton counts, fewer Krylov iterations."""
+    orc = oracle
+    n = 6
+    ref = orc.run_case(orc.load_case("voce_pa.toml"), nsteps=n, precond=1)
+    ident = orc.run_case(orc.load_case("voce_pa.toml"), nsteps=n, precond=0)
+    d = _run("voce_pa", n, tmp_path, jacobi=True)
+    s = d.avgs(0, 6)
+    assert np.linalg.norm(s[:, 2:] - ref["avg_stress"][:, 2:]) / np.linalg.norm(ref["avg_stress"][:, 2:]) < 1e-6
+    newton, krylov, calls = d.stats()
+    assert list(newton) == list(ref["newton_iters"])
+    assert np.all(np.abs(krylov - ref["krylov_iters"]) <= np.maximum(2, 0.02 * ref["krylov_iters"]))   # FP64 atomics: +-1 iteration
+    assert krylov.sum() < 0.9 * ident["krylov_iters"].sum()
+    assert d.diagnostics()["pcg_not_converged"] == 0
 
 
 def _variant_toml(tmp_path, base, edits, tag):
@@ -120,7 +144,7 @@ def test_velocity_gradient_bcs_match_golden(oracle, tmp_path):
     s = d.avgs(0, 6)
     assert np.max(np.abs(s[:, 2] / g[:, 2] - 1.0)) < 3e-6
     gF = orc.golden("voce_ea_cs_def_grad.txt")[:n]
-    assert np.max(np.abs(d.avgs(1, 9) - gF)) < 6e-6
+    assert np.max(np.abs(orc.fmt6(d.avgs(1, 9)) - gF)) < 1.001e-5     # one printed unit of F_ii ~ 1.00xxx
 
 
 @pytest.mark.parametrize("name", ["voce_full_cyclic_cs", "voce_full_cyclic_csm"])
@@ -130,8 +154,7 @@ def test_cyclic_velocity_gradient_bcs(oracle, tmp_path, name):
     d = _run(name, n, tmp_path)
     g = orc.golden(name + "_stress.txt")[:n]
     s = d.avgs(0, 6)
-    assert np.max(np.abs(s[:10, 2] / g[:10, 2] - 1.0)) < 6e-6
-    assert np.max(np.abs(s[:, 2] - g[:, 2])) < 5e-5 * np.abs(g[:, 2]).max()
+    assert np.max(np.abs(s[:, 2] - g[:, 2])) < 3e-6 * np.abs(g[:, 2]).max()
 
 
 def test_auto_time_stepping_matches_oracle(oracle, tmp_path):
@@ -174,3 +197,67 @@ def test_file_mesh_matches_generated_mesh(oracle, tmp_path, mesh):
     assert list(out[0][1][0]) == list(out[1][1][0])
     ref = orc.run_case(orc.load_case(auto), nsteps=n)
     assert np.linalg.norm(out[1][0][:, 2:] - ref["avg_stress"][:, 2:]) / np.linalg.norm(ref["avg_stress"][:, 2:]) < 1e-6
+
+
+def test_config5_p2_bbar_ea_nrls_cyclic(oracle, tmp_path):
+    """BASELINE config 5 as written - p = 2, B-bar, element assembly, NRLS, cyclic loading - on the 5^3 regression mesh: GPU driver vs
+    CPU oracle through the first load reversal (BC-change corrector with the p = 2 B-bar operator)."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    n = 13
+    edits = [('assembly = "FULL"', 'assembly = "EA"\n    integ_model = "BBAR"'), ("p_refinement = 1", "p_refinement = 2"), ("ref_ser = 1", "ref_ser = 0"),
+             ("[Solvers.NR]", '[Solvers.NR]\n        nl_solver = "NRLS"')]
+    path = _variant_toml(tmp_path, "voce_full_cyclic.toml", edits, "cfg5")
+    case = orc.load_case(path)
+    assert case["p"] == 2 and case["integ"] == 1 and case["nl_solver"] == 1 and len(case["bc_steps"]) == 5
+    ref = orc.run_case(case, nsteps=n)
+    assert ref["failed"] == 0
+    d = L.Driver.from_toml(path, out_dir=str(tmp_path))
+    for ti in range(1, n + 1):
+        assert d.step(ti), f"Newton failed at step {ti}"
+    s = d.avgs(0, 6)
+    assert s[10, 2] < s[9, 2] and s[12, 2] < s[11, 2]          # unloading after the reversal at step 11
+    assert np.linalg.norm(s[:, 2:] - ref["avg_stress"][:, 2:]) / np.linalg.norm(ref["avg_stress"][:, 2:]) < 1e-6
+    newton, krylov, calls = d.stats()
+    assert list(newton) == list(ref["newton_iters"])
+
+
+def test_config1_16cubed_one_step(oracle):
+    """BASELINE config 1: 16^3 auto-generated hex RVE, FCC Voce power law, partial-assembly PCG, one load step - GPU driver vs the CPU
+    oracle (the reference's CPU path restated) on the same seeded orientations."""
+    import exaconstit_amd.lib as L
+    import hipref
+    orc = oracle
+    N = 16
+    props = np.loadtxt(os.path.join(orc.REFDATA, "props_cp_voce.txt")).ravel()
+    quats = hipref.random_quats(N ** 3, seed=16)
+    dts = np.array([0.5])          # 0.05 % strain in one step: well past first yield
+    case = dict(nx=N, ny=N, nz=N, p=1, length=[1.0, 1.0, 1.0], xtal=0, kin=0, props=props, temp_k=298.0,
+                elem_grain=np.arange(N ** 3, dtype=np.int32), quats=quats, dts=dts, auto=None,
+                bc_steps=[1], bc_ids=[[1, 2, 3, 4]], bc_comps=[[3, 1, 2, 3]], bc_vals=[[0.0] * 11 + [1.0e-3]], bc_vgrad=[[0.0] * 9],
+                assembly=0, nl_solver=0, newton_rel=5e-5, newton_abs=5e-10, newton_iter=25, krylov_rel=1e-7, krylov_abs=1e-27, krylov_iter=1000,
+                additional_avgs=False, integ=0)
+    ref = orc.run_case(case)
+    assert ref["failed"] == 0
+    d = L.Driver.synthetic(N, props, quats, dts, assembly=0)
+    assert d.step(1)
+    s = d.avgs(0, 6)
+    assert abs(s[0, 2] / ref["avg_stress"][0, 2] - 1.0) < 1e-6
+    assert np.max(np.abs(s[0] - ref["avg_stress"][0])) < 1e-6 * abs(ref["avg_stress"][0, 2])
+    newton, krylov, calls = d.stats()
+    assert list(newton) == list(ref["newton_iters"])
+    assert newton[0] >= 2                                   # a plastic step
+
+
+def test_local_solver_failure_is_not_silent(oracle):
+    """A quadrature point whose ExaCMech solve does not converge fails the run in the reference (ECMECH_FAIL); here the count poisons the
+    residual norm so that Newton reports non-convergence instead of carrying on with an unconverged stress/tangent."""
+    import exaconstit_amd.lib as L
+    import hipref
+    orc = oracle
+    N = 4
+    props = np.loadtxt(os.path.join(orc.REFDATA, "props_cp_mts.txt")).ravel()
+    quats = hipref.random_quats(N ** 3, seed=3)
+    d = L.Driver.synthetic(N, props, quats, np.array([1.0]), slip=2, vz=40.0, newton=(3, 5e-5, 5e-10))     # 4000 % strain in one step
+    assert d.step(1) is False
+    assert d.diagnostics()["model_failed_points"] > 0

@@ -440,9 +440,11 @@ def test_element_blocked_layout_matches_aos(oracle, model, pkey):
         for k in a:
             tol = 1e-13 if k in ("J", "vgrad", "dp") else 1e-11      # the fused kernel's thread mapping differs (same arithmetic per point)
             assert rel_l2(b[k], a[k]) < tol, (assembly, k)
-    p3 = L.Context(0, _props(orc, "voce"), 298.0, 3, 8)
-    assert L.exa_set_quadrature_layout(p3.h, L.EXA_QLAYOUT_EB64) == -4      # built for p = 1 full integration and p = 2
-    p3.close()
+    with pytest.raises(RuntimeError):                    # p = 3 is refused at exa_create: orders 1 and 2 are what every entry point is built for
+        L.Context(0, _props(orc, "voce"), 298.0, 3, 8)
+    bb = L.Context(0, _props(orc, "voce"), 298.0, 1, 8, assembly=L.EXA_ASSEMBLY_EA, integ=L.EXA_INTEG_BBAR)
+    assert L.exa_set_quadrature_layout(bb.h, L.EXA_QLAYOUT_EB64) == -4      # built for p = 1 full integration and p = 2
+    bb.close()
 
 
 @pytest.mark.parametrize("integ,assembly,cap", [(0, 0, 0), (1, 1, 0), (0, 1, 4)])

@@ -1,0 +1,55 @@
+"""The RCCL transport of the stand-alone driver (ncclCommInitRank, ncclAllReduce, grouped ncclSend/ncclRecv; reference coupling sites
+src/mechanics_driver.cpp:312, src/system_driver.cpp:167, src/mechanics_kernels.hpp:119,124) on hardware.
+  * one GPU: EXA_FORCE_RCCL=1 runs every RCCL call on a one-rank communicator (the loopback tests of test_gpu_multirank.py cover the
+    partition logic, this covers the library calls);
+  * two or more GPUs: a torchrun-launched 2-rank run against the one-rank run (skipped on a one-GPU box; the driver's 8-GPU
+    scaling run uses the same path through bench.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(tmp_path, tag, case, nsteps, env_extra=None, nproc=1, jacobi=False):
+    import orc
+    out = os.path.join(str(tmp_path), tag + ".json")
+    env = dict(os.environ); env.update(env_extra or {}); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    args = [os.path.join(HERE, "rccl_worker.py"), os.path.join(orc.REFDATA, case + ".toml"), str(nsteps), out] + (["jacobi"] if jacobi else [])
+    if nproc == 1:
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", "29571"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize("case,jacobi", [("voce_pa", False), ("voce_ea", True)])
+def test_forced_rccl_on_one_rank(oracle, tmp_path, case, jacobi):
+    n = 4
+    plain = _worker(tmp_path, "plain", case, n, jacobi=jacobi)
+    forced = _worker(tmp_path, "forced", case, n, {"EXA_FORCE_RCCL": "1"}, jacobi=jacobi)
+    assert plain["ok"] and forced["ok"] and forced["forced"] and not plain["forced"]
+    a, b = np.array(plain["avg_stress"]), np.array(forced["avg_stress"])
+    assert np.max(np.abs(a - b)) < 1e-9 * np.abs(a).max()          # FP64 atomics in the scatter: not bitwise
+    assert plain["newton"] == forced["newton"]
+
+
+def test_two_ranks_over_rccl(oracle, tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device); the one-GPU box covers the calls through EXA_FORCE_RCCL")
+    n = 5
+    one = _worker(tmp_path, "one", "voce_pa", n)
+    two = _worker(tmp_path, "two", "voce_pa", n, nproc=2)
+    assert one["ok"] and two["ok"] and two["world"] == 2
+    a, b = np.array(one["avg_stress"]), np.array(two["avg_stress"])
+    assert np.max(np.abs(a - b)) < 1e-9 * np.abs(a).max()
+    assert one["newton"] == two["newton"]

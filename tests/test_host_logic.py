@@ -59,6 +59,31 @@ def test_options_reader_rejects_unsupported(tmp_path):
     assert rc == -1 and "ref_ser" in msg                     # uniform refinement of file meshes is not built: loud
     rc, msg = q(txt.replace('assembly = "EA"', 'assembly = "PA"\n    integ_model = "BBAR"'))
     assert rc == -1 and "BBAR" in msg                        # no partial-assembly gradient for B-bar (reference README.md:20)
+    # solver keys are validated like the reference does (src/option_parser.cpp:616-662): nothing silently becomes NR / CG
+    rc, msg = q(txt.replace('solver = "PCG"', 'solver = "GMRES"'))
+    assert rc == -1 and "GMRES" in msg.upper() and "PCG" in msg
+    rc, msg = q(txt.replace('solver = "PCG"', 'solver = "MINRES"'))
+    assert rc == -1 and "not built" in msg
+    rc, msg = q("\n".join(l for l in txt.splitlines() if not l.strip().startswith("solver =")))
+    assert rc == -1 and "GMRES" in msg.upper()              # the reference's default when the key is missing
+    rc, msg = q(txt.replace('solver = "PCG"', 'solver = "BiCG"'))
+    assert rc == -1 and "valid type" in msg
+    rc, msg = q(txt.replace("[Solvers.NR]", '[Solvers.NR]\n        nl_solver = "newton"'))
+    assert rc == -1 and "nl_solver" in msg
+
+
+def test_auto_time_stepping_with_changing_bcs_is_refused(tmp_path):
+    """reference src/option_parser.cpp:509-511"""
+    import exaconstit_amd.lib as L
+    text = open(os.path.join(REF, "voce_full_cyclic.toml")).read()
+    for fl in ("props_cp_voce.txt", "state_cp_voce.txt", "voce_quats.ori", "grains.txt", "custom_dt.txt"):
+        text = text.replace('"%s"' % fl, '"%s"' % os.path.join(REF, fl))
+    assert "[Time.Fixed]" in text
+    text = text.replace("[Time.Fixed]", "[Time.Auto]\n        dt_start = 0.1\n        dt_min = 0.05\n        t_final = 7.0\n    [Time.Fixed]")
+    bad = tmp_path / "bad.toml"; bad.write_text(text)
+    out = np.zeros(20); err = C.create_string_buffer(512)
+    rc = L.exa_options_query(str(bad).encode(), out.ctypes.data_as(C.POINTER(C.c_double)), err, 512)
+    assert rc == -1 and "changing boundary conditions" in err.value.decode()
 
 
 @pytest.mark.parametrize("nranks,order", [(1, 1), (2, 1), (3, 1), (4, 1), (8, 1), (1, 2), (4, 2)])
