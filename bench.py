@@ -52,7 +52,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(props, seconds_target=20.0):
+def cpu_baseline(props, seconds_target=12.0):
     """Oracle (CPU restatement of the reference's serial loops) timed on rank 0's host: one thread, bounded sample."""
     import hipref
     import orc
@@ -104,8 +104,8 @@ def cpu_baseline(props, seconds_target=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=300, help="timed constitutive passes (default 300: a timed region of about 2 s)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=int(os.environ.get("EXA_BENCH_N", "128")), help="elements per edge of the RVE (default 128)")
     ap.add_argument("--pcg-iters", type=int, default=100)
     ap.add_argument("--assembly", default="PA")

@@ -1,5 +1,6 @@
 // Implementation of the stand-alone host driver (see driver.hpp for the reference classes each part follows).
 #include "driver.hpp"
+#include "roctx.hpp"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <link.h>
@@ -306,6 +307,7 @@ int choose_newton_cap(const int* hist, double tail_cost_) {
 template <bool upd_crds>
 void NonlinearMechOperator::Setup(const double* k) {
    if (upd_crds) vk_update_coords(nd_, x_beg.p, k, dt_, x_cur.p, stream_);   // ExaModel::UpdateEndCoords (halo copies stay consistent)
+   ProfRegion prof("ecmech_kernel");   // reference: CALI_MARK_BEGIN("ecmech_kernel"), src/mechanics_ecmech.cpp:237
    EXA_HC(hipEventRecord(ev0_, stream_));
    if (fused_setup_) model_->ModelSetupLVec(x_cur.p, k, el_jac.p, stream_);   // L->E of x and v + SetupJacobianTerms inside the constitutive launch
    else {
@@ -523,6 +525,7 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    hipStream_t s = op.stream();
    const int64_t nd = op.Height(), nn = part.NN;
    double* S = op.scal.p;
+   ProfRegion prof("krylov_solver");
    hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1)); EXA_HC(hipEventRecord(e0, s));
    EXA_HC(hipMemsetAsync(x, 0, sizeof(double) * nd, s));
    EXA_HC(hipMemcpyAsync(cg_r_.p, b, sizeof(double) * nd, hipMemcpyDeviceToDevice, s));
@@ -585,6 +588,7 @@ bool SystemDriver::NewtonSolve(double* x, SolverStats& st) {
    hipStream_t s = op.stream();
    const int64_t nd = op.Height();
    const int calls0 = op.model_calls;
+   ProfRegion prof("newton_solver");
    op.Mult(x, r_.p);
    double norm = op.ResidualNorm(r_.p), norm_prev;
    const double norm_max = std::max(opt_.newton_rel * norm, opt_.newton_abs);
