@@ -29,6 +29,25 @@ constexpr double SQR2I = 0.70710678118654752, SQR6I = 0.40824829046386302, SQR2B
 constexpr double TINY_SQRT = 1.0e-90, EPS_SQRT = 1.0e-8;
 constexpr double GAM_RATIO_OVF = 1.0e45, LN_GAM_RATIO_MIN = -138.15510557964274;
 constexpr double E_SCALE = 5.0e-4, R_SCALE = 0.01;
+// Streaming accesses of the per-point records (read once / written once per launch) can carry the non-temporal hint (ECM_NT=1), the idea
+// being that they then do not displace the wave-slot scratch lines (spills) from L2.
+#ifndef ECM_NT
+#define ECM_NT 0   // measured at 128^3 (profiles/r02_nt_ab.txt): L2-boundary traffic 1534 -> 1446 B/qpt, elastic pass 5.43 -> 5.24 ms, plastic pass 7.28 -> 7.56 ms: not kept as the default
+#endif
+__device__ __forceinline__ double ldg(const double* p) {
+#if ECM_NT
+   return __builtin_nontemporal_load(p);
+#else
+   return *p;
+#endif
+}
+__device__ __forceinline__ void stg(double* p, double v) {
+#if ECM_NT
+   __builtin_nontemporal_store(v, p);
+#else
+   *p = v;
+#endif
+}
 
 // history layout (reference src/mechanics_ecmech.hpp:165-185)
 constexpr int H_SHRATE = 0, H_SHR = 1, H_FLOW = 2, H_NFEV = 3, H_E = 4, H_Q = 9, H_H = 13, H_GDOT = 14;
@@ -605,7 +624,7 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
    }
    voce_gdot12<false, true>(mp, pb.g_i, tau, gd, nullptr);
 #pragma unroll
-   for (int a = 0; a < NSLIP; a++) gdot_out[a * pb.gs] = gd[a];
+   for (int a = 0; a < NSLIP; a++) stg(&gdot_out[a * pb.gs], gd[a]);
 }
 
 // ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
@@ -814,24 +833,24 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
                   0.5 * (L[2 + 3 * 1] + L[1 + 3 * 2]), d_sm);
       double dnorm2 = 0; for (int i = 0; i < 5; i++) dnorm2 += d_sm[i] * d_sm[i];
       const double dnorm = sqrt(dnorm2), dEff = SQR2B3 * dnorm;
-      const double vOld = sv0[(IND_VOL) * QS], vNew = vOld * exp(dkk * dt), delv = vNew - vOld;
-      const double pOld = -(1.0 / 3.0) * (s0[(0) * QS] + s0[(1) * QS] + s0[(2) * QS]);
-      double s_old[5]; sym_to_vecd(s0[(0) * QS] + pOld, s0[(1) * QS] + pOld, s0[(2) * QS] + pOld, s0[(5) * QS], s0[(4) * QS], s0[(3) * QS], s_old);
+      const double vOld = ldg(&sv0[(IND_VOL) * QS]), vNew = vOld * exp(dkk * dt), delv = vNew - vOld;
+      const double pOld = -(1.0 / 3.0) * (ldg(&s0[(0) * QS]) + ldg(&s0[(1) * QS]) + ldg(&s0[(2) * QS]));
+      double s_old[5]; sym_to_vecd(ldg(&s0[(0) * QS]) + pOld, ldg(&s0[(1) * QS]) + pOld, ldg(&s0[(2) * QS]) + pOld, ldg(&s0[(5) * QS]), ldg(&s0[(4) * QS]), ldg(&s0[(3) * QS]), s_old);
       // ---- EOS ("updateSimple", EosModelConst<false>): p = K (1/v - 1) + Gamma e
-      const double eNew = sv0[(IND_EINT) * QS] - delv * pOld;
+      const double eNew = ldg(&sv0[(IND_EINT) * QS]) - delv * pOld;
       const double tK = mp.tK0 + eNew * mp.dtde;
       const double bulkNew = mp.bulk * vNew + mp.gamma * pOld * vNew;
       // ---- hardness to end of step with begin-of-step slip rates
-      double shrate_o = 0; for (int a = 0; a < NSLIP; a++) shrate_o += fabs(sv0[(H_GDOT + a) * QS]);
-      const double h_u = kin_update_h<KIN>(mp, sv0[(H_H) * QS], dt, shrate_o);
+      double shrate_o = 0; for (int a = 0; a < NSLIP; a++) shrate_o += fabs(ldg(&sv0[(H_GDOT + a) * QS]));
+      const double h_u = kin_update_h<KIN>(mp, ldg(&sv0[(H_H) * QS]), dt, shrate_o);
       // ---- point problem set-up
       pb.detV_ri = 1.0 / vNew;
       const double a_V_ri = 1.0 / cbrt(vNew);
       pb.esc = E_SCALE * a_V_ri; pb.esc_i = 1.0 / pb.esc;
-      double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += sv0[(H_Q + i) * QS] * sv0[(H_Q + i) * QS]; const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = sv0[(H_Q + i) * QS] * ni; }
+      double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += ldg(&sv0[(H_Q + i) * QS]) * ldg(&sv0[(H_Q + i) * QS]); const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = ldg(&sv0[(H_Q + i) * QS]) * ni; }
       double Cn[9]; quat_to_mat(qn, Cn);
       double dn[5]; rot_vecd_T(Cn, d_sm, dn);
-      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = sv0[(H_E + i) * QS] * a_V_ri; ECM_CD(CD_DSM + i) = d_sm[i]; ECM_CD(CD_SOLD + i) = s_old[i]; }
+      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = ldg(&sv0[(H_E + i) * QS]) * a_V_ri; ECM_CD(CD_DSM + i) = d_sm[i]; ECM_CD(CD_SOLD + i) = s_old[i]; }
       for (int i = 0; i < 3; i++) ECM_ST(st, ST_WN + i) = Cn[i] * w_sm[0] + Cn[3 + i] * w_sm[1] + Cn[6 + i] * w_sm[2];
       for (int i = 0; i < 4; i++) ECM_CD(CD_QN + i) = qn[i];
       ECM_CD(CD_VOLD) = vOld; ECM_CD(CD_VNEW) = vNew; ECM_CD(CD_ENEW) = eNew; ECM_CD(CD_DEFF) = dEff; ECM_CD(CD_BULK) = bulkNew; ECM_CD(CD_HU) = h_u;
@@ -946,7 +965,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       quat_to_mat(qf, Cf);
       double dq = 0; for (int i = 0; i < 4; i++) dq += qf[i] * qn[i];
       const double sg = dq < 0 ? -1.0 : 1.0;
-      for (int i = 0; i < 4; i++) sv1[(H_Q + i) * QS] = sg * qf[i];
+      for (int i = 0; i < 4; i++) stg(&sv1[(H_Q + i) * QS], sg * qf[i]);
    }
    const double kdj[5] = { mp.kd0 * pb.detV_ri, mp.kd0 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri };
    double s_lat[5];
@@ -957,18 +976,18 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       const double vNew = ECM_CD(CD_VNEW);
       double eNew = ECM_CD(CD_ENEW);
       { double wrk = 0; for (int k = 0; k < 5; k++) wrk += (ECM_CD(CD_SOLD + k) + s_sm[k]) * ECM_CD(CD_DSM + k); eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * wrk; }
-      sv1[(H_SHRATE) * QS] = shrate;
-      sv1[(H_SHR) * QS] = sv0[(H_SHR) * QS] + shrate * dt;
-      sv1[(H_FLOW) * QS] = ((ECM_CD(CD_DEFF) > TINY_SQRT) ? dis_rate * dt : 0.0) + sv0[(H_FLOW) * QS];   // accumulated plastic work
-      sv1[(H_NFEV) * QS] = (double)nfev;
-      { const double a_V = E_SCALE * pb.esc_i; for (int i = 0; i < 5; i++) sv1[(H_E + i) * QS] = e_f[i] * a_V; }   // state e = a_V E
+      stg(&sv1[(H_SHRATE) * QS], shrate);
+      stg(&sv1[(H_SHR) * QS], ldg(&sv0[(H_SHR) * QS]) + shrate * dt);
+      stg(&sv1[(H_FLOW) * QS], ((ECM_CD(CD_DEFF) > TINY_SQRT) ? dis_rate * dt : 0.0) + ldg(&sv0[(H_FLOW) * QS]));   // accumulated plastic work
+      stg(&sv1[(H_NFEV) * QS], (double)nfev);
+      { const double a_V = E_SCALE * pb.esc_i; for (int i = 0; i < 5; i++) stg(&sv1[(H_E + i) * QS], e_f[i] * a_V); }   // state e = a_V E
       if constexpr (!kin_is_km(KIN)) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS);
-      sv1[(H_H) * QS] = ECM_CD(CD_HU);
-      sv1[(IND_VOL) * QS] = vNew; sv1[(IND_EINT) * QS] = eNew;
+      stg(&sv1[(H_H) * QS], ECM_CD(CD_HU));
+      stg(&sv1[(IND_VOL) * QS], vNew); stg(&sv1[(IND_EINT) * QS], eNew);
       const double pNew = mp.bulk * (1.0 / vNew - 1.0) + mp.gamma * eNew;
       const double t1 = SQR2I * s_sm[0], t2 = SQR6I * s_sm[1];
-      s1[(0) * QS] = t1 - t2 - pNew; s1[(1) * QS] = -t1 - t2 - pNew; s1[(2) * QS] = SQR2B3 * s_sm[1] - pNew;
-      s1[(3) * QS] = SQR2I * s_sm[4]; s1[(4) * QS] = SQR2I * s_sm[3]; s1[(5) * QS] = SQR2I * s_sm[2];
+      stg(&s1[(0) * QS], t1 - t2 - pNew); stg(&s1[(1) * QS], -t1 - t2 - pNew); stg(&s1[(2) * QS], SQR2B3 * s_sm[1] - pNew);
+      stg(&s1[(3) * QS], SQR2I * s_sm[4]); stg(&s1[(4) * QS], SQR2I * s_sm[3]); stg(&s1[(5) * QS], SQR2I * s_sm[2]);
    }
 #ifndef ECM_NO_TANGENT
    // ---- tangent (last: it overwrites the parking area): lattice-frame d sigma'/d D' by implicit differentiation on the converged
@@ -1082,8 +1101,8 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
          const double bk = (j < 3) ? bulkNew : 0.0;
          // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[(i + 6 j) * QS]
-         cmat[(0 + 6 * j) * QS] = t1 - t2 + bk; cmat[(1 + 6 * j) * QS] = -t1 - t2 + bk; cmat[(2 + 6 * j) * QS] = SQR2B3 * T2[1] + bk;
-         cmat[(3 + 6 * j) * QS] = SQR2I * T2[4]; cmat[(4 + 6 * j) * QS] = SQR2I * T2[3]; cmat[(5 + 6 * j) * QS] = SQR2I * T2[2];
+         stg(&cmat[(0 + 6 * j) * QS], t1 - t2 + bk); stg(&cmat[(1 + 6 * j) * QS], -t1 - t2 + bk); stg(&cmat[(2 + 6 * j) * QS], SQR2B3 * T2[1] + bk);
+         stg(&cmat[(3 + 6 * j) * QS], SQR2I * T2[4]); stg(&cmat[(4 + 6 * j) * QS], SQR2I * T2[3]); stg(&cmat[(5 + 6 * j) * QS], SQR2I * T2[2]);
       }
    }
 #endif

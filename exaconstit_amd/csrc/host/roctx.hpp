@@ -10,9 +10,11 @@ struct Roctx {
    int (*push)(const char*) = nullptr;
    int (*pop)() = nullptr;
    Roctx() {
-      void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+      // rocprofv3 intercepts the SDK's roctx library; libroctx64 (roctracer) is the fall-back for the older tools
+      void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
       if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
-      if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
       if (h) { push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop"); }
       if (!push || !pop) { push = nullptr; pop = nullptr; }
    }

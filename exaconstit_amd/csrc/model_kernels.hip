@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
       p2::gather(r, [&](int a, int c) { return xl[gn[a] + (int64_t)nnodes * c]; }, gx);
       J11 = gx[0][0]; J21 = gx[1][0]; J31 = gx[2][0]; J12 = gx[0][1]; J22 = gx[1][1]; J32 = gx[2][1]; J13 = gx[0][2]; J23 = gx[1][2]; J33 = gx[2][2];
       double* Jo = Jio + vJ.base;
-      Jo[0] = J11; Jo[QS] = J21; Jo[2 * QS] = J31; Jo[3 * QS] = J12; Jo[4 * QS] = J22; Jo[5 * QS] = J32; Jo[6 * QS] = J13; Jo[7 * QS] = J23; Jo[8 * QS] = J33;
+      ecmdev::stg(Jo, J11); ecmdev::stg(Jo + QS, J21); ecmdev::stg(Jo + 2 * QS, J31); ecmdev::stg(Jo + 3 * QS, J12); ecmdev::stg(Jo + 4 * QS, J22); ecmdev::stg(Jo + 5 * QS, J32);
+      ecmdev::stg(Jo + 6 * QS, J13); ecmdev::stg(Jo + 7 * QS, J23); ecmdev::stg(Jo + 8 * QS, J33);
       const double detJ = J11 * (J22 * J33 - J32 * J23) - J21 * (J12 * J33 - J32 * J13) + J31 * (J12 * J23 - J22 * J13);
       const double di = 1.0 / detJ;
       const double Ji[3][3] = { { di * (J22 * J33 - J23 * J32), di * (J32 * J13 - J12 * J33), di * (J12 * J23 - J22 * J13) },
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
          J13 += x0 * g2; J23 += x1 * g2; J33 += x2 * g2;
       }
       double* Jo = Jio + vJ.base;
-      Jo[0] = J11; Jo[QS] = J21; Jo[2 * QS] = J31; Jo[3 * QS] = J12; Jo[4 * QS] = J22; Jo[5 * QS] = J32; Jo[6 * QS] = J13; Jo[7 * QS] = J23; Jo[8 * QS] = J33;
+      ecmdev::stg(Jo, J11); ecmdev::stg(Jo + QS, J21); ecmdev::stg(Jo + 2 * QS, J31); ecmdev::stg(Jo + 3 * QS, J12); ecmdev::stg(Jo + 4 * QS, J22); ecmdev::stg(Jo + 5 * QS, J32);
+      ecmdev::stg(Jo + 6 * QS, J13); ecmdev::stg(Jo + 7 * QS, J23); ecmdev::stg(Jo + 8 * QS, J33);
    } else {
       const double* Jq = Jio + vJ.base;
       J11 = Jq[0]; J21 = Jq[QS]; J31 = Jq[2 * QS]; J12 = Jq[3 * QS]; J22 = Jq[4 * QS]; J32 = Jq[5 * QS]; J13 = Jq[6 * QS]; J23 = Jq[7 * QS]; J33 = Jq[8 * QS];

@@ -16,7 +16,8 @@ from collections import defaultdict
 
 
 def short(name):
-    n = name.split("(")[0]
+    n = name.replace("(anonymous namespace)::", "")
+    n = n.split("(")[0]
     for pre in ("void ", "ecmdev::"):
         n = n.replace(pre, "")
     return n[:110]
