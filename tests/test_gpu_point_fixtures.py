@@ -1,0 +1,73 @@
+"""Per-quadrature-point golden fixtures (tests/golden/point_fixtures/*.npz, written by tests/golden/make_point_fixtures.py from the oracle
+after it was pinned to the reference's golden curves) replayed through the C ABI of the HIP library WITHOUT the oracle: inputs are the
+Jacobians, E-vector velocity, begin-of-step stress and state of 64 points per model in the elastic, transition and plastic regime; expected
+outputs are stress (1e-9 rel-L2), state (1e-8 per slot group; the evaluation counter, slot 3, must agree for >= 95 % of the points) and
+the tangent (1e-7).  Also checks the GPU tangent against central differences of the GPU stress update along isochoric directions."""
+import os
+
+import numpy as np
+import pytest
+
+import hipref
+from hipref import rel_l2, ptr
+
+pytestmark = pytest.mark.gpu
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "point_fixtures")
+MODELS = ["fcc_voce", "bcc_voce", "fcc_voce_nl", "bcc_voce_nl", "fcc_kmdd", "bcc_kmdd"]
+
+
+def _gpu_update(L, ctx, dev, dt, J, vel_e, s0, sv0, P):
+    d = [dev.up(a) for a in (J, vel_e, s0, sv0)]
+    o = [dev.zeros(6 * P), dev.zeros(28 * P), dev.zeros(36 * P)]
+    ctx.check(L.exa_model_setup(ctx.h, float(dt), ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(o[0]), ptr(o[1]), ptr(o[2]), None))
+    assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+    return [t.cpu().numpy() for t in o]
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_point_fixtures(name):
+    import exaconstit_amd.lib as L
+    z = np.load(os.path.join(FIX, name + ".npz"))
+    E, Q = int(z["E"]), int(z["Q"]); P = E * Q
+    dev = hipref.Dev()
+    ctx = L.Context(int(z["model"]), z["props"], 298.0, 1, E)
+    keep = np.ones(28, bool); keep[3] = False
+    for step in z["steps"]:
+        s1, sv1, cm = _gpu_update(L, ctx, dev, z[f"dt_{step}"], z[f"J_{step}"], z["vel_e"], z[f"s0_{step}"], z[f"sv0_{step}"], P)
+        assert rel_l2(s1, z[f"s1_{step}"]) < 1e-9, (name, step)
+        a = sv1.reshape(P, 28); b = z[f"sv1_{step}"].reshape(P, 28)
+        for lo, hi in ((0, 3), (4, 9), (9, 13), (13, 14), (14, 26), (26, 28)):
+            assert rel_l2(a[:, lo:hi], b[:, lo:hi]) < 1e-8, (name, step, lo)
+        assert np.mean(a[:, 3] == b[:, 3]) >= 0.95, (name, step)          # function-evaluation counts of the local solver
+        assert rel_l2(cm, z[f"cm_{step}"]) < 1e-7, (name, step)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["fcc_voce", "bcc_voce_nl", "bcc_kmdd"])
+def test_gpu_tangent_is_the_derivative_of_the_gpu_stress_update(name):
+    """Central differences through the C ABI in the plastic state of the fixture: a homogeneous, symmetric, trace-free velocity-gradient
+    perturbation dL (nodal velocities dv = dL x) changes neither spin nor volume, so tangent * (dt dL) must equal the stress difference."""
+    import exaconstit_amd.lib as L
+    z = np.load(os.path.join(FIX, name + ".npz"))
+    E, Q = int(z["E"]), int(z["Q"]); P = E * Q
+    dev = hipref.Dev()
+    ctx = L.Context(int(z["model"]), z["props"], 298.0, 1, E)
+    step = int(z["steps"][-1])
+    dt, J, s0, sv0 = float(z[f"dt_{step}"]), z[f"J_{step}"], z[f"s0_{step}"], z[f"sv0_{step}"]
+    vel = z["vel_e"].reshape(E, 3, 8); xe = z[f"xe_{step}"].reshape(E, 3, 8)          # E-vector layout (node, comp, elem): node fastest
+    _, _, cm = _gpu_update(L, ctx, dev, dt, J, z["vel_e"], s0, sv0, P)
+    C6 = cm.reshape(P, 6, 6).transpose(0, 2, 1)           # stored column-major: C[i + 6 j]  ->  [p, i, j]
+    h = 1.0e-7
+    worst = 0.0
+    for v in ((1, -1, 0, 0, 0, 0), (1, 1, -2, 0, 0, 0), (0, 0, 0, 1, 0, 0), (0, 0, 0, 0, 1, 0), (0, 0, 0, 0, 0, 1)):
+        v = np.array(v, dtype=np.float64)
+        dL = h * np.array([[v[0], v[5] / 2, v[4] / 2], [v[5] / 2, v[1], v[3] / 2], [v[4] / 2, v[3] / 2, v[2]]])
+        dv = np.einsum("ij,ejn->ein", dL, xe)
+        sp, _, _ = _gpu_update(L, ctx, dev, dt, J, (vel + dv).ravel(), s0, sv0, P)
+        sm, _, _ = _gpu_update(L, ctx, dev, dt, J, (vel - dv).ravel(), s0, sv0, P)
+        fd = (sp - sm).reshape(P, 6) / (2.0 * h * dt)
+        tan = np.einsum("pij,j->pi", C6, v)
+        err = np.linalg.norm(tan - fd, axis=1) / np.linalg.norm(fd, axis=1)
+        worst = max(worst, err.max())
+    assert worst < 2.0e-5, (name, worst)
+    ctx.close()
