@@ -9,6 +9,7 @@ int exa_launch_init_state(exa_ctx*, double*, const double*, const double*, hipSt
 int exa_launch_nfev_hist(exa_ctx*, const double*, int*, hipStream_t);
 int exa_launch_calc_dp(exa_ctx*, const double*, double*, hipStream_t);
 int exa_launch_jacobians(exa_ctx*, const double*, double*, hipStream_t);
+int exa_launch_jacobians_from_geom(exa_ctx*, const double*, double*, hipStream_t);
 int exa_launch_grad_calc(exa_ctx*, const double*, const double*, double*, hipStream_t);
 int exa_launch_residual_setup(exa_ctx*, const double*, const double*, hipStream_t);
 int exa_launch_residual_apply(exa_ctx*, double*, hipStream_t);
@@ -163,6 +164,11 @@ int exa_calc_dp(exa_ctx* ctx, const double* state, double* dp, exa_stream s) {
 int exa_jacobians(exa_ctx* ctx, const double* xe, double* J, exa_stream s) {
    if (!ctx || !xe || !J) return fail(ctx, EXA_ERR_ARG, "exa_jacobians: null pointer");
    return exa_launch_jacobians(ctx, xe, J, S(s));
+}
+
+int exa_jacobians_from_geom(exa_ctx* ctx, const double* gj, double* J, exa_stream s) {
+   if (!ctx || !gj || !J) return fail(ctx, EXA_ERR_ARG, "exa_jacobians_from_geom: null pointer");
+   return exa_launch_jacobians_from_geom(ctx, gj, J, S(s));
 }
 
 int exa_grad_calc(exa_ctx* ctx, const double* J, const double* fe, double* out, exa_stream s) {

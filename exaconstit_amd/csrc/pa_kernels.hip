@@ -39,6 +39,17 @@ __device__ __forceinline__ void adj_det(const double* Jq, double adj[9], double&
 }
 
 // ---- generic-order kernels -------------------------------------------------------------------------------------------
+// MFEM GeometricFactors::J, laid out (Q,3,3,E) with J(q,i,j,e) = dx_i/dxi_j, into the (3,3,Q,E) array of the integrators
+// (reference src/mechanics_operator.cpp:377-391: jac_view(l,k,j,i) = geom_j_view(j,l,k,i))
+template <bool QB>
+__global__ void k_jacobians_from_geom(const int Q, const int64_t P, const double* __restrict__ gj, double* __restrict__ J) {
+   const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (ip >= P) return;
+   const int q = (int)(ip % Q); const int64_t e = ip / Q;
+   const QView v = qview<QB>(9, Q, e, q);
+   for (int c = 0; c < 9; c++) J[v.base + (int64_t)c * v.stride] = gj[q + (int64_t)Q * (c + 9 * e)];   // c = l + 3 k on both sides
+}
+
 template <bool QB>
 __global__ void k_jacobians(const int Q, const int n, const int64_t P, const double* __restrict__ G, const double* __restrict__ xe, double* __restrict__ J) {
    extern __shared__ double sG[];
@@ -507,6 +518,11 @@ static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) 
 int exa_launch_jacobians(exa_ctx* ctx, const double* xe, double* J, hipStream_t s) {
    if (ctx->qblk) hipLaunchKernelGGL(k_jacobians<true>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, xe, J);
    else hipLaunchKernelGGL(k_jacobians<false>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, xe, J);
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
+int exa_launch_jacobians_from_geom(exa_ctx* ctx, const double* gj, double* J, hipStream_t s) {
+   if (ctx->qblk) hipLaunchKernelGGL(k_jacobians_from_geom<true>, dim3(nblk(ctx->P, 256)), dim3(256), 0, s, ctx->Q, ctx->P, gj, J);
+   else hipLaunchKernelGGL(k_jacobians_from_geom<false>, dim3(nblk(ctx->P, 256)), dim3(256), 0, s, ctx->Q, ctx->P, gj, J);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_grad_calc(exa_ctx* ctx, const double* J, const double* fe, double* out, hipStream_t s) {

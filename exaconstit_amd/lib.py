@@ -63,6 +63,7 @@ exa_model_nfev_hist = _sig("exa_model_nfev_hist", C.c_int, C.c_void_p, dptr, C.P
 exa_model_status = _sig("exa_model_status", C.c_int, C.c_void_p, C.c_void_p)
 exa_calc_dp = _sig("exa_calc_dp", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_jacobians = _sig("exa_jacobians", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
+exa_jacobians_from_geom = _sig("exa_jacobians_from_geom", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_grad_calc = _sig("exa_grad_calc", C.c_int, C.c_void_p, dptr, dptr, dptr, C.c_void_p)
 exa_residual_setup = _sig("exa_residual_setup", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_residual_apply = _sig("exa_residual_apply", C.c_int, C.c_void_p, dptr, C.c_void_p)

@@ -107,6 +107,9 @@ int exa_calc_dp(exa_ctx* ctx, const double* state_dev, double* dp_dev, exa_strea
 /* geometry helpers (MFEM GeometricFactors + re-layout, src/mechanics_operator.cpp:350-391; grad_calc on any field,
  * src/mechanics_kernels.cpp:7-78, used for the deformation gradient src/mechanics_operator.cpp:393-427) */
 int exa_jacobians(exa_ctx* ctx, const double* coords_evec_dev /*(n,3,E)*/, double* jacobian_dev, exa_stream s);
+/* Re-layout of mfem::GeometricFactors::J (Q,3,3,E) into the (3,3,Q,E) Jacobian array (src/mechanics_operator.cpp:377-391,
+ * src/mechanics_integrators.cpp:225-238): what an MFEM-side adapter calls instead of exa_jacobians. */
+int exa_jacobians_from_geom(exa_ctx* ctx, const double* geom_J_dev /*(Q,3,3,E)*/, double* jacobian_dev, exa_stream s);
 int exa_grad_calc(exa_ctx* ctx, const double* jacobian_dev, const double* field_evec_dev, double* grad_dev /*(3,3,Q,E), overwritten*/, exa_stream s);
 
 /* ExaNLFIntegrator seam ---------------------------------------------------------------------------------------- */

@@ -1,0 +1,128 @@
+// MFEM-side adapters that put libexaconstit_hip.so behind ExaConstit's two plug-in seams:
+//   HipExaModel          : ExaModel           reference src/mechanics_model.hpp:17-241 (ctor :70-75, ModelSetup :109-111, calcDpMat :233)
+//                                             replaces ECMechXtalModel<...>, src/mechanics_ecmech.hpp:111-363
+//   HipExaNLFIntegrator  : ExaNLFIntegrator   reference src/mechanics_integrators.hpp:14-76
+// selected in NonlinearMechOperator's model / integrator switch (src/mechanics_operator.cpp:49-210).
+//
+// Header-only.  In an ExaConstit build it is included after mfem.hpp and ExaConstit's own headers.  MFEM is not part of this
+// repository's image; tests/test_adapters.py compiles this very file against tests/mock_mfem/ (a small restatement of the part of the
+// mfem::Vector / QuadratureFunction / GeometricFactors / NonlinearFormIntegrator and ExaModel / ExaNLFIntegrator surface used below)
+// and drives ModelSetup -> AssemblePA/AddMultPA -> AssembleGradPA/AddMultGradPA/diagonal -> AssembleEA through it on the GPU.
+//
+// Device pointers: with mfem::Device::Configure("hip") Vector::Read()/Write()/ReadWrite() return device pointers, which is what the C ABI
+// expects.  Streams: nullptr (the default stream) keeps MFEM's implicit ordering.
+#pragma once
+
+#if defined(EXA_ADAPTER_MOCK_MFEM)
+#include "mock_mfem.hpp"               // tests/mock_mfem/mock_mfem.hpp
+#elif __has_include("mfem.hpp")
+#include "mfem.hpp"
+#include "mechanics_model.hpp"         // ExaConstit: ExaModel, Assembly
+#include "mechanics_integrators.hpp"   // ExaConstit: ExaNLFIntegrator
+#else
+#error "exaconstit_mfem_adapters.hpp needs MFEM (mfem.hpp) and ExaConstit's mechanics_model.hpp / mechanics_integrators.hpp on the include path"
+#endif
+
+#include <stdexcept>
+#include <string>
+#include "exaconstit_hip.h"
+
+#ifndef EXA_ADAPTER_VERIFY
+#define EXA_ADAPTER_VERIFY(cond, msg) do { if (!(cond)) throw std::runtime_error(std::string("exaconstit_hip adapter: ") + (msg)); } while (0)
+#endif
+
+// ExaConstit's (xtal_type, slip_type) -> library model id (src/mechanics_ecmech.hpp:407-414,460-463)
+inline int exa_model_id(bool bcc, int slip /* 0 powervoce, 1 powervocenl, 2 mtsdd */) {
+   return slip == 0 ? (bcc ? EXA_BCC_VOCE : EXA_FCC_VOCE) : (slip == 1 ? (bcc ? EXA_BCC_VOCE_NL : EXA_FCC_VOCE_NL) : (bcc ? EXA_BCC_KMDD : EXA_FCC_KMDD));
+}
+
+class HipExaModel : public ExaModel {
+   exa_ctx* ctx_ = nullptr;
+   bool check_local_solves_;
+ public:
+   HipExaModel(mfem::QuadratureFunction* q_stress0, mfem::QuadratureFunction* q_stress1, mfem::QuadratureFunction* q_matGrad,
+               mfem::QuadratureFunction* q_matVars0, mfem::QuadratureFunction* q_matVars1, mfem::ParGridFunction* beg_coords,
+               mfem::ParGridFunction* end_coords, mfem::Vector* props, int nProps, int nStateVars, double temp_k, int model_id, int order,
+               int nelems, Assembly assembly_, bool bbar = false, bool check_local_solves = true)
+      : ExaModel(q_stress0, q_stress1, q_matGrad, q_matVars0, q_matVars1, beg_coords, end_coords, props, nProps, nStateVars, assembly_),
+        check_local_solves_(check_local_solves) {
+      exa_config cfg;
+      cfg.model = model_id; cfg.nprops = nProps; cfg.props = props->HostRead(); cfg.temp_k = temp_k; cfg.order = order; cfg.nelems = nelems;
+      cfg.assembly = (assembly_ == Assembly::PA) ? EXA_ASSEMBLY_PA : EXA_ASSEMBLY_EA;      // FULL assembles the same element operator
+      cfg.integ = bbar ? EXA_INTEG_BBAR : EXA_INTEG_FULL; cfg.device = -1;
+      int err = 0;
+      ctx_ = exa_create(&cfg, &err);
+      EXA_ADAPTER_VERIFY(ctx_ != nullptr, "exa_create failed with code " + std::to_string(err));
+      EXA_ADAPTER_VERIFY(exa_num_state_vars(ctx_) == nStateVars, "state variable count mismatch");
+   }
+   ~HipExaModel() override { exa_destroy(ctx_); }
+   HipExaModel(const HipExaModel&) = delete; HipExaModel& operator=(const HipExaModel&) = delete;
+
+   // ECMechXtalModel::init_state_vars (src/mechanics_ecmech.hpp:264-300) with one quaternion per element
+   void InitStateVars(const mfem::Vector& quats_per_elem) {
+      EXA_ADAPTER_VERIFY(exa_init_state(ctx_, matVars0->ReadWrite(), quats_per_elem.Read(), nullptr) == EXA_OK, exa_last_error(ctx_));
+   }
+
+   // src/mechanics_model.hpp:109-111, called from NonlinearMechOperator::Setup (src/mechanics_operator.cpp:339-347).
+   // The library owns the reference-element gradient table (exa_shape_table), so loc_grad is not needed.
+   void ModelSetup(const int nqpts, const int nelems, const int /*space_dim*/, const int nnodes, const mfem::Vector& jacobian,
+                   const mfem::Vector& /*loc_grad*/, const mfem::Vector& vel) override {
+      EXA_ADAPTER_VERIFY(nqpts == exa_qpts_per_elem(ctx_) && nnodes == exa_nodes_per_elem(ctx_), "element order does not match the context");
+      (void)nelems;
+      const int rc = exa_model_setup(ctx_, dt, jacobian.Read(), vel.Read(), stress0->Read(), matVars0->Read(), stress1->Write(), matVars1->Write(),
+                                     matGrad->Write(), nullptr);
+      EXA_ADAPTER_VERIFY(rc == EXA_OK, exa_last_error(ctx_));
+      // ExaCMech fails the run when a local solve does not converge (ECMECH_FAIL); the count needs one 4-byte read-back
+      if (check_local_solves_) {
+         const int nfail = exa_model_status(ctx_, nullptr);
+         EXA_ADAPTER_VERIFY(nfail == 0, "the constitutive update did not converge at " + std::to_string(nfail) + " quadrature point(s)");
+      }
+   }
+   void UpdateModelVars() override {}
+   void calcDpMat(mfem::QuadratureFunction& DpMat) const override {            // src/mechanics_model.hpp:233, src/mechanics_ecmech.hpp:302-363
+      EXA_ADAPTER_VERIFY(exa_calc_dp(ctx_, matVars1->Read(), DpMat.Write(), nullptr) == EXA_OK, exa_last_error(ctx_));
+   }
+   exa_ctx* ctx() const { return ctx_; }
+};
+
+// TransformMatGradTo4D() (called for PA at src/mechanics_operator.cpp:297-300) is not needed with this integrator: the 4-D tensor is never
+// materialised, and the tangent in matGrad is already column-major (no transpose pass, cf. src/mechanics_ecmech.cpp:155-170).
+class HipExaNLFIntegrator : public ExaNLFIntegrator {
+   HipExaModel* hmodel_;
+   mfem::Vector jac_;          // (3,3,Q,E)
+   // geometric factors of the current (end-of-step) mesh nodes, re-laid-out as src/mechanics_integrators.cpp:225-238 does
+   void RefreshJacobians(const mfem::FiniteElementSpace& fes) {
+      const mfem::FiniteElement& el = *fes.GetFE(0);
+      const mfem::IntegrationRule* ir = &(mfem::IntRules.Get(el.GetGeomType(), 2 * el.GetOrder() + 1));
+      const mfem::GeometricFactors* g = fes.GetMesh()->GetGeometricFactors(*ir, mfem::GeometricFactors::JACOBIANS);
+      if (jac_.Size() != g->J.Size()) { jac_.SetSize(g->J.Size()); jac_.UseDevice(true); }
+      EXA_ADAPTER_VERIFY(exa_jacobians_from_geom(hmodel_->ctx(), g->J.Read(), jac_.Write(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
+   }
+ public:
+   explicit HipExaNLFIntegrator(HipExaModel* m) : ExaNLFIntegrator(m), hmodel_(m) {}
+   using ExaNLFIntegrator::AssemblePA;
+   void AssemblePA(const mfem::FiniteElementSpace& fes) override {                                   // src/mechanics_integrators.cpp:160-314
+      RefreshJacobians(fes);
+      EXA_ADAPTER_VERIFY(exa_residual_setup(hmodel_->ctx(), jac_.Read(), model->GetStress1()->Read(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
+   }
+   void AddMultPA(const mfem::Vector& /*x*/, mfem::Vector& y) const override {                       // :518-557
+      EXA_ADAPTER_VERIFY(exa_residual_apply(hmodel_->ctx(), y.ReadWrite(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
+   }
+   void AssembleGradPA(const mfem::Vector& /*x*/, const mfem::FiniteElementSpace& fes) override { AssembleGradPA(fes); }
+   void AssembleGradPA(const mfem::FiniteElementSpace& fes) override {                               // :331-513
+      RefreshJacobians(fes);
+      EXA_ADAPTER_VERIFY(exa_grad_setup(hmodel_->ctx(), model->GetModelDt(), jac_.Read(), model->GetMatGrad()->Read(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
+   }
+   void AddMultGradPA(const mfem::Vector& x, mfem::Vector& y) const override {                       // :562-622
+      EXA_ADAPTER_VERIFY(exa_grad_apply(hmodel_->ctx(), x.Read(), y.ReadWrite(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
+   }
+   void AssembleGradDiagonalPA(mfem::Vector& diag) const override {                                  // :625-748
+      EXA_ADAPTER_VERIFY(exa_grad_diagonal(hmodel_->ctx(), diag.ReadWrite(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
+   }
+   void AssembleGradEA(const mfem::Vector& /*x*/, const mfem::FiniteElementSpace& fes, mfem::Vector& emat) override { AssembleEA(fes, emat); }
+   void AssembleEA(const mfem::FiniteElementSpace& fes, mfem::Vector& emat) override {               // :756-1017
+      RefreshJacobians(fes);
+      EXA_ADAPTER_VERIFY(exa_grad_setup(hmodel_->ctx(), model->GetModelDt(), jac_.Read(), model->GetMatGrad()->Read(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
+      EXA_ADAPTER_VERIFY(exa_grad_get_ea(hmodel_->ctx(), emat.Write(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));   // reference layout (3n,3n,E)
+   }
+};
