@@ -518,9 +518,57 @@ void SystemDriver::UpdateVelocity(double* v) {
    }
 }
 
+// PCG on more than one rank: the Chronopoulos-Gear arrangement of the same recurrence needs ONE fused reduction per iteration - the pair
+// gamma = (r, u), delta = (A u, u) in a single 16-byte all-reduce - instead of the two 8-byte ones of MFEM's loop:
+//    u = M^-1 r,  s = A u,  beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old),
+//    p = u + beta p,  q = s + beta q (= A p),  x += alpha p,  r -= alpha q.
+// Same iterates in exact arithmetic, same stopping test on (r, M^-1 r) after each update, same iteration cap.  EXA_PCG_TWO_REDUCTIONS=1
+// keeps the two-reduction loop on several ranks (A/B switch).
+int SystemDriver::CGSolveSingleReduction(const double* b, double* x) {
+   NonlinearMechOperator& op = *oper_;
+   hipStream_t s = op.stream();
+   const int64_t nd = op.Height(), nn = part.NN;
+   double* S = op.scal.p;
+   ProfRegion prof("krylov_solver");
+   if (cg_s_.n < (size_t)nd) { cg_s_.alloc(nd); cg_q_.alloc(nd); }
+   hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1)); EXA_HC(hipEventRecord(e0, s));
+   const bool ident = op.precond == Precond::IDENTITY;
+   EXA_HC(hipMemsetAsync(x, 0, sizeof(double) * nd, s));
+   EXA_HC(hipMemcpyAsync(cg_r_.p, b, sizeof(double) * nd, hipMemcpyDeviceToDevice, s));
+   if (!ident) vk_pointwise(nd, op.dinv.p, cg_r_.p, cg_z_.p, s);
+   const double* u = ident ? cg_r_.p : cg_z_.p;
+   EXA_HC(hipMemsetAsync(cg_d_.p, 0, sizeof(double) * nd, s)); EXA_HC(hipMemsetAsync(cg_q_.p, 0, sizeof(double) * nd, s));
+   EXA_HC(hipMemsetAsync(cg_s_.p, 0, sizeof(double) * nd, s));
+   EXA_HC(hipMemsetAsync(S, 0, sizeof(double) * 11, s));
+   op.GradMult(u, cg_s_.p, true, S + 6, true, true);
+   vk_cg2_dots(nd, nn, op.weight.p, op.ess_mask.p, cg_r_.p, cg_z_.p, cg_s_.p, S + 6, op.partial.p, S + 8, ident, s);
+   comm.allreduce_sum(S + 8, 2, s);
+   vk_cg2_init(S, opt_.krylov_rel, opt_.krylov_abs, s);
+   double hS[11]; int launched = 0; bool done = false;
+   while (!done) {
+      for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) {
+         vk_cg2_update(nd, S, op.dinv.p, x, cg_r_.p, cg_z_.p, cg_d_.p, cg_s_.p, cg_q_.p, ident, s);
+         op.GradMult(u, cg_s_.p, true, S + 6, true, true);
+         vk_cg2_dots(nd, nn, op.weight.p, op.ess_mask.p, cg_r_.p, cg_z_.p, cg_s_.p, S + 6, op.partial.p, S + 8, ident, s);
+         comm.allreduce_sum(S + 8, 2, s);
+         vk_cg2_scalars(S, opt_.krylov_iter, s);
+      }
+      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 11, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+      done = (hS[6] != 0.0) || launched >= opt_.krylov_iter;
+   }
+   EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
+   float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+   const int iters = (hS[6] == 1.0 && hS[7] == 0.0) ? 0 : (int)hS[7];
+   op.timers.t_krylov_ms += ms; op.timers.krylov_iters += iters;
+   last_cg_flag = (int)hS[6]; cg_indefinite_iters += (int64_t)hS[10];
+   if (hS[6] != 1.0) cg_not_converged++;
+   return iters;
+}
+
 // device PCG (MFEM CGSolver::Mult with iterative_mode = false); all scalars stay on the device, the host only polls the
 // done-flag every cg_check_every iterations.
 int SystemDriver::CGSolve(const double* b, double* x) {
+   if (comm.nranks > 1 && std::getenv("EXA_PCG_TWO_REDUCTIONS") == nullptr) return CGSolveSingleReduction(b, x);
    NonlinearMechOperator& op = *oper_;
    hipStream_t s = op.stream();
    const int64_t nd = op.Height(), nn = part.NN;

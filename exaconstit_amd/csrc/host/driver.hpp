@@ -140,6 +140,7 @@ class SystemDriver {
    int RunAll();
    bool NewtonSolve(double* x, SolverStats& st);
    int CGSolve(const double* b, double* x);   // device PCG, returns iterations
+   int CGSolveSingleReduction(const double* b, double* x);   // more than one rank: one fused 16-byte all-reduce per iteration
    NonlinearMechOperator& oper() { return *oper_; }
    const ExaOptions& options() const { return opt_; }
    std::vector<double> avg_stress, avg_def_grad, avg_pl_work, avg_dp_tensor;   // one row per completed step (rank 0 view, all ranks identical)
@@ -159,7 +160,7 @@ class SystemDriver {
    void init(const std::vector<double>& props, const std::vector<double>& quats_local);
    ExaOptions opt_;
    std::unique_ptr<NonlinearMechOperator> oper_;
-   DevBuf<double> r_, c_, xt_, cg_r_, cg_z_, cg_d_, ess_val_;
+   DevBuf<double> r_, c_, xt_, cg_r_, cg_z_, cg_d_, cg_s_, cg_q_, ess_val_;
    std::vector<uint8_t> ess_host_; std::vector<double> ess_val_host_;
    DevBuf<uint8_t> vel_mask_, vg_mask_; bool have_vel_ = false, have_vgrad_ = false; double vgrad_[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
    double last_dt_ = 0.0;

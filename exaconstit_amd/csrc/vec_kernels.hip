@@ -144,6 +144,69 @@ __global__ void k_cg_step2z(int64_t n, const double* __restrict__ S, double* __r
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { d[i] = (IDENT ? r[i] : z[i]) + beta * d[i]; z[i] = 0.0; }
 }
 
+// ---- single-reduction PCG (Chronopoulos & Gear), used on more than one rank: one 16-byte all-reduce per iteration instead of two 8-byte ones
+// scalars as above; S[8], S[9] hold the reduced pair gamma = (r, u), delta = (A u, u)
+__global__ void k_cg2_init(double* S, double rel, double abs_) {          // after (gamma, delta) were reduced into S[8], S[9]
+   const double g = S[8], dl = S[9];
+   S[0] = g; S[1] = dl; S[3] = fmax(g * rel * rel, abs_ * abs_); S[7] = 0.0; S[5] = 0.0;
+   S[6] = (g < 0.0) ? -1.0 : ((g <= S[3]) ? 1.0 : 0.0);
+   if (S[6] == 0.0) { if (dl == 0.0) S[6] = -1.0; else { if (dl < 0.0) S[10] += 1.0; S[4] = g / dl; } }
+}
+__global__ void k_cg2_scalars(double* S, double max_iter) {               // new (gamma, delta) in S[8], S[9]
+   if (S[6] != 0.0) return;
+   const double gn = S[8], dl = S[9];
+   S[2] = gn; S[7] += 1.0;
+   if (gn <= S[3]) { S[6] = 1.0; return; }
+   if (S[7] >= max_iter) { S[6] = 2.0; return; }
+   const double beta = gn / S[0];
+   const double den = dl - beta * gn / S[4];                              // = (A p, p) of the next direction
+   S[1] = den;
+   if (den == 0.0) { S[6] = -1.0; return; }
+   if (den < 0.0) S[10] += 1.0;
+   S[5] = beta; S[4] = gn / den; S[0] = gn;
+}
+// p = u + beta p; q = s + beta q; x += alpha p; r -= alpha q; u = dinv r; s = 0 (the operator action that follows accumulates into it)
+template <bool IDENT>
+__global__ void k_cg2_update(int64_t n, const double* __restrict__ S, const double* __restrict__ dinv, double* __restrict__ x, double* __restrict__ r,
+                             double* __restrict__ u, double* __restrict__ p, double* __restrict__ sv, double* __restrict__ q) {
+   if (S[6] != 0.0) return;
+   const double alpha = S[4], beta = S[5];
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const double ui = IDENT ? r[i] : u[i];
+      const double pi = ui + beta * p[i], qi = sv[i] + beta * q[i];
+      p[i] = pi; q[i] = qi; x[i] += alpha * pi;
+      const double ri = r[i] - alpha * qi;
+      r[i] = ri;
+      if (!IDENT) u[i] = dinv[i] * ri;
+      sv[i] = 0.0;
+   }
+}
+// essential rows of s zeroed in place + the two partial weighted dots (r, u) and (s, u) in one pass (partial[0..nb) and partial[nb..2nb))
+template <bool IDENT>
+__global__ void k_cg2_dots(int64_t n, int64_t nn, const double* __restrict__ w, const uint8_t* __restrict__ m, const double* __restrict__ r, const double* __restrict__ u,
+                           double* __restrict__ sv, const double* __restrict__ flag, double* __restrict__ partial) {
+   __shared__ double sm[RBLK];
+   if (flag[0] != 0.0) return;
+   double a0 = 0, a1 = 0;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const double ui = IDENT ? r[i] : u[i], wi = w[i % nn];
+      a0 += wi * r[i] * ui;
+      if (m[i]) sv[i] = 0.0; else a1 += wi * sv[i] * ui;
+   }
+   const double s0 = block_sum(a0, sm); __syncthreads();
+   const double s1 = block_sum(a1, sm);
+   if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }
+}
+__global__ void k_reduce2(int nb, const double* __restrict__ partial, const double* __restrict__ flag, double* __restrict__ out2) {
+   __shared__ double sm[RBLK];
+   if (flag[0] != 0.0) return;
+   double a0 = 0, a1 = 0;
+   for (int i = threadIdx.x; i < nb; i += RBLK) { a0 += partial[i]; a1 += partial[nb + i]; }
+   const double s0 = block_sum(a0, sm); __syncthreads();
+   const double s1 = block_sum(a1, sm);
+   if (threadIdx.x == 0) { out2[0] = s0; out2[1] = s1; }
+}
+
 // essential rows of b zeroed in place + partial weighted dot (a, b): the operator's output mask and the PCG denominator in one pass
 __global__ void k_mask_dot_partial(int64_t n, int64_t nn, const double* __restrict__ w, const uint8_t* __restrict__ m, const double* __restrict__ a,
                                    double* __restrict__ b, const double* __restrict__ flag, double* __restrict__ partial) {
@@ -262,6 +325,20 @@ void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double
    else hipLaunchKernelGGL(k_cg_step1<false>, dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial);
    if (fuse_beta) hipLaunchKernelGGL(k_reduce_cg<1>, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S, (double)max_iter);
    else hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S + 6, S + 8);
+}
+void vk_cg2_init(double* S, double rel, double abs_, hipStream_t s) { hipLaunchKernelGGL(k_cg2_init, dim3(1), dim3(1), 0, s, S, rel, abs_); }
+void vk_cg2_scalars(double* S, int max_iter, hipStream_t s) { hipLaunchKernelGGL(k_cg2_scalars, dim3(1), dim3(1), 0, s, S, (double)max_iter); }
+void vk_cg2_update(int64_t n, const double* S, const double* dinv, double* x, double* r, double* u, double* p, double* sv, double* q, bool ident, hipStream_t s) {
+   if (ident) hipLaunchKernelGGL(k_cg2_update<true>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, dinv, x, r, u, p, sv, q);
+   else hipLaunchKernelGGL(k_cg2_update<false>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, dinv, x, r, u, p, sv, q);
+}
+// local parts of (r, u)_w and (s, u)_w -> out2[0..1] (device); masks the essential rows of s on the way
+void vk_cg2_dots(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* r, const double* u, double* sv, const double* flag, double* partial, double* out2,
+                 bool ident, hipStream_t s) {
+   const unsigned nb = gblk(n) < (unsigned)(DOT_BLOCKS / 2) ? gblk(n) : (unsigned)(DOT_BLOCKS / 2);
+   if (ident) hipLaunchKernelGGL(k_cg2_dots<true>, dim3(nb), dim3(RBLK), 0, s, n, nn, w, m, r, u, sv, flag, partial);
+   else hipLaunchKernelGGL(k_cg2_dots<false>, dim3(nb), dim3(RBLK), 0, s, n, nn, w, m, r, u, sv, flag, partial);
+   hipLaunchKernelGGL(k_reduce2, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out2);
 }
 void vk_cg_step2(int64_t n, const double* S, const double* z, double* d, hipStream_t s) { hipLaunchKernelGGL(k_cg_step2, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, d); }
 void vk_pack(int64_t n, const int32_t* idx, const double* y, double* buf, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_pack, dim3(nblk(n)), dim3(256), 0, s, n, idx, y, buf); }
