@@ -120,3 +120,34 @@ def test_cyclic_reversal_branches(oracle):
     assert np.max(np.abs(s[:, 2] - g[:, 2])) < 3e-6 * np.abs(g[:, 2]).max()
     for lo, hi in ((10, 14), (30, 34), (50, 54)):      # elastic unloading branches
         assert np.max(np.abs(s[lo:hi, 2] - g[lo:hi, 2])) < 1e-6 * np.abs(g[:, 2]).max()
+
+
+def test_auto_time_stepping_case_elastic_branch(oracle):
+    """mtsdd_full_auto (Time.Auto, IN625-like Kocks-Mecking properties, compression): the golden file holds stresses only, the step sizes
+    depend on the Newton iteration counts k_n of the reference's FULL-assembly + BoomerAMG solve (dt_{n+1} = dt_n * 25 * 0.333333 / k_n,
+    src/system_driver.cpp:263-269), which are not reproducible here.  The replay mode of the oracle (oracle/driver_port.hpp,
+    run_case_replay) infers k_n row by row: it tries the 25 admissible step sizes and keeps the one whose stress INCREMENT matches the golden
+    row.  On the elastic branch (rows 1-11) this pins the rule and the response: every increment is reproduced to < 0.02 MPa with the integer
+    sequence k = 2, 24, 6, 6, 15, 6, 6, 9, 21, 7 (24 Newton iterations on an elastic step: the reference's linear solver, not the material).
+    Row 2 of the golden file carries a one-off deficit of 2.01 MPa that persists unchanged through the elastic rows - an artefact of that
+    barely-converged step of the reference, not a material response (no slip below |tau| = tau_a = 260 MPa)."""
+    orc = oracle
+    g = orc.golden("mtsdd_full_auto_stress.txt")[:, 2]
+    out = orc.run_case(orc.load_case("mtsdd_full_auto.toml"), replay_target33=g[:11], replay_increments=True)
+    s = out["avg_stress"][:, 2]
+    assert len(s) == 11 and list(out["ks"][1:]) == [2, 24, 6, 6, 15, 6, 6, 9, 21, 7]
+    assert abs(s[0] / g[0] - 1.0) < 2e-6
+    off = s - g[:11]
+    assert np.all(np.abs(off[1:9] - off[1]) < 0.01) and abs(off[1] + 2.01) < 0.01      # rows 2-9 (sigma from -107 to -439 MPa): < 3e-5 of the increments
+    assert abs(off[9] - off[1]) < 0.06                                                  # row 10: first slip in the best-oriented grains
+
+
+@pytest.mark.xfail(reason="OPEN: thermally activated Kocks-Mecking regime (p = 0.8, q = 1.4, c_e = 26) is not pinned: with admissible step sizes the oracle "
+                          "follows the golden increments of rows 12-50 within 1.5 MPa but uses up t_final = 10 by row 50 of 71 (its stress at t = 10 is "
+                          "-725 MPa against the file's -773 MPa)", strict=False)
+def test_auto_time_stepping_case_plastic_branch(oracle):
+    orc = oracle
+    g = orc.golden("mtsdd_full_auto_stress.txt")[:, 2]
+    out = orc.run_case(orc.load_case("mtsdd_full_auto.toml"), replay_target33=g, replay_increments=True)
+    assert len(out["avg_stress"]) == len(g)
+    assert np.max(np.abs(np.diff(out["avg_stress"][:, 2]) - np.diff(g))) < 0.05
