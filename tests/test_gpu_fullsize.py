@@ -194,3 +194,64 @@ def test_full_size_order2_bbar_element_assembly(oracle):
     y1, y2, y12 = apply(x1), apply(x2), apply(0.7 * x1 - 1.9 * x2)
     assert float((y12 - (0.7 * y1 - 1.9 * y2)).norm() / y12.norm()) < 1e-12
     ctx.close()
+
+
+def test_config3_bcc_kmdd_128_sampled_against_oracle(oracle):
+    """BASELINE config 3: 128^3 hex RVE, BCC Kocks-Mecking dislocation-density model on one MI355X.  The constitutive pass in the driver's layout
+    (element-blocked, fused L-vector launch, tail split on) through the elastic-plastic transition; 48 sampled elements are recomputed by the
+    oracle from the inputs the last GPU pass consumed."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    N = 128
+    rve = hipref.make_rve(orc, N)
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    props = np.loadtxt(os.path.join(orc.REFDATA, "props_cp_mts.txt")).ravel()
+    ctx = L.Context(L.EXA_BCC_KMDD, props, 298.0, 1, E, assembly=L.EXA_ASSEMBLY_PA)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+    ctx.check(L.exa_set_quadrature_layout(ctx.h, L.EXA_QLAYOUT_EB64))
+    ctx.check(L.exa_set_newton_cap(ctx.h, 8))
+    nq = lambda w: int(L.exa_qf_size(ctx.h, w))
+    quats = hipref.random_quats(E)
+    d_sv = [dev.zeros(nq(28)), dev.zeros(nq(28))]; d_s = [dev.zeros(nq(6)), dev.zeros(nq(6))]
+    d_cm = dev.zeros(nq(36)); d_J = dev.zeros(nq(9))
+    d_quats_keep = dev.up(quats.ravel())
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_sv[0]), ptr(d_quats_keep), None))
+    v_nodes = hipref.velocity_field(rve)
+    d_v = dev.up(v_nodes); d_x = dev.up(rve["X"])
+    dts = [0.005, 0.195, 0.1, 0.1, 0.1]
+    for i, dt in enumerate(dts):
+        d_x += dt * d_v
+        if i == len(dts) - 1:
+            sv_in, s_in = d_sv[0].clone(), d_s[0].clone()
+        ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(d_s[0]), ptr(d_sv[0]), ptr(d_s[1]), ptr(d_sv[1]), ptr(d_cm), ptr(d_J), None))
+        assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+        d_sv.reverse(); d_s.reverse()
+    assert ctx.check(L.exa_model_tail_count(ctx.h, None)) > 0            # the last launch did use the tail split
+
+    def rows(t, w):   # element-blocked [block of 64][q][comp][lane] -> (P, w) in the reference's point order
+        nb = (E + 63) // 64
+        return t.view(nb, Q, w, 64).permute(0, 3, 1, 2).reshape(nb * 64 * Q, w)[:P]
+    rng = np.random.default_rng(3)
+    es = np.sort(rng.choice(E, 48, replace=False))
+    qidx = torch.from_numpy((es[:, None] * Q + np.arange(Q)[None, :]).ravel()).to(dev.dev)
+    take = lambda t, w: rows(t, w)[qidx].cpu().numpy().ravel()
+    conn = rve["conn"].reshape(E, n)[es]
+    x_end = d_x.cpu().numpy()
+    xe = np.stack([x_end[conn + NN * c] for c in range(3)], axis=1).ravel()
+    ve = np.stack([v_nodes[conn + NN * c] for c in range(3)], axis=1).ravel()
+    Js = np.zeros(9 * len(es) * Q); orc.lib().orc_jacobians(1, len(es), orc._p(xe), orc._p(Js))
+    assert rel_l2(take(d_J, 9), Js) < 1e-13
+    s1 = np.zeros(6 * len(es) * Q); sv = np.zeros(28 * len(es) * Q); cm = np.zeros(36 * len(es) * Q)
+    nf = orc.lib().orc_model_setup(1, 2, orc._p(props), len(props), Q, len(es), n, 28, C.c_double(dts[-1]), C.c_double(298.0), orc._p(Js), orc._p(rve["G"]),
+                                   orc._p(ve), orc._p(take(s_in, 6)), orc._p(take(sv_in, 28)), orc._p(s1), orc._p(sv), orc._p(cm), None, 1, 0, 0)
+    assert nf == 0
+    assert rel_l2(take(d_s[0], 6), s1) < 1e-9
+    assert rel_l2(take(d_cm, 36), cm) < 1e-7
+    keep = np.ones(28, bool); keep[3] = False
+    assert rel_l2(take(d_sv[0], 28).reshape(-1, 28)[:, keep], sv.reshape(-1, 28)[:, keep]) < 1e-8
+    assert np.abs(sv.reshape(-1, 28)[:, 14:26]).sum() > 0                  # plastic
+    ctx.close()
