@@ -217,11 +217,12 @@ def main():
                 traffic["_file"] = "profiles/" + cands[-1]
         except Exception:
             traffic = {}
-        flops = None
+        flops = None; valu_per_wave = None
         try:
             cf = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_flops.json"))
             if cf:
-                flops = json.load(open(os.path.join(ROOT, "profiles", cf[-1])))["k_model_setup"]["plastic"]["flop_per_qpt"]
+                pl = json.load(open(os.path.join(ROOT, "profiles", cf[-1])))["k_model_setup"]["plastic"]
+                flops = pl["flop_per_qpt"]; valu_per_wave = pl["valu_insts_per_wave"]
         except Exception:
             flops = None
         model_gbs = MODEL_BYTES_PER_QPT * P_local / (kern_ms * 1e-3) / 1e9
@@ -248,9 +249,16 @@ def main():
                          "bytes_per_qpt": MODEL_BYTES_PER_QPT, "avg_kernel_ms": kern_ms,
                          "fp64_flop_per_qpt": flops, "fp64_tflops": (flops * P_local / (kern_ms * 1e-3) / 1e12) if flops else None,
                          "fp64_vector_frac": (flops * P_local / (kern_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TFLOPS) if flops else None,
-                         "note": "FP64-VALU-bound kernel (78 % VALU-busy, SURVEY 8(d)): the HBM fraction of the ALGORITHMIC bytes is reported as the "
-                                 "contract asks; measured traffic (PMC) is ~2x the algorithmic bytes (parking + spills, DESIGN 4.1); "
-                                 "see roofline_pcg_apply for the HBM-bound half of the metric"},
+                         # FP64 issue roofline: a wave64 FP64 VALU instruction occupies its SIMD for 4 cycles (16 FMA lanes per clock and SIMD = the
+                         # 78.6 TFLOP/s vector peak); issue time = instructions per wave x 4 cycles x waves per SIMD / 2.4 GHz
+                         "fp64_issue": ({"valu_insts_per_wave": valu_per_wave, "ms_at_full_issue": valu_per_wave * 4.0 * (P_local / 64.0 / 1024.0) / 2.4e9 * 1e3,
+                                         "frac": valu_per_wave * 4.0 * (P_local / 64.0 / 1024.0) / 2.4e9 * 1e3 / kern_ms} if valu_per_wave else None),
+                         "note": "the contract's HBM fraction of the ALGORITHMIC bytes (928 B/qpt) is reported in frac; the launch itself is bound by FP64 VALU "
+                                 "issue: SQ counters (profiles/r02_pmc_sq_summary.txt) show the VALU busy 87 % of the wave cycles, and the wave-cycle count "
+                                 "of a launch (12.9 M per SIMD in 6.98 ms) says the chip sustains ~1.85 GHz under this FP64 load, not the nominal 2.4 GHz the "
+                                 "fp64_issue figures are priced at (a pure v_fma_f64 loop reaches 63.7 TFLOP/s = 81 % of the 78.6 TFLOP/s nominal peak, "
+                                 "profiles/r02_mfma_tangent_experiment.txt); traffic = L2-boundary bytes from the PMC passes (spill stores make it ~1.6x the "
+                                 "algorithmic bytes, DESIGN 4.1); roofline_pcg_apply is the HBM-bound half of the metric"},
             "roofline_pcg_apply": {"kernel": ("k_ea_apply_p1 (element mat-vec)" if ea_streamed else "k_grad_apply_p1<LVEC,GEO,CMP> (AddMultGradPA / matrix-free element-assembly action + gather/scatter)"), "bound": "hbm",
                                    "achieved": moved * P_local / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": moved * P_local / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -7,6 +7,7 @@
 #include "../../../include/exaconstit_driver.h"
 #include <cmath>
 #include <cstring>
+#include <string>
 
 using namespace exa_host;
 
@@ -146,7 +147,8 @@ int exa_driver_bench_model(exa_driver* d, int steps, double* out, char* err, int
       hipStream_t s = op.stream();
       hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1));
       const double t0 = op.timers.t_model_ms;
-      ProfRegion prof("timed_region_model");
+      const std::string rname = "timed_region_model[passes=" + std::to_string(steps) + "]";   // the bench's warm-up / elastic / plastic loops differ in length
+      ProfRegion prof(rname.c_str());
       EXA_HC(hipEventRecord(e0, s));
       for (int i = 0; i < steps; i++) op.Setup<true>(sd.v_sol.p);
       EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
@@ -169,7 +171,8 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out, char* err, int e
       const double rel = o.krylov_rel, ab = o.krylov_abs; const int mi = o.krylov_iter;
       o.krylov_rel = 0.0; o.krylov_abs = 0.0; o.krylov_iter = iters;
       const double t0 = op.timers.t_krylov_ms;
-      ProfRegion prof("timed_region_pcg");
+      const std::string rname = "timed_region_pcg[iters=" + std::to_string(iters) + "]";
+      ProfRegion prof(rname.c_str());
       const int it = sd.CGSolve(r.p, c.p);
       out[0] = op.timers.t_krylov_ms - t0; out[1] = it;
       o.krylov_rel = rel; o.krylov_abs = ab; o.krylov_iter = mi;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # run on the GPU box: FP64 operation counts of the constitutive kernel (plastic-regime pass = last dispatch of bench.py)
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d gpurun_out/${tag}_pmc_flops -- python bench.py --steps 3 --warmup 1 --pcg-iters 10 --no-cpu-baseline > gpurun_out/${tag}_pmc_flops.log 2>&1
 python - <<PY

@@ -9,7 +9,7 @@ CMD="python bench.py --steps ${STEPS:-100} --warmup 5 --pcg-iters 100 --no-cpu-b
 rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d gpurun_out/${tag}_trace -- $CMD > gpurun_out/${tag}_trace.log 2>&1
 python scripts/region_summary.py gpurun_out/${tag}_trace gpurun_out/${tag}_region_summary.csv
 cp $(ls gpurun_out/${tag}_trace/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_kernel_stats.csv 2>/dev/null
-tail -1 gpurun_out/${tag}_trace.log > gpurun_out/${tag}_bench_under_rocprof.json
+grep '^{"metric"' gpurun_out/${tag}_trace.log > gpurun_out/${tag}_bench_under_rocprof.json
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python bench.py --steps 3 --warmup 1 --pcg-iters 20 --no-cpu-baseline > gpurun_out/${tag}_pmc_$c.log 2>&1
 done
