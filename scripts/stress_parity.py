@@ -35,6 +35,10 @@ for name, xtal, kin, pfile, model in [("fcc_voce", 0, 0, "props_cp_voce.txt", 0)
         ctx.check(L.exa_model_setup(ctx.h, dt, *[ptr(t) for t in d], *[ptr(t) for t in o], None))
         nfg = ctx.check(L.exa_model_status(ctx.h, None))
         gs, gc = o[0].cpu().numpy().reshape(P, 6), o[2].cpu().numpy().reshape(P, 36)
+        # which points gave up: the evaluation counter (state slot 3) of a non-converged solve is at its cap of 200 (or the trust region collapsed)
+        fo = set(np.nonzero(sv1.reshape(P, 28)[:, 3] >= 200)[0]); fg = set(np.nonzero(o[1].cpu().numpy().reshape(P, 28)[:, 3] >= 200)[0])
+        if nfo or nfg:
+            print(f"    non-converged points: oracle {nfo} (at the 200-evaluation cap: {len(fo)}), gpu {nfg} (at the cap: {len(fg)}), common at the cap: {len(fo & fg)}", flush=True)
         rs, rc = s1.reshape(P, 6), cm.reshape(P, 36)
         good = np.isfinite(gs).all(1) & np.isfinite(rs).all(1)
         es = np.linalg.norm(gs - rs, axis=1) / (np.linalg.norm(rs, axis=1) + 1e-30)
