@@ -568,7 +568,7 @@ int SystemDriver::CGSolveSingleReduction(const double* b, double* x) {
 // device PCG (MFEM CGSolver::Mult with iterative_mode = false); all scalars stay on the device, the host only polls the
 // done-flag every cg_check_every iterations.
 int SystemDriver::CGSolve(const double* b, double* x) {
-   if (comm.nranks > 1 && std::getenv("EXA_PCG_TWO_REDUCTIONS") == nullptr) return CGSolveSingleReduction(b, x);
+   if ((comm.nranks > 1 || comm.forced()) && std::getenv("EXA_PCG_TWO_REDUCTIONS") == nullptr) return CGSolveSingleReduction(b, x);
    NonlinearMechOperator& op = *oper_;
    hipStream_t s = op.stream();
    const int64_t nd = op.Height(), nn = part.NN;

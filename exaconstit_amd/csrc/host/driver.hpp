@@ -35,6 +35,7 @@ class Comm {
    void halo_sum(const Partition& part, double* y, hipStream_t s);
    void setup_halo(const Partition& part);
    double max_over_ranks(double v);
+   bool forced() const { return force_; }   // EXA_FORCE_RCCL=1: the one-rank communicator runs the multi-rank code paths and every RCCL call
  private:
    void loopback_reduce(double* dev, int n, int op, hipStream_t s);
    void* comm_ = nullptr; void* loop_ = nullptr; bool force_ = false;

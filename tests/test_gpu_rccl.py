@@ -38,8 +38,11 @@ def test_forced_rccl_on_one_rank(oracle, tmp_path, case, jacobi):
     forced = _worker(tmp_path, "forced", case, n, {"EXA_FORCE_RCCL": "1"}, jacobi=jacobi)
     assert plain["ok"] and forced["ok"] and forced["forced"] and not plain["forced"]
     a, b = np.array(plain["avg_stress"]), np.array(forced["avg_stress"])
-    assert np.max(np.abs(a - b)) < 1e-9 * np.abs(a).max()          # FP64 atomics in the scatter: not bitwise
+    # the forced run also takes the multi-rank PCG (single fused 16-byte all-reduce per iteration) instead of the one-rank loop: same answers
+    # to the Krylov tolerance, same Newton counts, Krylov counts within a few iterations
+    assert np.max(np.abs(a - b)) < 1e-7 * np.abs(a).max()
     assert plain["newton"] == forced["newton"]
+    assert all(abs(x - y) <= max(3, 0.03 * x) for x, y in zip(plain["krylov"], forced["krylov"]))
 
 
 def test_two_ranks_over_rccl(oracle, tmp_path):
