@@ -142,12 +142,14 @@ def test_auto_time_stepping_case_elastic_branch(oracle):
     assert abs(off[9] - off[1]) < 0.06                                                  # row 10: first slip in the best-oriented grains
 
 
-@pytest.mark.xfail(reason="OPEN: thermally activated Kocks-Mecking regime (p = 0.8, q = 1.4, c_e = 26) is not pinned: with admissible step sizes the oracle "
-                          "follows the golden increments of rows 12-50 within 1.5 MPa but uses up t_final = 10 by row 50 of 71 (its stress at t = 10 is "
-                          "-725 MPa against the file's -773 MPa)", strict=False)
+@pytest.mark.xfail(reason="OPEN: thermally activated Kocks-Mecking regime (p = 0.8, q = 1.4, c_e = 26) is not pinned: the last row of the golden file is at "
+                          "t = t_final = 10 exactly, where the oracle's sigma_33 is -725 MPa against the file's -773 MPa (the response there does not depend on "
+                          "the step sizes: 20 or 200 steps agree to 0.1 MPa); replay experiments in DESIGN.md section 5", strict=False)
 def test_auto_time_stepping_case_plastic_branch(oracle):
     orc = oracle
-    g = orc.golden("mtsdd_full_auto_stress.txt")[:, 2]
-    out = orc.run_case(orc.load_case("mtsdd_full_auto.toml"), replay_target33=g, replay_increments=True)
-    assert len(out["avg_stress"]) == len(g)
-    assert np.max(np.abs(np.diff(out["avg_stress"][:, 2]) - np.diff(g))) < 0.05
+    g = orc.golden("mtsdd_full_auto_stress.txt")
+    case = orc.load_case("mtsdd_full_auto.toml")
+    case["auto"] = None; case["dts"] = np.full(20, 0.5)
+    out = orc.run_case(case)
+    assert out["failed"] == 0
+    assert abs(out["avg_stress"][-1, 2] / g[-1, 2] - 1.0) < 2e-3
