@@ -53,8 +53,9 @@ __device__ __forceinline__ void stg(double* p, double v) {
 constexpr int H_SHRATE = 0, H_SHR = 1, H_FLOW = 2, H_NFEV = 3, H_E = 4, H_Q = 9, H_H = 13, H_GDOT = 14;
 constexpr int NUM_HIST = 26, NSTATEV = 28, IND_VOL = 26, IND_EINT = 27;
 
-enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2 };
-constexpr bool kin_is_km(int k) { return k == KIN_KMBALD; }
+enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2,
+       KIN_KMBALD_GA = 3 };   // compile-time variant of KIN_KMBALD for with_g_athermal (BCC): same arithmetic, window systems deferred (eval_rj)
+constexpr bool kin_is_km(int k) { return k == KIN_KMBALD || k == KIN_KMBALD_GA; }
 
 // Schmid tensors of the 12 FCC {111}<110> systems: P = vecd(sym(s x m)), Q = axial(skew(s x m)).
 // a = sqrt(3)/6, b = sqrt(6)/12.
@@ -293,8 +294,15 @@ ECM_DI void mts_dG(const MatParams& mp, double c_e, double t_frac, double& exp_a
 #ifndef ECM_KW
 #define ECM_KW 2
 #endif
+#ifndef ECM_KD
+#define ECM_KD 2
+#endif
+constexpr int KD = ECM_KD;   // systems per group of the cheap classes in the deferred form (only one exp each: wider groups for ILP)
+#ifndef ECM_KM_DEFER
+#define ECM_KM_DEFER 1   // athermal-threshold (BCC) variant: window systems are treated one per lane after the group loop (eval_rj)
+#endif
 constexpr int KW = ECM_KW;   // slip systems evaluated together by the Kocks-Mecking kinetics (ILP vs registers; tuned on MI355X)
-template <bool WITHD>
+template <bool WITHD, int KW = ECM_KW>
 ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double tau[KW], double gdot[KW], double dg[KW]) {
    const double g_i = mp.with_g_athermal ? 1.0 / mp.tau_a : 1.0 / kv.g;
    const double gAth = mp.with_g_athermal ? kv.g : mp.tau_a;
@@ -336,8 +344,18 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
          for (int a = 0; a < KW; a++) mts_dG(mp, kv.c_e, (-at[a] - gAth) * g_i, eab[a], dfb[a]);
 #pragma unroll
          for (int a = 0; a < KW; a++) ef[a] = exp(eaf[a]);
+         // backward jumps: exp(x) is exactly 0 in double for x < -745.2, which is the case for every in-window system of the athermal-threshold
+         // variant ((-|tau| - g) / tau_a << -1): the call is skipped when no lane of the wave needs it (bit-identical)
+         bool any_b = (KW != 1);     // (the grouped form keeps the unconditional call: its exp chains interleave with the forward ones)
 #pragma unroll
-         for (int a = 0; a < KW; a++) eb[a] = exp(eab[a]);
+         for (int a = 0; a < KW; a++) any_b = any_b || (inwin[a] && eab[a] > -746.0);
+         if (any_b) {
+#pragma unroll
+            for (int a = 0; a < KW; a++) eb[a] = exp(eab[a]);
+         } else {
+#pragma unroll
+            for (int a = 0; a < KW; a++) eb[a] = 0.0;
+         }
 #pragma unroll
          for (int a = 0; a < KW; a++) pw[a] = 0.0;
          if (any_tail) {   // power-law tail: only above t_min = (1e-60)^m (rare for large 1/m)
@@ -447,6 +465,7 @@ struct Prob {
    double dt_ri, detV_ri, sc, sc_i, g_i;   // sc = epsdot_scale_inv, sc_i = 1/sc, g_i = 1/g
    double esc, esc_i;                      // E_SCALE / a_V and its inverse
    double* st;                             // per-thread stash
+   const double* pqt;                      // Kocks-Mecking: slip table in LDS (12 rows of 8), nullptr -> PQ_TAB in global memory
    int gs;                                 // stride of the slip-rate outputs (1 or 64, see point_update's QS)
    KinVals kv;
 };
@@ -534,7 +553,100 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 #pragma unroll
          for (int j = 0; j < 5; j++) jac.B[i][j] = 0.0;
    }
-   {
+   // (the runtime flag is always set in the KIN_KMBALD_GA instantiation; with the test compiled away the register allocator of ROCm 7.2
+   //  spills 850 B/lane instead of 330 and the kernel runs 2.5x slower, so the never-taken alternative stays in that instantiation)
+   if (ECM_KM_DEFER && KIN == KIN_KMBALD_GA && mp.with_g_athermal) {
+      // Athermal-threshold variant (BCC): a system is dormant (|tau| <= g), drag-limited (at_0 > t_max: one exp) or - for |tau| - g inside
+      // the narrow thermally activated window (0, t_max tau_a] - needs the full balanced kinetics (four more exp/log).  About 1 % of
+      // the (point, system) pairs are in the window, but a wave of 64 points x KW systems nearly always holds one, so the grouped form
+      // below pays the window phases in almost every group.  Here the groups only do the cheap classes and note the window systems in a
+      // per-lane bit mask; a second loop then treats ONE pending system per lane and pass (table row by lane-varying index), which
+      // ends after max-over-lanes(pending) ~ 1-2 passes.  Same arithmetic per system; only the order of the 12 contributions to the
+      // sums changes (round-off).
+      const double g_ia = 1.0 / mp.tau_a, gAth = pb.kv.g, wi = 1.0 / mp.wrD;
+      unsigned pend = 0;
+#pragma unroll 1
+      for (int a0 = 0; a0 < NSLIP; a0 += KD) {
+         double pq[KD][8], tau[KD], gd[KD], dg[KD], xr[KD];
+         bool live[KD], over[KD], any_live = false;
+#pragma unroll
+         for (int a = 0; a < KD; a++) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) pq[a][c] = PQ_TAB[a0 + a][c];
+            tau[a] = pq[a][0] * k[0] + pq[a][1] * k[1] + pq[a][2] * k[2] + pq[a][3] * k[3] + pq[a][4] * k[4];
+            const double at = fabs(tau[a]);
+            xr[a] = (at - gAth) * wi;
+            live[a] = (tau[a] != 0.0) && (xr[a] > 0.0); over[a] = fmax(0.0, at - gAth) * g_ia > mp.t_max;
+            any_live = any_live || live[a];
+            gd[a] = 0.0; dg[a] = 0.0;
+            if (live[a] && !over[a]) pend |= 1u << (a0 + a);
+         }
+         if (any_live) {
+            double ex[KD];
+#pragma unroll
+            for (int a = 0; a < KD; a++) ex[a] = exp(-fmax(xr[a], 0.0));
+#pragma unroll
+            for (int a = 0; a < KD; a++) {
+               const bool small = xr[a] < EPS_SQRT;
+               const double gr = small ? pb.kv.gam_r * xr[a] : pb.kv.gam_r * (1.0 - ex[a]);
+               const double dgr = (small ? pb.kv.gam_r : pb.kv.gam_r * ex[a]) * wi;
+               if (live[a] && over[a]) { gd[a] = copysign(gr, tau[a]); dg[a] = dgr; }
+            }
+         }
+#pragma unroll
+         for (int a = 0; a < KD; a++) {
+            if (gdot_out) gdot_out[(a0 + a) * pb.gs] = gd[a];
+            dis += tau[a] * gd[a]; shr += fabs(gd[a]);
+#pragma unroll
+            for (int c = 0; c < 5; c++) dp[c] += pq[a][c] * gd[a];
+#pragma unroll
+            for (int c = 0; c < 3; c++) wp[c] += pq[a][5 + c] * gd[a];
+            if (WITHJ) {
+               double gp[5];
+#pragma unroll
+               for (int c = 0; c < 5; c++) gp[c] = dg[a] * pq[a][c];
+#pragma unroll
+               for (int i = 0; i < 5; i++)
+#pragma unroll
+                  for (int j = i; j < 5; j++) jac.A[sidx(i, j)] += pq[a][i] * gp[j];
+#pragma unroll
+               for (int i = 0; i < 3; i++)
+#pragma unroll
+                  for (int j = 0; j < 5; j++) jac.B[i][j] += pq[a][5 + i] * gp[j];
+            }
+         }
+      }
+      while (__ballot(pend != 0) != 0ull) {      // one pending window system per lane and pass
+         if (pend != 0) {
+            const int a = __ffs((int)pend) - 1; pend &= pend - 1;
+            double pq[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) pq[c] = pb.pqt ? pb.pqt[8 * a + c] : PQ_TAB[a][c];      // lane-varying row: LDS copy of the 768-byte table
+            double tau1[1] = { pq[0] * k[0] + pq[1] * k[1] + pq[2] * k[2] + pq[3] * k[3] + pq[4] * k[4] }, gd1[1], dg1[1];
+            kmbald_gdot4<WITHJ, 1>(mp, pb.kv, tau1, gd1, dg1);
+            if (gdot_out) gdot_out[a * pb.gs] = gd1[0];
+            dis += tau1[0] * gd1[0]; shr += fabs(gd1[0]);
+#pragma unroll
+            for (int c = 0; c < 5; c++) dp[c] += pq[c] * gd1[0];
+#pragma unroll
+            for (int c = 0; c < 3; c++) wp[c] += pq[5 + c] * gd1[0];
+            if (WITHJ) {
+               double gp[5];
+#pragma unroll
+               for (int c = 0; c < 5; c++) gp[c] = dg1[0] * pq[c];
+#pragma unroll
+               for (int i = 0; i < 5; i++)
+#pragma unroll
+                  for (int j = i; j < 5; j++) jac.A[sidx(i, j)] += pq[i] * gp[j];
+#pragma unroll
+               for (int i = 0; i < 3; i++)
+#pragma unroll
+                  for (int j = 0; j < 5; j++) jac.B[i][j] += pq[5 + i] * gp[j];
+            }
+         }
+      }
+      ok = isfinite(shr);
+   } else {
 #pragma unroll 1
       for (int a0 = 0; a0 < NSLIP; a0 += KW) {   // rolled over groups: the table rows of a group come in through scalar loads
          double pq[KW][8], tau[KW], gd[KW], dg[KW];
@@ -819,9 +931,10 @@ ECM_DI double norm8(const double v[8]) { double s = 0; for (int i = 0; i < 8; i+
 // AoS quadrature functions, 64 for the element-blocked layout (exa_internal.hpp, QView)
 template <int KIN, int QS>
 ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const double* __restrict__ sv0, const double* __restrict__ s0,
-                        double* __restrict__ sv1, double* __restrict__ s1, double* __restrict__ cmat, double* st, const int kcap) {
+                        double* __restrict__ sv1, double* __restrict__ s1, double* __restrict__ cmat, double* st, const int kcap,
+                        const double* pq_lds = nullptr) {
    double* cold = cmat;
-   Prob pb; pb.st = st; pb.gs = QS;
+   Prob pb; pb.st = st; pb.gs = QS; pb.pqt = pq_lds;
    pb.dt_ri = 1.0 / dt;
    {
       // ---- kernel_setup (reference src/mechanics_ecmech.cpp:42-99)

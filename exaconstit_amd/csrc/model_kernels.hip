@@ -35,10 +35,11 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    constexpr bool P2F = (NFIX == 27);   // triquadratic fused path: G holds the 3 x 6 one-dimensional tables, read through scalar loads
    extern __shared__ double sG[];   // (n,3,Q) shape table (not for P2F), then the per-thread stash
    const int tab = P2F ? 0 : n * 3 * Q;
-   if (!P2F) {
-      for (int i = threadIdx.x; i < tab; i += blockDim.x) sG[i] = G[i];
-      __syncthreads();
-   }
+   // Kocks-Mecking: the slip table (12 rows of 8) behind the stash, for the rows that are read by lane-varying index (ecm_device.hpp, eval_rj)
+   const int pqo = tab + ecmdev::ST_SLOTS * ECM_STASH_STRIDE;
+   if (!P2F) for (int i = threadIdx.x; i < tab; i += blockDim.x) sG[i] = G[i];
+   if (ecmdev::kin_is_km(KIN) && threadIdx.x < 8 * ecmdev::NSLIP) sG[pqo + threadIdx.x] = (&ecmdev::PQ_TAB[0][0])[threadIdx.x];
+   if (!P2F || ecmdev::kin_is_km(KIN)) __syncthreads();
    int q; int64_t e;
    if (tail_mode) {   // dense pass over the points the capped launch handed over: thread t owns point tail[1 + t]
       const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    }
    // per-thread stash behind the shape table in LDS: slot s of this thread at stash[s * 256 + threadIdx.x]
    double* st = sG + tab + threadIdx.x;
-   const int rc = point_update<KIN, QS>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, cmat + vC.base, st, kcap);
+   const int rc = point_update<KIN, QS>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, cmat + vC.base, st, kcap, sG + pqo);
    if (rc == 2) { const int slot = atomicAdd(&tail[0], 1); tail[1 + slot] = (int)(e * Q + q); }
    else if (rc) atomicAdd(fail, 1);
 }
@@ -201,7 +202,8 @@ static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel
    const int bs = 256;
    // QB: one wave per (64-element block, q)
    const int64_t nb = QB ? (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64) : (ctx->P + bs - 1) / bs;
-   const size_t lds = sizeof(double) * ((NFIX == 27 ? (size_t)0 : (size_t)ctx->n * 3 * ctx->Q) + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE);
+   const size_t lds = sizeof(double) * ((NFIX == 27 ? (size_t)0 : (size_t)ctx->n * 3 * ctx->Q) + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE +
+                                        (ecmdev::kin_is_km(KIN) ? (size_t)8 * ecmdev::NSLIP : (size_t)0));
    const double* G = NFIX == 27 ? ctx->T1_dev : ctx->G_dev;
    static_assert(ECM_STASH_STRIDE == 256, "stash stride must equal the block size");
    const bool split = ctx->newton_cap > 0 && ctx->tail_dev != nullptr;
@@ -249,8 +251,13 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
          else launch_model<KIN_VOCE_NL, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
       default:
-         if (lv) launch_model<KIN_KMBALD, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
-         else launch_model<KIN_KMBALD, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         if (ECM_KM_DEFER && ctx->mp.with_g_athermal) {   // athermal-threshold variant (BCC): instantiation with the deferred window systems
+            if (lv) launch_model<KIN_KMBALD_GA, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+            else launch_model<KIN_KMBALD_GA, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         } else {
+            if (lv) launch_model<KIN_KMBALD, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+            else launch_model<KIN_KMBALD, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         }
          break;
    }
    EXA_HIP_CHECK(ctx, hipGetLastError());
