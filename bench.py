@@ -179,6 +179,7 @@ def main():
     barrier()
     t_model = max_over_ranks(time.perf_counter() - t0)
     kern_ms = max_over_ranks(m["kernel_ms"]) / args.steps
+    nfev = drv.nfev_hist()
     value = P_global * args.steps / t_model
     # ---- timed region 2: PCG iterations -----------------------------------------------------------------------------------
     drv.bench_pcg(max(2, args.pcg_iters // 10))   # warm-up
@@ -241,7 +242,10 @@ def main():
                                    f"{'partial' if args.assembly.upper() == 'PA' else 'element'}-assembly PCG", "elements": N ** 3,
                        "qpts": P_global, "decomposition": f"{world} block(s)"},
             "pcg_iters_per_s": pcg_it_s, "pcg_iters": pc["iters"], "pcg_ms_per_iter": pcg_ms / max(pc["iters"], 1),
-            "pcg_wall_s": t_pcg_wall, "nonconverged_points": m["failed"], "elastic_regime": elastic,
+            "pcg_wall_s": t_pcg_wall, "nonconverged_points": m["failed"],
+            "local_solver_evals": {"mean": float((nfev * np.arange(64)).sum() / max(nfev.sum(), 1)), "max": int(np.nonzero(nfev)[0].max()) if nfev.any() else 0,
+                                   "hist": {str(i): int(c) for i, c in enumerate(nfev) if c}, "note": "residual/Jacobian evaluations of the 8-unknown point solve per quadrature point (rank 0), last timed pass"},
+            "elastic_regime": elastic,
             "prepare_passes": {"passes": len(PREP_DTS), "wall_s": prep_s, "note": "the 10 kinematic passes through the elastic-plastic transition that bring the RVE to the benchmark state"},
             "roofline": {"kernel": f"k_model_setup<{'KM-DD' if 'kmdd' in args.model else 'Voce'}> (fused node gather + grad_calc + ExaCMech update + tangent)", "bound": "hbm",
                          "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS,

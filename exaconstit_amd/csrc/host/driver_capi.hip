@@ -108,6 +108,14 @@ void exa_driver_get_diagnostics(exa_driver* d, int64_t* out) {
    out[0] = d->sd->oper().model_fail_total; out[1] = d->sd->cg_not_converged; out[2] = d->sd->cg_indefinite_iters; out[3] = d->sd->last_cg_flag;
 }
 
+int exa_driver_nfev_hist(exa_driver* d, int* hist64, char* err, int errlen) {
+   try {
+      NonlinearMechOperator& op = d->sd->oper();
+      if (exa_model_nfev_hist(op.GetModel()->ctx(), op.matVars1.p, hist64, op.stream()) != EXA_OK) throw std::runtime_error(exa_last_error(op.GetModel()->ctx()));
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
 // ---- benchmark hooks --------------------------------------------------------------------------------------------------
 // Kinematically drive the RVE into the plastic regime: nodal velocity v = L0 x (+ seeded perturbation), `nsteps` constitutive
 // passes with state/coordinate updates and no equilibrium solve (SURVEY 8(d) kernel micro-benchmark).

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
                                                      const double* __restrict__ state0, double* __restrict__ stress1,
                                                      double* __restrict__ state1, double* __restrict__ cmat, int* __restrict__ fail,
                                                      const int kcap, int* __restrict__ tail, const int tail_mode) {
+   if (tail_mode && (int64_t)blockIdx.x * blockDim.x >= tail[0]) return;   // tail launch: its grid covers the worst case, blocks beyond the list leave before the table fill
    const int n = NFIX ? NFIX : n_rt;
    constexpr bool P2F = (NFIX == 27);   // triquadratic fused path: G holds the 3 x 6 one-dimensional tables, read through scalar loads
    extern __shared__ double sG[];   // (n,3,Q) shape table (not for P2F), then the per-thread stash

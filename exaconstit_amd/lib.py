@@ -152,6 +152,7 @@ exa_driver_get_avgs = _sig("exa_driver_get_avgs", C.c_int, C.c_void_p, C.c_int, 
 exa_driver_get_stats = _sig("exa_driver_get_stats", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
 exa_driver_get_timers = _sig("exa_driver_get_timers", None, C.c_void_p, C.POINTER(C.c_double))
 exa_driver_reset_timers = _sig("exa_driver_reset_timers", None, C.c_void_p)
+exa_driver_nfev_hist = _sig("exa_driver_nfev_hist", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_int)
 exa_driver_get_diagnostics = _sig("exa_driver_get_diagnostics", None, C.c_void_p, C.POINTER(C.c_int64))
 exa_driver_bench_prepare = _sig("exa_driver_bench_prepare", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_char_p, C.c_int)
 exa_driver_bench_model = _sig("exa_driver_bench_model", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
@@ -238,6 +239,13 @@ class Driver:
         import numpy as np
         dts = np.ascontiguousarray(dts, dtype=np.float64)
         self._chk(exa_driver_bench_prepare(self.h, len(dts) if advance else 0, dts.ctypes.data_as(C.POINTER(C.c_double)), perturb, self._err, 512))
+
+    def nfev_hist(self):
+        """Histogram (64 bins) of the local-solver evaluation counts of the last constitutive launch."""
+        import numpy as np
+        h = np.zeros(64, dtype=np.int32)
+        self._chk(exa_driver_nfev_hist(self.h, h.ctypes.data_as(C.POINTER(C.c_int)), self._err, 512))
+        return h
 
     def bench_model(self, steps):
         import numpy as np

@@ -50,6 +50,8 @@ void exa_driver_reset_timers(exa_driver* d);
  * library's ECMECH_FAIL; here Newton reports non-convergence), [1] PCG solves without convergence, [2] PCG iterations with
  * (Ad, d) < 0 (MFEM: "The operator is not positive definite"), [3] flag of the last PCG solve (1 ok, 2 max_iter, -1 (Ad, d) = 0). */
 void exa_driver_get_diagnostics(exa_driver* d, int64_t* out4);
+/* 64-bin histogram of the local-solver evaluation counts (ExaCMech's nFEval state variable) of the last constitutive launch */
+int exa_driver_nfev_hist(exa_driver* d, int* hist64, char* err, int errlen);
 int exa_driver_bench_prepare(exa_driver* d, int nsteps, const double* dts, double perturb, char* err, int errlen);
 int exa_driver_bench_model(exa_driver* d, int steps, double* out3, char* err, int errlen);
 int exa_driver_bench_pcg(exa_driver* d, int iters, double* out3, char* err, int errlen);
