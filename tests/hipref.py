@@ -44,6 +44,16 @@ def l_to_e(rve, L):
     return out.ravel()
 
 
+def e_to_l(rve, Ev):
+    """transpose of l_to_e: sums the element contributions (E, 3, n) into an L-vector (byNODES)"""
+    n, E, NN = rve["n"], rve["E"], rve["NN"]
+    conn = rve["conn"].reshape(E, n)
+    out = np.zeros(3 * NN)
+    for c in range(3):
+        np.add.at(out, conn + NN * c, np.asarray(Ev).reshape(E, 3, n)[:, c, :])
+    return out
+
+
 def velocity_field(rve, scale=1.0, seed=7):
     """Nodal velocity of a perturbed uniaxial tension: v = L0 x + noise (SURVEY 8(d) kernel micro-benchmark shape)."""
     rng = np.random.default_rng(seed)

@@ -585,6 +585,94 @@ def test_abi_error_behaviour(oracle):
     ctx.close()
 
 
+def _aos_to_eb64(a, E, Q, W):
+    """(E*Q, W) rows in the reference's point order -> [block of 64 elements][q][component][lane], zero padded"""
+    nb = (E + 63) // 64
+    full = np.zeros((nb * 64 * Q, W)); full[: E * Q] = np.asarray(a).reshape(E * Q, W)
+    return np.ascontiguousarray(full.reshape(nb, 64, Q, W).transpose(0, 2, 3, 1)).ravel()
+
+
+@pytest.mark.parametrize("name,xtal,kin,pkey,model", CASES)
+def test_default_product_path_matches_oracle(oracle, name, xtal, kin, pkey, model):
+    """The path the stand-alone driver and bench.py run by default - element-blocked quadrature functions, the fused L-vector constitutive
+    launch (node gather + Jacobians + update), the residual from L-vectors, and the geometry-recomputing action on compact tangent records,
+    partial and element assembly - compared DIRECTLY with the oracle point by point, every step from elastic to fully plastic (the other
+    layout tests compare this path with the reference-layout path; here there is no intermediate)."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 5, distort=0.15)      # E = 125: a partial last block of 64
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    props = _props(orc, pkey)
+    quats = hipref.random_quats(E)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    v_nodes = hipref.velocity_field(rve)
+    vel_e = hipref.l_to_e(rve, v_nodes)
+    hist = np.zeros(26); orc.lib().orc_hist_init(xtal, kin, orc._p(props), len(props), orc._p(hist))
+    sv0 = np.tile(np.concatenate([hist, [1.0, 0.0]]), P).reshape(P, 28); sv0[:, 9:13] = np.repeat(quats, Q, axis=0); sv0 = sv0.ravel()
+    s0 = np.zeros(6 * P)
+    ctxs = {}
+    for assembly in (L.EXA_ASSEMBLY_PA, L.EXA_ASSEMBLY_EA):
+        ctx = L.Context(model, props, 298.0, 1, E, assembly=assembly)
+        ctx.check(L.exa_set_quadrature_layout(ctx.h, L.EXA_QLAYOUT_EB64)); ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+        ctx.check(L.exa_set_tangent_form(ctx.h, L.EXA_TANGENT_DEV5_BULK))
+        if assembly == L.EXA_ASSEMBLY_EA: ctx.check(L.exa_set_ea_matrix_free(ctx.h, 1))
+        ctxs[assembly] = ctx
+    ctx = ctxs[L.EXA_ASSEMBLY_PA]
+    sz = lambda w: int(L.exa_qf_size(ctx.h, w))
+    x = rve["X"].copy()
+    xg = np.random.default_rng(5).standard_normal(3 * NN)
+    mask_np = (np.random.default_rng(6).random(3 * NN) < 0.1).astype(np.uint8)
+    keep = np.ones(28, bool); keep[3] = False
+    for step, dt in enumerate([0.005, 0.195, 0.1, 0.2, 0.4, 0.5, 1.0]):
+        x = x + v_nodes * dt
+        xe = hipref.l_to_e(rve, x)
+        J = np.zeros(9 * P); orc.lib().orc_jacobians(1, E, orc._p(xe), orc._p(J))
+        nf, s1, sv1, cm, vg = _orc_model_setup(orc, xtal, kin, props, rve, dt, J, vel_e, s0, sv0)
+        assert nf == 0
+        d_s0 = dev.up(_aos_to_eb64(s0, E, Q, 6)); d_sv0 = dev.up(_aos_to_eb64(sv0, E, Q, 28))
+        d_s1 = dev.zeros(sz(6)); d_sv1 = dev.zeros(sz(28)); d_cm = dev.zeros(sz(36)); d_J = dev.zeros(sz(9))
+        d_x = dev.up(x); d_v = dev.up(v_nodes)
+        ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(d_s0), ptr(d_sv0), ptr(d_s1), ptr(d_sv1), ptr(d_cm), ptr(d_J), None))
+        assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+        assert rel_l2(_eb64_to_aos(d_J, E, Q, 9).cpu().numpy().ravel(), J) < 1e-13
+        assert rel_l2(_eb64_to_aos(d_s1, E, Q, 6).cpu().numpy().ravel(), s1) < 1e-9, (name, step)
+        a = _eb64_to_aos(d_sv1, E, Q, 28).cpu().numpy()[:, keep]; b = sv1.reshape(P, 28)[:, keep]
+        for lo, hi in ((0, 3), (3, 8), (8, 12), (12, 13), (13, 25), (25, 27)):
+            assert rel_l2(a[:, lo:hi], b[:, lo:hi]) < 1e-8, (name, step, lo)
+        assert rel_l2(_eb64_to_aos(d_cm, E, Q, 36).cpu().numpy().ravel(), cm) < 1e-7, (name, step)
+        # residual F(sigma) from L-vectors against the oracle's AssemblePA + AddMultPA + E->L
+        dmat = np.zeros(9 * P); orc.lib().orc_assemble_pa(Q, E, orc._p(rve["W"]), orc._p(J), orc._p(s1), orc._p(dmat))
+        ye = np.zeros(3 * n * E); orc.lib().orc_add_mult_pa(Q, E, n, orc._p(rve["G"]), orc._p(dmat), orc._p(ye))
+        y_ref = hipref.e_to_l(rve, ye)
+        d_s1o = dev.up(_aos_to_eb64(s1, E, Q, 6))      # the oracle's stress: the integrator alone (nodal forces are differences of large numbers)
+        d_y = dev.zeros(3 * NN); ctx.check(L.exa_residual_lvec(ctx.h, ptr(d_J), ptr(d_s1o), ptr(d_y), None))
+        assert rel_l2(d_y.cpu().numpy(), y_ref) < 1e-11, (name, step)
+        # tangent action K x (masked rows and columns) on the oracle's tangent: PA chain and EA matrices of the oracle
+        C4 = np.zeros(81 * P); D4 = np.zeros(81 * P)
+        orc.lib().orc_transform_4d(C.c_int64(P), orc._p(cm), orc._p(C4))
+        orc.lib().orc_assemble_grad_pa(Q, E, C.c_double(dt), orc._p(rve["W"]), orc._p(J), orc._p(C4), orc._p(D4))
+        xm = xg * (1 - mask_np)
+        ke = np.zeros(3 * n * E); orc.lib().orc_add_mult_grad_pa(Q, E, n, orc._p(rve["G"]), orc._p(D4), orc._p(hipref.l_to_e(rve, xm)), orc._p(ke))
+        k_pa = hipref.e_to_l(rve, ke)      # (the action masks the input columns; the output rows are the caller's)
+        emat = np.zeros(9 * n * n * E)
+        orc.lib().orc_assemble_ea(Q, E, n, C.c_double(dt), orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(cm), orc._p(emat))
+        ke2 = np.zeros(3 * n * E); orc.lib().orc_ea_mult(E, n, orc._p(emat), orc._p(hipref.l_to_e(rve, xm)), orc._p(ke2))
+        k_ea = hipref.e_to_l(rve, ke2)
+        d_cm_o = dev.up(_aos_to_eb64(cm, E, Q, 36)); d_xg = dev.up(xg); d_mask = dev.up(mask_np)
+        for assembly, k_ref in ((L.EXA_ASSEMBLY_PA, k_pa), (L.EXA_ASSEMBLY_EA, k_ea)):
+            c2 = ctxs[assembly]
+            c2.check(L.exa_grad_setup(c2.h, dt, ptr(d_J), ptr(d_cm_o), None))
+            c2.check(L.exa_grad_set_coords(c2.h, ptr(d_x)))
+            d_k = dev.zeros(3 * NN); c2.check(L.exa_grad_apply_lvec(c2.h, ptr(d_xg), ptr(d_k), ptr(d_mask), None))
+            assert rel_l2(d_k.cpu().numpy(), k_ref) < 1e-11, (name, step, assembly)
+        s0, sv0 = s1, sv1
+    assert np.abs(sv0.reshape(P, 28)[:, 14:26]).sum(axis=1).min() > 0      # fully plastic at the end
+    for c in ctxs.values(): c.close()
+
+
 @pytest.mark.parametrize("model,pkey", [(0, "voce"), (2, "voce"), (5, "mts")])
 def test_compact_tangent_form(oracle, model, pkey):
     """EXA_TANGENT_DEV5_BULK: the tangents the constitutive kernel returns have the deviatoric-block + bulk form to round-off

@@ -50,7 +50,7 @@ def test_pa_equals_ea_equals_dense(oracle, p, cmat):
     assert rel_l2(d_pa, d_ea) < 1e-13
 
 
-@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("p", [1, 2, 3, 6])      # 6: the order the reference's own vector test runs at (test/mechanics_test.cpp:188)
 def test_pa_residual_equals_dense(oracle, p):
     orc = oracle
     rve = hipref.make_rve(orc, 2, p=p)
@@ -111,7 +111,7 @@ def _bbar_dense(rve, J, eDS, Cm, dt, e):
     return M
 
 
-@pytest.mark.parametrize("p", [1, 2])
+@pytest.mark.parametrize("p", [1, 2, 3])      # 3: the order of the reference's ICExaNLFIntegratorEATest (test/mechanics_test.cpp:471)
 def test_bbar_ea_and_residual(oracle, p):
     """ICExaNLFIntegratorEATest / ICExaNLFIntegratorPAVecTest (reference test/mechanics_test.cpp:468-746)."""
     orc = oracle
@@ -141,6 +141,24 @@ def test_bbar_ea_and_residual(oracle, p):
     orc.lib().orc_add_mult_pa_bbar(Q, E, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(eDS), orc._p(hyd), orc._p(y3))
     orc.lib().orc_element_vector(Q, E, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(hyd), orc._p(y4))
     assert rel_l2(y3, y4) < 1e-12
+
+
+def test_bbar_residual_order6(oracle):
+    """ICExaNLFIntegratorPAVecTest at the reference's own order (6, test/mechanics_test.cpp:630): matrix-free B-bar residual == dense one."""
+    orc = oracle
+    p = 6
+    rve = hipref.make_rve(orc, 2, p=p)
+    E, Q, n = rve["E"], rve["Q"], rve["n"]
+    P = E * Q
+    xe = hipref.l_to_e(rve, rve["X"])
+    J = np.zeros(9 * P); orc.lib().orc_jacobians(p, E, orc._p(xe), orc._p(J))
+    eDS = np.zeros(3 * n * E)
+    orc.lib().orc_element_eds(Q, E, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(eDS))
+    sig = np.ones(6 * P)
+    y1 = np.zeros(3 * n * E); y2 = np.zeros(3 * n * E)
+    orc.lib().orc_add_mult_pa_bbar(Q, E, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(eDS), orc._p(sig), orc._p(y1))
+    orc.lib().orc_element_vector_bbar(Q, E, n, orc._p(rve["W"]), orc._p(rve["G"]), orc._p(J), orc._p(eDS), orc._p(sig), orc._p(y2))
+    assert rel_l2(y1, y2) < 2e-14
 
 
 def test_bbar_nrls_case_runs(oracle):
