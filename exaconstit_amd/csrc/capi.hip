@@ -78,6 +78,7 @@ exa_ctx* exa_create(const exa_config* cfg, int* err) {
 
 void exa_destroy(exa_ctx* ctx) {
    if (!ctx) return;
+   (void)hipFree(ctx->n2e_off); (void)hipFree(ctx->n2e_idx); (void)hipFree(ctx->ev_det);
    (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->tail_dev); (void)hipFree(ctx->scratch_dev);
    (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->T1_dev); (void)hipFree(ctx->pa_c); (void)hipFree(ctx->tbuf);
    delete ctx;
@@ -230,6 +231,13 @@ int exa_grad_tangent_defect(exa_ctx* ctx, const double* C, double* defect_host, 
    return EXA_OK;
 }
 
+int exa_set_deterministic(exa_ctx* ctx, int on) {
+   if (!ctx) return EXA_ERR_ARG;
+   if (on && (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL))
+      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_set_deterministic: the ordered E->L sum is built for p = 1 full integration (fused L-vector kernels) and exa_restrict_transpose_add");
+   ctx->det = on != 0; return EXA_OK;
+}
+
 int exa_set_ea_matrix_free(exa_ctx* ctx, int on) {
    if (!ctx) return EXA_ERR_ARG;
    ctx->ea_matfree = on != 0; return EXA_OK;
@@ -312,6 +320,30 @@ int exa_restrict_transpose_add(exa_ctx* ctx, const double* Ev, double* L, exa_st
    return exa_launch_restrict_T(ctx, Ev, L, S(s));
 }
 
+}  // extern "C"
+// node -> (element, local node) table of the current connectivity, entries of a node in ascending element order (built once per
+// connectivity on the host: one device->host copy of the element table)
+int exa_det_prepare(exa_ctx* ctx) {
+   if (ctx->n2e_off && ctx->det_conn == ctx->conn && ctx->det_nnodes == ctx->nnodes) return EXA_OK;
+   if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "deterministic E->L: connectivity not set");
+   const size_t ne = (size_t)ctx->n * ctx->E;
+   if (ne >= (size_t)INT32_MAX) return fail(ctx, EXA_ERR_UNSUPPORTED, "deterministic E->L: element table too large for 32-bit entries");
+   std::vector<int32_t> conn(ne);
+   EXA_HIP_CHECK(ctx, hipMemcpy(conn.data(), ctx->conn, sizeof(int32_t) * ne, hipMemcpyDeviceToHost));
+   std::vector<int32_t> off((size_t)ctx->nnodes + 1, 0), idx(ne);
+   for (size_t k = 0; k < ne; k++) { if (conn[k] < 0 || conn[k] >= ctx->nnodes) return fail(ctx, EXA_ERR_ARG, "deterministic E->L: node index out of range"); off[(size_t)conn[k] + 1]++; }
+   for (int i = 0; i < ctx->nnodes; i++) off[(size_t)i + 1] += off[i];
+   { std::vector<int32_t> cur(off.begin(), off.end() - 1); for (size_t k = 0; k < ne; k++) idx[(size_t)cur[conn[k]]++] = (int32_t)k; }   // k = a + n e ascending -> element order
+   (void)hipFree(ctx->n2e_off); (void)hipFree(ctx->n2e_idx); ctx->n2e_off = nullptr; ctx->n2e_idx = nullptr;
+   EXA_HIP_CHECK(ctx, hipMalloc(&ctx->n2e_off, sizeof(int32_t) * off.size())); EXA_HIP_CHECK(ctx, hipMalloc(&ctx->n2e_idx, sizeof(int32_t) * ne));
+   EXA_HIP_CHECK(ctx, hipMemcpy(ctx->n2e_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
+   EXA_HIP_CHECK(ctx, hipMemcpy(ctx->n2e_idx, idx.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice));
+   if (!ctx->ev_det) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->ev_det, sizeof(double) * 24 * PA_BLK * (size_t)((ctx->E + PA_BLK - 1) / PA_BLK)));
+   ctx->det_conn = ctx->conn; ctx->det_nnodes = ctx->nnodes;
+   return EXA_OK;
+}
+extern "C" {
+
 // driver-internal variant: `gate` (nullable) is a device flag; a non-zero value turns the launch into a no-op so that a
 // PCG loop whose scalars live on the device can be enqueued without host synchronisation.
 int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, exa_stream s) {
@@ -321,6 +353,7 @@ int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const ui
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
       if (ctx->ea_matfree && ctx->n == 27) return exa_launch_mf_apply_p2(ctx, x, y, mask, gate, true, S(s));
       if (ea_from_records(ctx)) return exa_launch_grad_apply_p1(ctx, x, y, true, mask, gate, S(s), true);
+      if (ctx->det) return fail(ctx, EXA_ERR_UNSUPPORTED, "deterministic mode: the L-vector action of assembled element matrices scatters with atomics; use exa_set_ea_matrix_free or exa_grad_apply + exa_restrict_transpose_add");
       if (int rc = assemble_ea(ctx, S(s))) return rc;
       return ctx->ea_generic ? exa_launch_ea_apply_gen(ctx, x, y, true, mask, gate, S(s)) : exa_launch_ea_apply_p1(ctx, x, y, true, mask, gate, S(s));
    }

@@ -50,6 +50,8 @@ struct exa_ctx {
    double* pa_c = nullptr;                  // compact tangent records (25 + 1 per point) of the geometry-recomputing p = 1 action; allocated when the form is selected
    int tangent_form = 0;                    // EXA_TANGENT_*
    int pac_pairs = 0;                       // 16-byte pairs per point of the compact record: 13 (D, K) at p = 1, 18 (+ geometry) at p = 2
+   // deterministic E->L (exa_set_deterministic): node -> (element, local node) table in element order + per-element output scratch
+   int det = 0; int32_t* n2e_off = nullptr; int32_t* n2e_idx = nullptr; double* ev_det = nullptr; int det_nnodes = 0; const int32_t* det_conn = nullptr;
    const double* coords_lvec = nullptr;     // optional: nodal coordinates the Jacobians of exa_grad_setup came from (geometry recomputed in the apply)
    // status
    int* fail_count_dev = nullptr;

@@ -180,7 +180,7 @@ void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
       }
       EXA_HC(hipStreamSynchronize(s));
       g->barrier();
-      vk_unpack_add(ntot, idx_all_.p, rbuf_all_.p, y, s);
+      unpack(y, s);
       return;
    }
    nccl_check(rccl().GroupStart(), "ncclGroupStart");
@@ -189,7 +189,15 @@ void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
       nccl_check(rccl().Recv(rb(i), cnt(i), ncclDouble, part.nbrs[i].rank, (ncclComm_t)comm_, s), "ncclRecv");
    }
    nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
-   vk_unpack_add(ntot, idx_all_.p, rbuf_all_.p, y, s);
+   unpack(y, s);
+}
+
+// adds the received segments to y.  A dof on an edge or corner of the block occurs in several segments: one launch over all of them adds
+// with atomics in arbitrary order; in deterministic mode the segments are added one after the other (no dof twice within a segment)
+void Comm::unpack(double* y, hipStream_t s) {
+   if (!deterministic) { vk_unpack_add((int64_t)seg_off_.back(), idx_all_.p, rbuf_all_.p, y, s); return; }
+   for (size_t i = 0; i + 1 < seg_off_.size(); i++)
+      vk_unpack_add((int64_t)(seg_off_[i + 1] - seg_off_[i]), idx_all_.p + seg_off_[i], rbuf_all_.p + seg_off_[i], y, s);
 }
 
 // =====================================================================================================================
@@ -249,6 +257,11 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
       compact_tangent_ = !env_is("EXA_TANGENT_FORM", "full") && !ea_streamed && ((fast_p1_ && !env_is("EXA_APPLY_GEO", "off")) || part.p == 2);
    }
    if (compact_tangent_) abi_check(ctx_, exa_set_tangent_form(ctx_, EXA_TANGENT_DEV5_BULK), "exa_set_tangent_form");
+   // EXA_DETERMINISTIC=1: ordered E->L sums and halo additions instead of FP64 atomics: bit-reproducible residuals, CG iterates and results
+   if (const char* dm = std::getenv("EXA_DETERMINISTIC")) if (std::string(dm) == "1") {
+      abi_check(ctx_, exa_set_deterministic(ctx_, 1), "exa_set_deterministic");
+      comm_.deterministic = true;
+   }
    abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 and p = 2 paths (EXA_QLAYOUT=aos switches back for A/B runs)
    const char* ql = std::getenv("EXA_QLAYOUT");

@@ -35,8 +35,10 @@ class Comm {
    void halo_sum(const Partition& part, double* y, hipStream_t s);
    void setup_halo(const Partition& part);
    double max_over_ranks(double v);
+   bool deterministic = false;               // halo contributions added segment by segment (fixed order) instead of one atomic pass
    bool forced() const { return force_; }   // EXA_FORCE_RCCL=1: the one-rank communicator runs the multi-rank code paths and every RCCL call
  private:
+   void unpack(double* y, hipStream_t s);
    void loopback_reduce(double* dev, int n, int op, hipStream_t s);
    void* comm_ = nullptr; void* loop_ = nullptr; bool force_ = false;
    DevBuf<int32_t> idx_all_; DevBuf<double> sbuf_all_, rbuf_all_; std::vector<size_t> seg_off_{ 0 };   // concatenated neighbour segments

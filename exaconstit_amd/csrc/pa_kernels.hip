@@ -200,7 +200,7 @@ __global__ void k_tangent_defect(const int Q, const int64_t P, const double* __r
 template <bool LVEC, bool GEO, bool CMP = false, bool TRANS = false>
 __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const double* __restrict__ pa, const double* __restrict__ x, double* __restrict__ y,
                                                           const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
-                                                          const double* __restrict__ gate, const double* __restrict__ coords) {
+                                                          const double* __restrict__ gate, const double* __restrict__ coords, double* __restrict__ ev = nullptr) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
    if (e >= E) return;
    if (gate != nullptr && gate[0] != 0.0) return;   // device-side "solver already converged" flag
@@ -281,7 +281,12 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
 #pragma unroll
          for (int a = 0; a < 8; a++) Y[c][a] += G1(a, 0, q) * T[0][c] + G1(a, 1, q) * T[1][c] + G1(a, 2, q) * T[2][c];
    }
-   if (LVEC) {
+   if (LVEC && ev != nullptr) {   // deterministic mode: element outputs to the scratch ([block][c][a][lane]), summed per node by k_e2l_gather
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+         for (int a = 0; a < 8; a++) ev[(blk * 24 + c * 8 + a) * PA_BLK + lane] = Y[c][a];
+   } else if (LVEC) {
 #pragma unroll
       for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_diag_p1(const int E, const doub
 // fused AssemblePA + AddMultPA + scatter-add for p = 1
 template <bool LVEC, bool QB>
 __global__ __launch_bounds__(PA_BLK) void k_residual_p1(const int E, const double* __restrict__ W, const double* __restrict__ J, const double* __restrict__ S,
-                                                        double* __restrict__ y, const int32_t* __restrict__ conn, const int nnodes) {
+                                                        double* __restrict__ y, const int32_t* __restrict__ conn, const int nnodes, double* __restrict__ ev = nullptr) {
    const int64_t e = (int64_t)blockIdx.x * PA_BLK + threadIdx.x;
    if (e >= E) return;
    double Y[3][8];
@@ -361,7 +366,12 @@ __global__ __launch_bounds__(PA_BLK) void k_residual_p1(const int E, const doubl
 #pragma unroll
          for (int a = 0; a < 8; a++) Y[k][a] += G1(a, 0, q) * D[0][k] + G1(a, 1, q) * D[1][k] + G1(a, 2, q) * D[2][k];
    }
-   if (LVEC) {
+   if (LVEC && ev != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+         for (int a = 0; a < 8; a++) ev[((int64_t)blockIdx.x * 24 + c * 8 + a) * PA_BLK + threadIdx.x] = Y[c][a];
+   } else if (LVEC) {
 #pragma unroll
       for (int a = 0; a < 8; a++) {
          const int g = conn[a + 8 * e];
@@ -488,6 +498,29 @@ __global__ void k_restrict_T(const int n, const int E, const int nnodes, const i
    for (int c = 0; c < 3; c++) atomicAdd(&L[g + (int64_t)nnodes * c], Ev[a + n * (c + 3 * e)]);
 }
 
+// Deterministic E->L: node i adds the contributions of its elements in the fixed order of the node -> (element, local node) table
+// (ascending element index) instead of racing FP64 atomics: bit-reproducible L-vectors, hence bit-reproducible CG iterates.
+// BLOCKED: contributions in the [block of 64 elements][c][a][lane] scratch the fused p = 1 kernels write; otherwise an E-vector (n,3,E).
+template <bool BLOCKED>
+__global__ void k_e2l_gather(const int n, const int nnodes, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, const double* __restrict__ ev,
+                             double* __restrict__ y, const double* __restrict__ gate) {
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= nnodes) return;
+   if (gate != nullptr && gate[0] != 0.0) return;
+   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+   for (int k = off[i]; k < off[i + 1]; k++) {
+      const int code = idx[k]; const int64_t e = code / n; const int a = code % n;
+      if (BLOCKED) {
+         const int64_t b = ((e >> 6) * 24 + a) * PA_BLK + (e & 63);
+         s0 += ev[b]; s1 += ev[b + 8 * PA_BLK]; s2 += ev[b + 16 * PA_BLK];
+      } else {
+         const int64_t b = a + (int64_t)n * 3 * e;
+         s0 += ev[b]; s1 += ev[b + n]; s2 += ev[b + 2 * n];
+      }
+   }
+   y[i] += s0; y[i + (int64_t)nnodes] += s1; y[i + 2 * (int64_t)nnodes] += s2;
+}
+
 // partial sums of W detJ * qf(c) and of W detJ: one block -> (vdim + 1) partials
 template <bool QB>
 __global__ void k_vol_avg_partial(const int Q, const int64_t P, const int vdim, const double* __restrict__ W, const double* __restrict__ J,
@@ -542,13 +575,22 @@ int exa_launch_residual_apply_from(exa_ctx* ctx, const double* D, double* Y, hip
    hipLaunchKernelGGL(k_residual_apply, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, D, Y);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
+int exa_det_prepare(exa_ctx* ctx);   // capi.hip: builds the node -> element table on first use
+static int det_gather(exa_ctx* ctx, double* y, const double* gate, hipStream_t s) {
+   hipLaunchKernelGGL(k_e2l_gather<true>, dim3(nblk(ctx->nnodes, 256)), dim3(256), 0, s, ctx->n, ctx->nnodes, ctx->n2e_off, ctx->n2e_idx, ctx->ev_det, y, gate);
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
 int exa_launch_residual_p1(exa_ctx* ctx, const double* J, const double* S, double* y, bool lvec, hipStream_t s) {
    const unsigned nb = nblk(ctx->E, PA_BLK);
-   if (lvec && ctx->qblk) hipLaunchKernelGGL((k_residual_p1<true, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
-   else if (lvec) hipLaunchKernelGGL((k_residual_p1<true, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
+   double* ev = nullptr;
+   if (lvec && ctx->det) { if (int rc = exa_det_prepare(ctx)) return rc; ev = ctx->ev_det; }
+   if (lvec && ctx->qblk) hipLaunchKernelGGL((k_residual_p1<true, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes, ev);
+   else if (lvec) hipLaunchKernelGGL((k_residual_p1<true, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes, ev);
    else if (ctx->qblk) hipLaunchKernelGGL((k_residual_p1<false, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
    else hipLaunchKernelGGL((k_residual_p1<false, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
-   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   if (ev) return det_gather(ctx, y, nullptr, s);
+   return EXA_OK;
 }
 int exa_launch_grad_setup_pa(exa_ctx* ctx, double dt, const double* J, const double* C, hipStream_t s) {
    const dim3 grid(nblk(ctx->E, PA_BLK));
@@ -564,14 +606,18 @@ int exa_launch_grad_setup_pa(exa_ctx* ctx, double dt, const double* J, const dou
 }
 int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s, bool trans) {
    const unsigned nb = nblk(ctx->E, PA_BLK);
-#define GA_LAUNCH(G, CM, T, REC, CRD) hipLaunchKernelGGL((k_grad_apply_p1<true, G, CM, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, REC, x, y, ctx->conn, ctx->nnodes, mask, gate, CRD)
+   double* ev = nullptr;
+   if (lvec && ctx->det) { if (int rc = exa_det_prepare(ctx)) return rc; ev = ctx->ev_det; }
+#define GA_LAUNCH(G, CM, T, REC, CRD) hipLaunchKernelGGL((k_grad_apply_p1<true, G, CM, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, REC, x, y, ctx->conn, ctx->nnodes, mask, gate, CRD, ev)
    const double* none = nullptr;
    if (lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) GA_LAUNCH(true, true, false, ctx->pa_c, ctx->coords_lvec);   // D or D^T in the record
    else if (lvec && ctx->coords_lvec) { if (trans) GA_LAUNCH(true, false, true, ctx->pa, ctx->coords_lvec); else GA_LAUNCH(true, false, false, ctx->pa, ctx->coords_lvec); }
    else if (lvec) { if (trans) GA_LAUNCH(false, false, true, ctx->pa, none); else GA_LAUNCH(false, false, false, ctx->pa, none); }
    else hipLaunchKernelGGL((k_grad_apply_p1<false, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask, gate, none);
 #undef GA_LAUNCH
-   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   if (ev) return det_gather(ctx, y, gate, s);
+   return EXA_OK;
 }
 // max over the points of the relative deviation of C from the compact tangent form; result as the bit pattern of a double in *out_dev
 int exa_launch_tangent_defect(exa_ctx* ctx, const double* C, unsigned long long* out_dev, hipStream_t s) {
@@ -607,6 +653,11 @@ int exa_launch_restrict(exa_ctx* ctx, const double* L, double* Ev, hipStream_t s
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_restrict_T(exa_ctx* ctx, const double* Ev, double* L, hipStream_t s) {
+   if (ctx->det) {
+      if (int rc = exa_det_prepare(ctx)) return rc;
+      hipLaunchKernelGGL(k_e2l_gather<false>, dim3(nblk(ctx->nnodes, 256)), dim3(256), 0, s, ctx->n, ctx->nnodes, ctx->n2e_off, ctx->n2e_idx, Ev, L, (const double*)nullptr);
+      EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+   }
    hipLaunchKernelGGL(k_restrict_T, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), 0, s, ctx->n, ctx->E, ctx->nnodes, ctx->conn, Ev, L);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }

@@ -76,6 +76,7 @@ exa_restrict = _sig("exa_restrict", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_restrict_transpose_add = _sig("exa_restrict_transpose_add", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_grad_apply_lvec = _sig("exa_grad_apply_lvec", C.c_int, C.c_void_p, dptr, dptr, dptr, C.c_void_p)
 exa_set_tangent_form = _sig("exa_set_tangent_form", C.c_int, C.c_void_p, C.c_int)
+exa_set_deterministic = _sig("exa_set_deterministic", C.c_int, C.c_void_p, C.c_int)
 exa_grad_tangent_defect = _sig("exa_grad_tangent_defect", C.c_int, C.c_void_p, dptr, C.POINTER(C.c_double), C.c_void_p)
 EXA_TANGENT_FULL, EXA_TANGENT_DEV5_BULK = 0, 1
 exa_set_ea_matrix_free = _sig("exa_set_ea_matrix_free", C.c_int, C.c_void_p, C.c_int)

@@ -158,6 +158,12 @@ int exa_grad_tangent_defect(exa_ctx* ctx, const double* ddsdde_dev, double* defe
  * contexts keep the assembled path.  The matrices themselves are assembled on the first call that needs them (exa_grad_apply on
  * E-vectors, exa_grad_diagonal, exa_grad_get_ea).  Default: off. */
 int exa_set_ea_matrix_free(exa_ctx* ctx, int on);
+/* Bit-reproducible E->L sums (reference: mfem::ElementRestriction::MultTranspose; the fused kernels here scatter with FP64 atomics, whose
+ * order - and therefore the last bits of the L-vector, and from there every CG iterate - changes from run to run).  With `on` != 0
+ * exa_residual_lvec, exa_grad_apply_lvec (partial assembly and element assembly from the point records) and exa_restrict_transpose_add
+ * write per-element outputs and add them node by node in ascending element order (node -> element table built once per connectivity).
+ * Costs one extra write + read of the element outputs (24 doubles per element).  p = 1 full-integration contexts; default off. */
+int exa_set_deterministic(exa_ctx* ctx, int on);
 /* fused AssemblePA + AddMultPA + E->L: y_L += B^T sigma (p = 1 full integration; p = 2 full integration and B-bar, where the
  * element-average gradients are refreshed from the Jacobians first: ICExaNLFIntegrator::AssemblePA + AddMultPA) */
 int exa_residual_lvec(exa_ctx* ctx, const double* jacobian_dev, const double* stress1_dev, double* y_lvec_dev, exa_stream s);

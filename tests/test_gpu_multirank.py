@@ -84,3 +84,20 @@ def test_file_mesh_partitioned_matches_single_rank(oracle, tmp_path, mesh, nrank
     for s, st in _run_ranks(L, toml, nranks, 4, tmp_path / f"r{nranks}"):
         assert np.max(np.abs(s - ref[0])) < 1e-9 * np.abs(ref[0]).max()
         assert list(st[0]) == list(ref[1][0])
+
+
+def test_deterministic_mode_is_bit_reproducible(oracle, tmp_path, monkeypatch):
+    """EXA_DETERMINISTIC=1 (ordered E->L sums and halo additions): two runs of the same partitioned case give the same bits - averages,
+    Newton and Krylov counts - on 1 and on 4 ranks; and the answers are the atomic path's to round-off."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    toml = os.path.join(orc.REFDATA, "voce_pa.toml")
+    base = _run_ranks(L, toml, 1, 4, tmp_path / "base")[0]
+    monkeypatch.setenv("EXA_DETERMINISTIC", "1")
+    for nranks in (1, 4):
+        a = _run_ranks(L, toml, nranks, 4, tmp_path / f"a{nranks}")
+        b = _run_ranks(L, toml, nranks, 4, tmp_path / f"b{nranks}")
+        for (sa, sta), (sb, stb) in zip(a, b):
+            assert np.array_equal(sa, sb)
+            assert all(list(x) == list(y) for x, y in zip(sta, stb))
+        assert np.max(np.abs(a[0][0] - base[0])) < 1e-9 * np.abs(base[0]).max()

@@ -673,6 +673,58 @@ def test_default_product_path_matches_oracle(oracle, name, xtal, kin, pkey, mode
     for c in ctxs.values(): c.close()
 
 
+@pytest.mark.parametrize("assembly", [0, 1])
+def test_deterministic_e_to_l(oracle, assembly):
+    """exa_set_deterministic: the ordered E->L sum gives the same residual / action / transpose-restriction as the atomic scatter to
+    round-off, and the SAME BITS on every repetition (which the atomic scatter does not promise)."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 9, distort=0.15)      # 729 elements: 12 blocks of 64, the last one partial
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    rng = np.random.default_rng(11)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    xg = dev.up(rng.standard_normal(3 * NN)); mask = dev.up((rng.random(3 * NN) < 0.1).astype(np.uint8))
+    ev = dev.up(rng.standard_normal(3 * n * E))
+    out = {}
+    for det in (0, 1):
+        ctx = L.Context(0, _props(orc, "voce"), 298.0, 1, E, assembly=assembly)
+        ctx.check(L.exa_set_quadrature_layout(ctx.h, L.EXA_QLAYOUT_EB64)); ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+        ctx.check(L.exa_set_tangent_form(ctx.h, L.EXA_TANGENT_DEV5_BULK))
+        if assembly == 1: ctx.check(L.exa_set_ea_matrix_free(ctx.h, 1))
+        ctx.check(L.exa_set_deterministic(ctx.h, det))
+        sz = lambda w: int(L.exa_qf_size(ctx.h, w))
+        sv = [dev.zeros(sz(28)), dev.zeros(sz(28))]; sg = [dev.zeros(sz(6)), dev.zeros(sz(6))]; cm = dev.zeros(sz(36)); J = dev.zeros(sz(9))
+        d_q = dev.up(hipref.random_quats(E).ravel())
+        ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(d_q), None))
+        d_x = dev.up(rve["X"]); d_v = dev.up(hipref.velocity_field(rve, scale=2.0))
+        for dt in (0.1, 0.5):
+            d_x += dt * d_v
+            ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(sg[0]), ptr(sv[0]), ptr(sg[1]), ptr(sv[1]), ptr(cm), ptr(J), None))
+            sv.reverse(); sg.reverse()
+        ctx.check(L.exa_grad_setup(ctx.h, 0.5, ptr(J), ptr(cm), None)); ctx.check(L.exa_grad_set_coords(ctx.h, ptr(d_x)))
+        reps = []
+        for rep in range(3):
+            y_r = dev.zeros(3 * NN); ctx.check(L.exa_residual_lvec(ctx.h, ptr(J), ptr(sg[0]), ptr(y_r), None))
+            y_a = dev.zeros(3 * NN); ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(xg), ptr(y_a), ptr(mask), None))
+            y_t = dev.zeros(3 * NN); ctx.check(L.exa_restrict_transpose_add(ctx.h, ptr(ev), ptr(y_t), None))
+            reps.append((y_r.clone(), y_a.clone(), y_t.clone()))
+        if det:
+            for r in reps[1:]:
+                for a, b in zip(reps[0], r):
+                    assert torch.equal(a, b)
+        out[det] = [t.cpu().numpy() for t in reps[0]]
+        ctx.close()
+    for a, b in zip(out[0], out[1]):
+        assert rel_l2(b, a) < 1e-14
+    # not offered where the scatter is not built for it
+    c2 = L.Context(0, _props(orc, "voce"), 298.0, 2, 8)
+    assert L.exa_set_deterministic(c2.h, 1) == -4
+    c2.close()
+
+
 @pytest.mark.parametrize("model,pkey", [(0, "voce"), (2, "voce"), (5, "mts")])
 def test_compact_tangent_form(oracle, model, pkey):
     """EXA_TANGENT_DEV5_BULK: the tangents the constitutive kernel returns have the deviatoric-block + bulk form to round-off
