@@ -233,8 +233,6 @@ int exa_grad_tangent_defect(exa_ctx* ctx, const double* C, double* defect_host, 
 
 int exa_set_deterministic(exa_ctx* ctx, int on) {
    if (!ctx) return EXA_ERR_ARG;
-   if (on && (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL))
-      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_set_deterministic: the ordered E->L sum is built for p = 1 full integration (fused L-vector kernels) and exa_restrict_transpose_add");
    ctx->det = on != 0; return EXA_OK;
 }
 
@@ -350,6 +348,8 @@ int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const ui
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec: connectivity not set");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec called before exa_grad_setup");
+   if (ctx->det && (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL))
+      return fail(ctx, EXA_ERR_UNSUPPORTED, "deterministic mode: the fused L-vector action is ordered for p = 1 full integration only; use exa_restrict + exa_grad_apply + exa_restrict_transpose_add");
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
       if (ctx->ea_matfree && ctx->n == 27) return exa_launch_mf_apply_p2(ctx, x, y, mask, gate, true, S(s));
       if (ea_from_records(ctx)) return exa_launch_grad_apply_p1(ctx, x, y, true, mask, gate, S(s), true);
@@ -374,6 +374,7 @@ int exa_grad_apply_lvec(exa_ctx* ctx, const double* x, double* y, const uint8_t*
 int exa_residual_lvec(exa_ctx* ctx, const double* J, const double* stress1, double* y, exa_stream s) {
    if (!ctx || !J || !stress1 || !y) return fail(ctx, EXA_ERR_ARG, "exa_residual_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_residual_lvec: connectivity not set");
+   if (ctx->det && ctx->p == 2) return fail(ctx, EXA_ERR_UNSUPPORTED, "deterministic mode: the fused p = 2 residual scatters with atomics; use exa_residual_setup/apply + exa_restrict_transpose_add");
    if (ctx->p == 2) {
       if (ctx->cfg.integ == EXA_INTEG_BBAR && !ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * PA_BLK * (size_t)((ctx->E + PA_BLK - 1) / PA_BLK)));
       return exa_launch_residual_p2(ctx, J, stress1, y, S(s));

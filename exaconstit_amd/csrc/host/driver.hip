@@ -237,6 +237,11 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    nn_ = part.NN; nd_ = 3 * nn_; E_ = part.E; npe_ = part.n;
    fast_p1_ = (part.p == 1 && !bbar);          // fused L-vector kernels exist for p = 1 full integration
    lvec_grad_ = fast_p1_ || opt.assembly == Assembly::EA || part.p == 2;   // p = 2: matrix-free action from the point records (PA and EA)
+   // EXA_DETERMINISTIC=1: ordered E->L sums and halo additions instead of FP64 atomics: bit-reproducible residuals, CG iterates and results.
+   // The fused kernels are ordered for p = 1 full integration; the other contexts take the E-vector entries + the ordered E->L sum.
+   const bool det = std::getenv("EXA_DETERMINISTIC") && std::string(std::getenv("EXA_DETERMINISTIC")) == "1";
+   const bool det_unfused = det && !fast_p1_;
+   if (det_unfused) lvec_grad_ = false;
    fused_setup_ = std::getenv("EXA_UNFUSED_SETUP") == nullptr;
    // tail split of the constitutive launch (include/exaconstit_hip.h): EXA_NEWTON_CAP=off | <K> | unset (chosen from the evaluation-count histogram of the previous launch)
    // The controller runs for the Kocks-Mecking family only: for the Voce kernels the model never finds a paying cap in steady state and
@@ -249,23 +254,19 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.5 : 4.0;
    // element assembly: the element matrices are 2x (p = 1) to 5x (p = 2) the bytes of the records they are built from, so the action is
    // computed from the records and the matrices only exist if somebody asks for them (diagonal, export); EXA_EA_ASSEMBLED=1 streams them instead
-   if (opt.assembly == Assembly::EA && (part.p == 2 || fast_p1_) && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1"))
+   if (!det_unfused && opt.assembly == Assembly::EA && (part.p == 2 || fast_p1_) && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1"))
       abi_check(ctx_, exa_set_ea_matrix_free(ctx_, 1), "exa_set_ea_matrix_free");
    {  // compact tangent records wherever a record-based action runs: p = 1 PA / matrix-free EA with the geometry recomputed, p = 2 matrix-free
       auto env_is = [](const char* k, const char* v) { const char* e = std::getenv(k); return e && std::string(e) == v; };
       const bool ea_streamed = opt.assembly == Assembly::EA && env_is("EXA_EA_ASSEMBLED", "1");
-      compact_tangent_ = !env_is("EXA_TANGENT_FORM", "full") && !ea_streamed && ((fast_p1_ && !env_is("EXA_APPLY_GEO", "off")) || part.p == 2);
+      compact_tangent_ = !det_unfused && !env_is("EXA_TANGENT_FORM", "full") && !ea_streamed && ((fast_p1_ && !env_is("EXA_APPLY_GEO", "off")) || part.p == 2);
    }
    if (compact_tangent_) abi_check(ctx_, exa_set_tangent_form(ctx_, EXA_TANGENT_DEV5_BULK), "exa_set_tangent_form");
-   // EXA_DETERMINISTIC=1: ordered E->L sums and halo additions instead of FP64 atomics: bit-reproducible residuals, CG iterates and results
-   if (const char* dm = std::getenv("EXA_DETERMINISTIC")) if (std::string(dm) == "1") {
-      abi_check(ctx_, exa_set_deterministic(ctx_, 1), "exa_set_deterministic");
-      comm_.deterministic = true;
-   }
+   if (det) { abi_check(ctx_, exa_set_deterministic(ctx_, 1), "exa_set_deterministic"); comm_.deterministic = true; }
    abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 and p = 2 paths (EXA_QLAYOUT=aos switches back for A/B runs)
    const char* ql = std::getenv("EXA_QLAYOUT");
-   lvec_resid_ = fast_p1_ || part.p == 2;      // fused L-vector residual kernels (p = 1 full integration; p = 2 plain and B-bar)
+   lvec_resid_ = fast_p1_ || (part.p == 2 && !det);      // fused L-vector residual kernels (p = 1 full integration; p = 2 plain and B-bar)
    if (lvec_resid_ && !(ql && std::string(ql) == "aos")) abi_check(ctx_, exa_set_quadrature_layout(ctx_, EXA_QLAYOUT_EB64), "exa_set_quadrature_layout");
    auto qf = [&](int vdim) { return (size_t)exa_qf_size(ctx_, vdim); };
    conn.upload(part.conn); abi_check(ctx_, exa_set_connectivity(ctx_, conn.p, nn_), "exa_set_connectivity");

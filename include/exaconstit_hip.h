@@ -162,7 +162,9 @@ int exa_set_ea_matrix_free(exa_ctx* ctx, int on);
  * order - and therefore the last bits of the L-vector, and from there every CG iterate - changes from run to run).  With `on` != 0
  * exa_residual_lvec, exa_grad_apply_lvec (partial assembly and element assembly from the point records) and exa_restrict_transpose_add
  * write per-element outputs and add them node by node in ascending element order (node -> element table built once per connectivity).
- * Costs one extra write + read of the element outputs (24 doubles per element).  p = 1 full-integration contexts; default off. */
+ * Costs one extra write + read of the element outputs (24 doubles per element).  The fused L-vector entries are ordered for p = 1 full
+ * integration; in other contexts they return EXA_ERR_UNSUPPORTED while the mode is on and the E-vector entries + exa_restrict_transpose_add
+ * are the reproducible route (what the stand-alone driver then takes).  Default off. */
 int exa_set_deterministic(exa_ctx* ctx, int on);
 /* fused AssemblePA + AddMultPA + E->L: y_L += B^T sigma (p = 1 full integration; p = 2 full integration and B-bar, where the
  * element-average gradients are refreshed from the Jacobians first: ICExaNLFIntegrator::AssemblePA + AddMultPA) */

@@ -719,9 +719,12 @@ def test_deterministic_e_to_l(oracle, assembly):
         ctx.close()
     for a, b in zip(out[0], out[1]):
         assert rel_l2(b, a) < 1e-14
-    # not offered where the scatter is not built for it
+    # other contexts: the fused L-vector entries refuse while the mode is on (the E-vector entries + exa_restrict_transpose_add are the ordered route)
     c2 = L.Context(0, _props(orc, "voce"), 298.0, 2, 8)
-    assert L.exa_set_deterministic(c2.h, 1) == -4
+    assert L.exa_set_deterministic(c2.h, 1) == 0
+    d_c2 = torch.zeros(27 * 8, dtype=torch.int32, device=dev.dev); c2.check(L.exa_set_connectivity(c2.h, ptr(d_c2), 125))
+    z = dev.zeros(8 * 27 * 9)
+    assert L.exa_residual_lvec(c2.h, ptr(z), ptr(z), ptr(z), None) == -4
     c2.close()
 
 
