@@ -42,17 +42,27 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    if (ecmdev::kin_is_km(KIN) && threadIdx.x < 8 * ecmdev::NSLIP) sG[pqo + threadIdx.x] = (&ecmdev::PQ_TAB[0][0])[threadIdx.x];
    if (!P2F || ecmdev::kin_is_km(KIN)) __syncthreads();
    int q; int64_t e;
+#ifndef EXA_MODEL_XCD_REMAP
+#define EXA_MODEL_XCD_REMAP 0
+#endif
+   // workgroups are dealt round-robin to the 8 XCDs; remapped, an XCD works on one contiguous eighth of the element blocks (node gathers of
+   // neighbouring blocks then hit the same L2)
+   int64_t bidx = blockIdx.x;
+   if (EXA_MODEL_XCD_REMAP && !tail_mode) {
+      const unsigned nb = gridDim.x, qq = nb >> 3, r = nb & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+      bidx = x < r ? (int64_t)x * (qq + 1) + i : (int64_t)r * (qq + 1) + (int64_t)(x - r) * qq + i;
+   }
    if (tail_mode) {   // dense pass over the points the capped launch handed over: thread t owns point tail[1 + t]
       const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
       if (t >= tail[0]) return;
       const int64_t ipt = tail[1 + t];
       q = (int)(ipt % Q); e = ipt / Q;
    } else if (QB) {   // wave = (block of 64 elements, q); lane = element
-      const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+      const int64_t gw = bidx * (blockDim.x >> 6) + (threadIdx.x >> 6);
       q = (int)(gw % Q); e = (gw / Q) * 64 + (threadIdx.x & 63);
       if (e * Q >= P) return;
    } else {
-      const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      const int64_t ip = bidx * blockDim.x + threadIdx.x;
       if (ip >= P) return;
       q = (int)(ip % Q); e = ip / Q;
    }
