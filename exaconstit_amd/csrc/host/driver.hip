@@ -465,6 +465,8 @@ static void load_case_data(const ExaOptions& opt, const Partition& part, std::ve
    }
 }
 
+SystemDriver::~SystemDriver() { if (cg_graph_) (void)hipGraphExecDestroy((hipGraphExec_t)cg_graph_); }
+
 SystemDriver::SystemDriver(const ExaOptions& opt, int rank, int nranks, const void* uid) : opt_(opt) {
    comm.init(rank, nranks, uid);
    if (opt.mesh_type == "auto") {
@@ -491,6 +493,7 @@ void SystemDriver::init(const std::vector<double>& props, const std::vector<doub
    v_sol.alloc(nd); v_sol.zero(); r_.alloc(nd); c_.alloc(nd); xt_.alloc(nd); cg_r_.alloc(nd); cg_z_.alloc(nd); cg_d_.alloc(nd); ess_val_.alloc(nd);
    ess_host_.assign(nd, 0); ess_val_host_.assign(nd, 0.0);
    dt_class = opt_.dt;
+   if (const char* g = std::getenv("EXA_PCG_GRAPH")) { if (std::string(g) == "0") cg_graph_max_dofs = 0; else if (std::string(g) == "all") cg_graph_max_dofs = INT64_MAX; }
 }
 
 // BCManager::updateBCData + UpdateEssTDofs; component codes reference src/BCData.cpp:25-116
@@ -607,25 +610,43 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    // inside the action, with its scatter skipping the essential rows, was measured too: the pass it saves costs what it adds to the
    // action kernel, +0.8 %.)
    const bool one = comm.nranks == 1;
-   while (!done) {
-      for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) {
-         // identity preconditioner + fused loop: z == r is never materialised (the un-fused path reads z in k_cg_step2)
-         const bool ident = fused && op.precond == Precond::IDENTITY;
-         vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, ident, fused && one, opt_.krylov_iter, s);
-         if (!(fused && one)) { comm.allreduce_sum(S + 8, 1, s); vk_cg_beta(S, opt_.krylov_iter, s); }
-         if (fused) {
-            vk_cg_step2z(nd, S, cg_z_.p, cg_r_.p, cg_d_.p, ident, s);      // d = z + beta d; z = 0
-            op.GradMult(cg_d_.p, cg_z_.p, true, S + 6, true, true);       // z += K d (input masked in the kernel, output mask folded into the dot)
-            vk_mask_dot(nd, nn, op.weight.p, op.ess_mask.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s, one ? S : nullptr);
-            if (!one) { comm.allreduce_sum(S + 8, 1, s); vk_cg_den(S, s); }
-         } else {
-            vk_cg_step2(nd, S, cg_z_.p, cg_d_.p, s);
-            op.GradMult(cg_d_.p, cg_z_.p, true, S + 6);
-            vk_dot(nd, nn, op.weight.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s);
-            comm.allreduce_sum(S + 8, 1, s);
-            vk_cg_den(S, s);
-         }
+   auto iteration = [&]() {
+      // identity preconditioner + fused loop: z == r is never materialised (the un-fused path reads z in k_cg_step2)
+      const bool ident = fused && op.precond == Precond::IDENTITY;
+      vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, ident, fused && one, opt_.krylov_iter, s);
+      if (!(fused && one)) { comm.allreduce_sum(S + 8, 1, s); vk_cg_beta(S, opt_.krylov_iter, s); }
+      if (fused) {
+         vk_cg_step2z(nd, S, cg_z_.p, cg_r_.p, cg_d_.p, ident, s);      // d = z + beta d; z = 0
+         op.GradMult(cg_d_.p, cg_z_.p, true, S + 6, true, true);       // z += K d (input masked in the kernel, output mask folded into the dot)
+         vk_mask_dot(nd, nn, op.weight.p, op.ess_mask.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s, one ? S : nullptr);
+         if (!one) { comm.allreduce_sum(S + 8, 1, s); vk_cg_den(S, s); }
+      } else {
+         vk_cg_step2(nd, S, cg_z_.p, cg_d_.p, s);
+         op.GradMult(cg_d_.p, cg_z_.p, true, S + 6);
+         vk_dot(nd, nn, op.weight.p, cg_d_.p, cg_z_.p, S + 6, op.partial.p, S + 8, s);
+         comm.allreduce_sum(S + 8, 1, s);
+         vk_cg_den(S, s);
       }
+   };
+   // Small systems are launch-bound (16^3: 6 kernels of 2-3 us per iteration): the cg_check_every iterations between two polls of the
+   // done-flag are captured once in a hipGraph and replayed.  Every kernel of an iteration takes its scalars from the device array and is
+   // a no-op once the flag is set or max_iter is reached, so the graph always holds the full chunk.  One rank, fused loop only (no
+   // collective inside the capture); above graph_max_dofs the kernels are long enough to hide their launches (measured).
+   const bool use_graph = one && fused && !comm.forced() && nd <= cg_graph_max_dofs && cg_check_every > 1;
+   if (use_graph && (!cg_graph_ || cg_graph_x_ != x || cg_graph_key_ != (int)op.precond)) {
+      if (cg_graph_) { (void)hipGraphExecDestroy((hipGraphExec_t)cg_graph_); cg_graph_ = nullptr; }
+      hipGraph_t g = nullptr;
+      EXA_HC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      for (int k = 0; k < cg_check_every; k++) iteration();
+      EXA_HC(hipStreamEndCapture(s, &g));
+      hipGraphExec_t ge = nullptr;
+      EXA_HC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      cg_graph_ = ge; cg_graph_x_ = x; cg_graph_key_ = (int)op.precond;
+   }
+   while (!done) {
+      if (use_graph) { EXA_HC(hipGraphLaunch((hipGraphExec_t)cg_graph_, s)); launched += cg_check_every; }
+      else for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) iteration();
       EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 11, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
       done = (hS[6] != 0.0) || launched >= opt_.krylov_iter;
    }

@@ -131,6 +131,7 @@ class NonlinearMechOperator {
 class SystemDriver {
  public:
    SystemDriver(const ExaOptions& opt, int rank, int nranks, const void* nccl_uid);
+   ~SystemDriver();
    // synthetic RVE without files (bench): N^3 elements, one grain per element, seeded orientations
    SystemDriver(const ExaOptions& opt, const std::vector<double>& props, const std::vector<double>& quats_per_global_elem, int rank, int nranks, const void* nccl_uid);
    void UpdateEssBdr(const BCEntry& bc);
@@ -153,6 +154,7 @@ class SystemDriver {
    bool write_files = true; std::string out_dir = ".";
    Precond precond = Precond::IDENTITY;
    int cg_check_every = 16;
+   int64_t cg_graph_max_dofs = 3 * 33 * 33 * 33;   // PCG iterations replayed from a hipGraph up to this many local dofs (32^3 elements at p = 1: +9 % at 16^3, +3 % at 32^3, a loss from 48^3 on); EXA_PCG_GRAPH=0 | all
    // linear-solver diagnostics (MFEM's CGSolver prints these): flag of the last solve (1 converged, 2 max_iter, -1 den == 0),
    // number of solves that did not converge, iterations that saw (Ad, d) < 0
    int last_cg_flag = 1; int64_t cg_not_converged = 0, cg_indefinite_iters = 0;
@@ -167,6 +169,7 @@ class SystemDriver {
    std::vector<uint8_t> ess_host_; std::vector<double> ess_val_host_;
    DevBuf<uint8_t> vel_mask_, vg_mask_; bool have_vel_ = false, have_vgrad_ = false; double vgrad_[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
    double last_dt_ = 0.0;
+   void* cg_graph_ = nullptr; const double* cg_graph_x_ = nullptr; int cg_graph_key_ = -1;   // captured PCG chunk (hipGraphExec_t) and what it was captured for
 };
 
 }  // namespace exa_host
