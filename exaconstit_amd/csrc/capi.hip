@@ -137,6 +137,7 @@ int exa_model_status(exa_ctx* ctx, exa_stream s) {
 
 int exa_set_newton_cap(exa_ctx* ctx, int max_evals) {
    if (!ctx || (max_evals != 0 && max_evals < 2)) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_cap: 0 (off) or >= 2");
+   if (max_evals && ctx->P >= (int64_t)INT32_MAX) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_cap: the deferred-point list holds 32-bit point ids (P < 2^31)");
    ctx->newton_cap = max_evals; return EXA_OK;
 }
 int exa_model_nfev_hist(exa_ctx* ctx, const double* state, int* hist64_host, exa_stream s) {

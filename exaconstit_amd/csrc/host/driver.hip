@@ -465,7 +465,7 @@ static void load_case_data(const ExaOptions& opt, const Partition& part, std::ve
    }
 }
 
-SystemDriver::~SystemDriver() { if (cg_graph_) (void)hipGraphExecDestroy((hipGraphExec_t)cg_graph_); }
+SystemDriver::~SystemDriver() { drop_cg_graph(); }
 
 SystemDriver::SystemDriver(const ExaOptions& opt, int rank, int nranks, const void* uid) : opt_(opt) {
    comm.init(rank, nranks, uid);
@@ -579,7 +579,22 @@ int SystemDriver::CGSolveSingleReduction(const double* b, double* x) {
    op.timers.t_krylov_ms += ms; op.timers.krylov_iters += iters;
    last_cg_flag = (int)hS[6]; cg_indefinite_iters += (int64_t)hS[10];
    if (hS[6] != 1.0) cg_not_converged++;
+   report_cg(hS, iters);
    return iters;
+}
+
+// what MFEM prints (CGSolver::Mult): breakdown, indefinite operator, no convergence within max_iter
+void SystemDriver::report_cg(const double* hS, int iters) const {
+   if (comm.rank == 0 && (verbose || std::getenv("EXA_VERBOSE"))) {
+      if (hS[10] > 0.0) std::cerr << "PCG: The operator is not positive definite. (Ad, d) < 0 in " << (int)hS[10] << " iteration(s)\n";
+      if (hS[6] == -1.0) std::cerr << "PCG: (Ad, d) = 0, stopping after " << iters << " iterations\n";
+      else if (hS[6] != 1.0) std::cerr << "PCG: No convergence! (" << iters << " iterations)\n";
+   }
+}
+
+void SystemDriver::drop_cg_graph() {
+   if (cg_graph_) { (void)hipGraphExecDestroy((hipGraphExec_t)cg_graph_); cg_graph_ = nullptr; }
+   cg_graph_x_ = nullptr; cg_graph_key_ = -1;
 }
 
 // device PCG (MFEM CGSolver::Mult with iterative_mode = false); all scalars stay on the device, the host only polls the
@@ -632,17 +647,25 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    // done-flag are captured once in a hipGraph and replayed.  Every kernel of an iteration takes its scalars from the device array and is
    // a no-op once the flag is set or max_iter is reached, so the graph always holds the full chunk.  One rank, fused loop only (no
    // collective inside the capture); above graph_max_dofs the kernels are long enough to hide their launches (measured).
-   const bool use_graph = one && fused && !comm.forced() && nd <= cg_graph_max_dofs && cg_check_every > 1;
-   if (use_graph && (!cg_graph_ || cg_graph_x_ != x || cg_graph_key_ != (int)op.precond)) {
-      if (cg_graph_) { (void)hipGraphExecDestroy((hipGraphExec_t)cg_graph_); cg_graph_ = nullptr; }
-      hipGraph_t g = nullptr;
+   // The capture bakes in every kernel argument: the solution pointer, the preconditioner variant, the iteration cap (an argument of
+   // k_cg_step1 / the reductions) and the chunk length - all of them are part of the key.
+   const int64_t graph_key = ((int64_t)op.precond << 48) ^ ((int64_t)cg_check_every << 32) ^ (int64_t)opt_.krylov_iter;
+   bool use_graph = one && fused && !comm.forced() && nd <= cg_graph_max_dofs && cg_check_every > 1;
+   if (use_graph && (!cg_graph_ || cg_graph_x_ != x || cg_graph_key_ != graph_key)) {
+      drop_cg_graph();
+      // whatever happens between begin and end, the stream must leave capture mode and the graph must not leak
+      hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; std::string cap_err;
       EXA_HC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      for (int k = 0; k < cg_check_every; k++) iteration();
-      EXA_HC(hipStreamEndCapture(s, &g));
-      hipGraphExec_t ge = nullptr;
-      EXA_HC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(g);
-      cg_graph_ = ge; cg_graph_x_ = x; cg_graph_key_ = (int)op.precond;
+      try { for (int k = 0; k < cg_check_every; k++) iteration(); } catch (const std::exception& e) { cap_err = e.what(); }
+      const hipError_t ec = hipStreamEndCapture(s, &g);
+      if (cap_err.empty() && ec == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+         cg_graph_ = ge; cg_graph_x_ = x; cg_graph_key_ = graph_key;
+      } else {
+         (void)hipGetLastError();   // clear the sticky capture error; the plain launch loop below does the work
+         use_graph = false; cg_graph_max_dofs = 0;
+         if (comm.rank == 0) std::cerr << "PCG: hipGraph capture failed (" << (cap_err.empty() ? "capture/instantiate" : cap_err) << "), using stream launches\n";
+      }
+      if (g) (void)hipGraphDestroy(g);
    }
    while (!done) {
       if (use_graph) { EXA_HC(hipGraphLaunch((hipGraphExec_t)cg_graph_, s)); launched += cg_check_every; }
@@ -657,11 +680,7 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    // what MFEM prints (CGSolver::Mult): breakdown, indefinite operator, no convergence within max_iter
    last_cg_flag = (int)hS[6]; cg_indefinite_iters += (int64_t)hS[10];
    if (hS[6] != 1.0) cg_not_converged++;
-   if (comm.rank == 0 && (verbose || std::getenv("EXA_VERBOSE"))) {
-      if (hS[10] > 0.0) std::cerr << "PCG: The operator is not positive definite. (Ad, d) < 0 in " << (int)hS[10] << " iteration(s)\n";
-      if (hS[6] == -1.0) std::cerr << "PCG: (Ad, d) = 0, stopping after " << iters << " iterations\n";
-      else if (hS[6] != 1.0) std::cerr << "PCG: No convergence! (" << iters << " iterations)\n";
-   }
+   report_cg(hS, iters);
    return iters;
 }
 

@@ -145,6 +145,8 @@ class SystemDriver {
    bool NewtonSolve(double* x, SolverStats& st);
    int CGSolve(const double* b, double* x);   // device PCG, returns iterations
    int CGSolveSingleReduction(const double* b, double* x);   // more than one rank: one fused 16-byte all-reduce per iteration
+   void drop_cg_graph();                      // forget the captured PCG chunk (its solution buffer is about to go away)
+   void report_cg(const double* hS, int iters) const;   // MFEM CGSolver::Mult diagnostics (verbose / EXA_VERBOSE)
    NonlinearMechOperator& oper() { return *oper_; }
    const ExaOptions& options() const { return opt_; }
    std::vector<double> avg_stress, avg_def_grad, avg_pl_work, avg_dp_tensor;   // one row per completed step (rank 0 view, all ranks identical)
@@ -169,7 +171,7 @@ class SystemDriver {
    std::vector<uint8_t> ess_host_; std::vector<double> ess_val_host_;
    DevBuf<uint8_t> vel_mask_, vg_mask_; bool have_vel_ = false, have_vgrad_ = false; double vgrad_[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
    double last_dt_ = 0.0;
-   void* cg_graph_ = nullptr; const double* cg_graph_x_ = nullptr; int cg_graph_key_ = -1;   // captured PCG chunk (hipGraphExec_t) and what it was captured for
+   void* cg_graph_ = nullptr; const double* cg_graph_x_ = nullptr; int64_t cg_graph_key_ = -1;   // captured PCG chunk (hipGraphExec_t) and what it was captured for
 };
 
 }  // namespace exa_host

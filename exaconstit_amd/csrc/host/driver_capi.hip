@@ -184,6 +184,7 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out, char* err, int e
       const int it = sd.CGSolve(r.p, c.p);
       out[0] = op.timers.t_krylov_ms - t0; out[1] = it;
       o.krylov_rel = rel; o.krylov_abs = ab; o.krylov_iter = mi;
+      sd.drop_cg_graph();   // the captured chunk refers to the local solution buffer c
       hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1));
       EXA_HC(hipEventRecord(e0, s));
       for (int i = 0; i < iters; i++) exa_grad_apply_lvec(op.GetModel()->ctx(), r.p, c.p, op.ess_mask.p, s);

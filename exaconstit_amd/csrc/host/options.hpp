@@ -177,7 +177,6 @@ struct ExaOptions {
          auto_dt_fname = d.str("Time.Auto.auto_dt_file", "auto_dt_out.txt");
          if (changing) throw std::runtime_error("Automatic time stepping is currently not compatible with changing boundary conditions");   // src/option_parser.cpp:509-511
          if (dt_scale < 0.0 || dt_scale > 1.0) throw std::runtime_error("dt_scale for auto time stepping needs to be between 0 and 1.");
-         if (dt_scale < 0.0 || dt_scale > 1.0) throw std::runtime_error("dt_scale for auto time stepping needs to be between 0 and 1.");
          nsteps = (int)std::ceil(t_final / dt_min);   // reference src/mechanics_driver.cpp:212
       } else { dt = d.num("Time.Fixed.dt", 1.0); t_final = d.num("Time.Fixed.t_final", 1.0); nsteps = (int)std::ceil(t_final / dt - 1e-9); }
       avg_stress_fname = d.str("Visualizations.avg_stress_fname", "avg_stress.txt");

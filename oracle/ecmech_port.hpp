@@ -345,7 +345,7 @@ inline void mts_dG(const Model& m, double c_e, double t_frac, double& exp_arg, d
 
 // Kocks-Mecking balanced thermally-activated (w) + drag-limited (r) kinetics ("kinetics_mtswr_d")
 inline void kmbald_gdot(const Model& m, const KinVals& kv, double tau, double& gdot, double& dgdot_dtau) {
-   static const double gdot_w_pl_scaling = std::getenv("ORC_PLS") ? std::atof(std::getenv("ORC_PLS")) : 10.0;
+   static const double gdot_w_pl_scaling = 10.0;
    gdot = 0; dgdot_dtau = 0;
    if (tau == 0.0) return;
    // FCC ("Kin_FCC_B"): athermal threshold tau_a, thermal barrier g.  BCC ("Kin_BCC_A", withGAthermal): athermal
