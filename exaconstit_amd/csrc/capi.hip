@@ -5,6 +5,7 @@
 #include <cstdio>
 
 int exa_launch_model_setup(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, hipStream_t);
+int exa_launch_model_setup_rec(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
 int exa_launch_init_state(exa_ctx*, double*, const double*, const double*, hipStream_t);
 int exa_launch_nfev_hist(exa_ctx*, const double*, int*, hipStream_t);
 int exa_launch_calc_dp(exa_ctx*, const double*, double*, hipStream_t);
@@ -125,6 +126,25 @@ int exa_model_setup_lvec(exa_ctx* ctx, double dt, const double* x_lvec, const do
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec: call exa_set_connectivity first");
    if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec: dt must be positive");
    return exa_launch_model_setup(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, ddsdde, S(s));
+}
+
+int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* x_lvec, const double* v_lvec, const double* stress0, const double* state0,
+                                 double* stress1, double* state1, double* J_out, exa_stream s) {
+   if (!ctx || !x_lvec || !v_lvec || !stress0 || !state0 || !stress1 || !state1 || !J_out) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: null pointer");
+   if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec_records: call exa_set_connectivity first");
+   if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: dt must be positive");
+   if (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL || !ctx->qblk || ctx->tangent_form != EXA_TANGENT_DEV5_BULK ||
+       !(ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree))
+      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_model_setup_lvec_records: needs p = 1 full integration, the element-blocked layout, the compact tangent form and PA or matrix-free EA");
+   if (ctx->pa_c && ctx->pac_pairs != PAC_PAIRS) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec_records: compact records of another shape exist");
+   if (!ctx->pa_c) {
+      ctx->pac_pairs = PAC_PAIRS;
+      EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa_c, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 2 * PAC_PAIRS * PA_BLK * sizeof(double)));
+      EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa_c, 0, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 2 * PAC_PAIRS * PA_BLK * sizeof(double), S(s)));
+   }
+   const int rc = exa_launch_model_setup_rec(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, S(s));
+   if (rc == EXA_OK) { ctx->have_grad = true; ctx->emat_valid = false; ctx->grad_records_only = true; }
+   return rc;
 }
 
 int exa_model_status(exa_ctx* ctx, exa_stream s) {
@@ -255,6 +275,7 @@ int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, ex
    }
    int rc = exa_launch_grad_setup_pa(ctx, dt, J, C, S(s));
    if (rc) return rc;
+   ctx->grad_records_only = false;
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
       const bool bbar = ctx->cfg.integ == EXA_INTEG_BBAR;
       ctx->ea_generic = bbar || ctx->p != 1;
@@ -275,6 +296,7 @@ int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, ex
 int exa_grad_apply(exa_ctx* ctx, const double* x, double* y, exa_stream s) {
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply: null pointer");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply called before exa_grad_setup");
+   if (ctx->grad_records_only) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply: the gradient data are the compact records of exa_model_setup_lvec_records; call exa_grad_setup for the full records");
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
       if (int rc = assemble_ea(ctx, S(s))) return rc;
       return ctx->ea_generic ? exa_launch_ea_apply_gen(ctx, x, y, false, nullptr, nullptr, S(s)) : exa_launch_ea_apply_p1(ctx, x, y, false, nullptr, nullptr, S(s));
@@ -286,6 +308,7 @@ int exa_grad_apply(exa_ctx* ctx, const double* x, double* y, exa_stream s) {
 int exa_grad_diagonal(exa_ctx* ctx, double* d, exa_stream s) {
    if (!ctx || !d) return fail(ctx, EXA_ERR_ARG, "exa_grad_diagonal: null pointer");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_diagonal called before exa_grad_setup");
+   if (ctx->grad_records_only) return fail(ctx, EXA_ERR_STATE, "exa_grad_diagonal: the gradient data are the compact records of exa_model_setup_lvec_records; call exa_grad_setup for the full records");
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
       if (int rc = assemble_ea(ctx, S(s))) return rc;
       return ctx->ea_generic ? exa_launch_ea_diag_gen(ctx, d, S(s)) : exa_launch_ea_diag_p1(ctx, d, S(s));
@@ -297,6 +320,7 @@ int exa_grad_diagonal(exa_ctx* ctx, double* d, exa_stream s) {
 int exa_grad_get_ea(exa_ctx* ctx, double* emat, exa_stream s) {
    if (!ctx || !emat) return fail(ctx, EXA_ERR_ARG, "exa_grad_get_ea: null pointer");
    if (!ctx->have_grad || ctx->cfg.assembly != EXA_ASSEMBLY_EA) return fail(ctx, EXA_ERR_STATE, "exa_grad_get_ea: no element matrices assembled");
+   if (ctx->grad_records_only) return fail(ctx, EXA_ERR_STATE, "exa_grad_get_ea: the gradient data are the compact records of exa_model_setup_lvec_records; call exa_grad_setup first");
    if (int rc = assemble_ea(ctx, S(s))) return rc;
    return ctx->ea_generic ? exa_launch_ea_export_gen(ctx, emat, S(s)) : exa_launch_ea_export_p1(ctx, emat, S(s));
 }
@@ -349,6 +373,7 @@ int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const ui
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec: connectivity not set");
    if (!ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec called before exa_grad_setup");
+   if (ctx->grad_records_only && !ctx->coords_lvec) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec: name the nodal coordinates with exa_grad_set_coords (the compact records hold no geometry)");
    if (ctx->det && (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL))
       return fail(ctx, EXA_ERR_UNSUPPORTED, "deterministic mode: the fused L-vector action is ordered for p = 1 full integration only; use exa_restrict + exa_grad_apply + exa_restrict_transpose_add");
    if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {

@@ -449,12 +449,12 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #endif
 constexpr int ST_EN = 0, ST_DN = 5, ST_WN = 10, ST_XS = 13, ST_CD = 21, ST_SLOTS = 38;   // ST_XS: restore copy of the unknowns; ST_CD: parking slots
 constexpr int ST_NCD = ST_SLOTS - ST_CD;
-constexpr int CD_DSM = 0, CD_SOLD = 5, CD_QN = 10, CD_VOLD = 14, CD_VNEW = 15, CD_ENEW = 16, CD_DEFF = 17, CD_BULK = 18, CD_HU = 19;
+constexpr int CD_DSM = 0, CD_SOLD = 5, CD_QN = 10, CD_VOLD = 14, CD_VNEW = 15, CD_ENEW = 16, CD_DEFF = 17, CD_BULK = 18, CD_HU = 19, CD_TSC = 20;
 #define ECM_ST(p, slot) (p)[(slot) * ECM_STASH_STRIDE]
 // compiler-only barrier: what was parked must be re-loaded later instead of being kept alive in registers
 #define ECM_PARK_BARRIER() asm volatile("" ::: "memory")
 // parking slot c (compile-time): the first ST_NCD live in the LDS stash, the rest in the point's tangent slot in global memory
-#define ECM_CD(c) (*(((c) < ST_NCD) ? &ECM_ST(st, ST_CD + (((c) < ST_NCD) ? (c) : 0)) : &cold[(c) * QS]))
+#define ECM_CD(c) (*(((c) < ST_NCD) ? &ECM_ST(st, ST_CD + (((c) < ST_NCD) ? (c) : 0)) : &cold[(((c) < ST_NCD) ? 0 : (c) - ST_NCD) * CSTR]))
 
 // ------------------------------------------------------------------------------------------------------------
 // the point problem: unknowns x = (delta e / E_SCALE, xi / R_SCALE).  e is the library's strain STATE = a_V * E with a_V = detV^(1/3)
@@ -929,11 +929,17 @@ ECM_DI double norm8(const double v[8]) { double s = 0; for (int i = 0; i < 8; i+
 // ------------------------------------------------------------------------------------------------------------
 // QS: distance (in doubles) between consecutive values of one point in the state / stress / tangent arrays: 1 for the reference's
 // AoS quadrature functions, 64 for the element-blocked layout (exa_internal.hpp, QView)
-template <int KIN, int QS>
+// REC: instead of the 36 tangent entries the point's COMPACT GRADIENT RECORD is written (exa_internal.hpp, PAC_PAIRS): the 5 x 5 block the
+// tangent is built from, D = D55 / dt, and the bulk term K, both times tsc = dt W_q / detJ - what AssembleGradPA + the projection of
+// k_grad_setup_pa<.., CMP> would produce from the 36 entries (reference src/mechanics_integrators.cpp:331-414), without the round trip.
+// cmat then points at the lane's first 16-byte pair of the record ([13 pairs][64 lanes][2]); trd stores D^T (element-assembly contexts).
+template <int KIN, int QS, bool REC = false>
 ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const double* __restrict__ sv0, const double* __restrict__ s0,
                         double* __restrict__ sv1, double* __restrict__ s1, double* __restrict__ cmat, double* st, const int kcap,
-                        const double* pq_lds = nullptr) {
-   double* cold = cmat;
+                        const double* pq_lds = nullptr, const double tsc = 0.0, const bool trd = false) {
+   // parking area for the cold values that do not fit the LDS stash: the point's own output slot (written last)
+   constexpr int CSTR = REC ? 128 : QS;
+   double* cold = REC ? cmat : cmat + ST_NCD * QS;
    Prob pb; pb.st = st; pb.gs = QS; pb.pqt = pq_lds;
    pb.dt_ri = 1.0 / dt;
    {
@@ -967,6 +973,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       for (int i = 0; i < 3; i++) ECM_ST(st, ST_WN + i) = Cn[i] * w_sm[0] + Cn[3 + i] * w_sm[1] + Cn[6 + i] * w_sm[2];
       for (int i = 0; i < 4; i++) ECM_CD(CD_QN + i) = qn[i];
       ECM_CD(CD_VOLD) = vOld; ECM_CD(CD_VNEW) = vNew; ECM_CD(CD_ENEW) = eNew; ECM_CD(CD_DEFF) = dEff; ECM_CD(CD_BULK) = bulkNew; ECM_CD(CD_HU) = h_u;
+      if (REC) ECM_CD(CD_TSC) = tsc;
       double adots_ref;
       if (kin_is_km(KIN)) {
          const double sq = sqrt(h_u);
@@ -1192,6 +1199,26 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       for (int k = 0; k < 5; k++)
 #pragma unroll
          for (int c = 0; c < 5; c++) { double v = 0; for (int l = 0; l < 5; l++) v += Q5[k][l] * Llat[l][c]; T1[k][c] = v; }
+      if constexpr (REC) {
+         const double rsc = ECM_CD(CD_TSC);
+         const double dsc = rsc * pb.dt_ri * (okT ? 1.0 : 0.0);
+         double Dm[26];
+#pragma unroll
+         for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) { double v = 0; for (int l = 0; l < 5; l++) v += T1[k][l] * Q5[c][l]; Dm[k + 5 * c] = v * dsc; }
+         if (trd) {
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+               for (int c = k + 1; c < 5; c++) { const double v = Dm[k + 5 * c]; Dm[k + 5 * c] = Dm[c + 5 * k]; Dm[c + 5 * k] = v; }
+         }
+         Dm[25] = bulkNew * rsc;
+         double2* rc = reinterpret_cast<double2*>(cmat);
+#pragma unroll
+         for (int pr = 0; pr < 13; pr++) rc[pr * 64] = make_double2(Dm[2 * pr], Dm[2 * pr + 1]);
+         return (conv && ok) ? 0 : 1;
+      }
       const double dti = pb.dt_ri * (okT ? 1.0 : 0.0);
 #pragma unroll
       for (int k = 0; k < 5; k++) {

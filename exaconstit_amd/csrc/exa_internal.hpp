@@ -45,6 +45,7 @@ struct exa_ctx {
    bool ea_matfree = false, emat_valid = false;   // EA, p = 2: L-vector action computed from the point records, matrices assembled on demand
    bool qblk = false;                       // quadrature functions in the element-blocked layout (see QView below)
    bool have_resid = false, have_grad = false;
+   bool grad_records_only = false;          // gradient data = compact records written by the constitutive launch: no 46-double records, no element matrices
    // L-vector support
    const int32_t* conn = nullptr; int nnodes = 0;
    double* pa_c = nullptr;                  // compact tangent records (25 + 1 per point) of the geometry-recomputing p = 1 action; allocated when the form is selected

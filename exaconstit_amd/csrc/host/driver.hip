@@ -211,11 +211,15 @@ void ExaCMechModel::ModelSetup(const double* jacobian, const double* vel_evec, h
 void ExaCMechModel::ModelSetupLVec(const double* x_lvec, const double* v_lvec, double* jacobian_out, hipStream_t s) {
    abi_check(ctx_, exa_model_setup_lvec(ctx_, dt_, x_lvec, v_lvec, stress0_->p, matVars0_->p, stress1_->p, matVars1_->p, matGrad_->p, jacobian_out, s), "exa_model_setup_lvec");
 }
+void ExaCMechModel::ModelSetupLVecRecords(const double* x_lvec, const double* v_lvec, double* jacobian_out, hipStream_t s) {
+   abi_check(ctx_, exa_model_setup_lvec_records(ctx_, dt_, x_lvec, v_lvec, stress0_->p, matVars0_->p, stress1_->p, matVars1_->p, jacobian_out, s), "exa_model_setup_lvec_records");
+}
 void ExaCMechModel::calcDpMat(double* dp, hipStream_t s) const { abi_check(ctx_, exa_calc_dp(ctx_, matVars1_->p, dp, s), "exa_calc_dp"); }
 
 // =====================================================================================================================
 // NonlinearMechOperator
 // =====================================================================================================================
+static bool env_is_off(const char* k) { const char* e = std::getenv(k); return e && std::string(e) == "off"; }
 static int model_id(const ExaOptions& o) {
    const bool bcc = o.xtal == XtalType::BCC;
    switch (o.slip) {
@@ -262,6 +266,11 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
       compact_tangent_ = !det_unfused && !env_is("EXA_TANGENT_FORM", "full") && !ea_streamed && ((fast_p1_ && !env_is("EXA_APPLY_GEO", "off")) || part.p == 2);
    }
    if (compact_tangent_) abi_check(ctx_, exa_set_tangent_form(ctx_, EXA_TANGENT_DEV5_BULK), "exa_set_tangent_form");
+   // Gradient records straight from the constitutive launch (p = 1, compact form, identity "Jacobi" of the reference): no tangent field, no
+   // defect check, no AssembleGradPA pass per Newton iteration.  EXA_TANGENT_RECORDS=off keeps the tangent field + exa_grad_setup (A/B switch);
+   // true Jacobi needs the 46-double records for the diagonal and takes that route as well (SetPrecond).
+   records_setup_ = fast_p1_ && compact_tangent_ && fused_setup_ && !det && !env_is_off("EXA_TANGENT_RECORDS") &&
+                    !(std::getenv("EXA_QLAYOUT") && std::string(std::getenv("EXA_QLAYOUT")) == "aos");
    if (det) { abi_check(ctx_, exa_set_deterministic(ctx_, 1), "exa_set_deterministic"); comm_.deterministic = true; }
    abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 and p = 2 paths (EXA_QLAYOUT=aos switches back for A/B runs)
@@ -273,14 +282,17 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    x_ref.upload(part.X); x_beg.upload(part.X); x_cur.upload(part.X);
    weight.upload(part.weight);
    el_x.alloc(3 * (size_t)npe_ * E_); el_v.alloc(3 * (size_t)npe_ * E_); el_y_.alloc(3 * (size_t)npe_ * E_); el_jac.alloc(qf(9));
-   stress0.alloc(qf(6)); stress1.alloc(qf(6)); matVars0.alloc(qf(28)); matVars1.alloc(qf(28)); matGrad.alloc(qf(36));
-   stress0.zero(); stress1.zero(); matVars1.zero(); matGrad.zero();
+   stress0.alloc(qf(6)); stress1.alloc(qf(6)); matVars0.alloc(qf(28)); matVars1.alloc(qf(28));
+   if (!records_setup_) { matGrad.alloc(qf(36)); matGrad.zero(); }   // (allocated on demand if the records route is left, see SetPrecond)
+   stress0.zero(); stress1.zero(); matVars1.zero();
    diag.alloc(nd_); dinv.alloc(nd_); tmp_l_.alloc(nd_); tmp_r_.alloc(nd_); el_x2_.alloc(3 * (size_t)npe_ * E_); ess_mask.alloc(nd_); ess_mask.zero();
    partial.alloc(DOT_BLOCKS * 4); scal.alloc(16); scal.zero();
    { DevBuf<double> q; q.upload(quats_per_elem); abi_check(ctx_, exa_init_state(ctx_, matVars0.p, q.p, stream_), "exa_init_state"); EXA_HC(hipStreamSynchronize(stream_)); }
    model_.reset(new ExaCMechModel(ctx_, &stress0, &stress1, &matGrad, &matVars0, &matVars1));
    comm_.setup_halo(part);
 }
+
+void NonlinearMechOperator::ensure_mat_grad() { if (matGrad.n == 0) { matGrad.alloc((size_t)exa_qf_size(ctx_, 36)); matGrad.zero(stream_); } }
 
 NonlinearMechOperator::~NonlinearMechOperator() { exa_destroy(ctx_); (void)hipEventDestroy(ev0_); (void)hipEventDestroy(ev1_); (void)hipStreamDestroy(stream_); }
 
@@ -323,8 +335,10 @@ void NonlinearMechOperator::Setup(const double* k) {
    if (upd_crds) vk_update_coords(nd_, x_beg.p, k, dt_, x_cur.p, stream_);   // ExaModel::UpdateEndCoords (halo copies stay consistent)
    ProfRegion prof("ecmech_kernel");   // reference: CALI_MARK_BEGIN("ecmech_kernel"), src/mechanics_ecmech.cpp:237
    EXA_HC(hipEventRecord(ev0_, stream_));
-   if (fused_setup_) model_->ModelSetupLVec(x_cur.p, k, el_jac.p, stream_);   // L->E of x and v + SetupJacobianTerms inside the constitutive launch
+   if (use_records()) model_->ModelSetupLVecRecords(x_cur.p, k, el_jac.p, stream_);   // ... and AssembleGradPA: the launch writes the action's point records
+   else if (fused_setup_) { ensure_mat_grad(); model_->ModelSetupLVec(x_cur.p, k, el_jac.p, stream_); }   // L->E of x and v + SetupJacobianTerms inside the constitutive launch
    else {
+      ensure_mat_grad();
       abi_check(ctx_, exa_restrict(ctx_, x_cur.p, el_x.p, stream_), "exa_restrict");
       abi_check(ctx_, exa_jacobians(ctx_, el_x.p, el_jac.p, stream_), "exa_jacobians");   // SetupJacobianTerms
       abi_check(ctx_, exa_restrict(ctx_, k, el_v.p, stream_), "exa_restrict");
@@ -362,6 +376,11 @@ void NonlinearMechOperator::ResidualAction(double* y) {
 void NonlinearMechOperator::Mult(const double* k, double* y) { Setup<true>(k); ResidualAction(y); }
 
 void NonlinearMechOperator::GetGradient() {
+   if (use_records()) {   // the constitutive launch of the last residual evaluation wrote the records of this state; the action recomputes the geometry from x_cur
+      abi_check(ctx_, exa_grad_set_coords(ctx_, x_cur.p), "exa_grad_set_coords");
+      vk_jacobi_setup(nd_, ess_mask.p, diag.p, 1, dinv.p, stream_);
+      return;
+   }
    // compact tangent form of the p = 1 PA action (include/exaconstit_hip.h): valid for ExaCMech tangents; verified on the data of
    // every call (one pass over the tangent field, one 8-byte read-back per Newton iteration) and dropped for good if it ever fails
    if (compact_tangent_) {

@@ -64,6 +64,8 @@ class ExaCMechModel {
    void ModelSetup(const double* jacobian, const double* vel_evec, hipStream_t s);
    // the same with the operator's L->E restrictions and Jacobian refresh fused in (writes the Jacobians)
    void ModelSetupLVec(const double* x_lvec, const double* v_lvec, double* jacobian_out, hipStream_t s);
+   // ... and with AssembleGradPA fused in too: writes the compact gradient records instead of the tangent field (p = 1 fast path)
+   void ModelSetupLVecRecords(const double* x_lvec, const double* v_lvec, double* jacobian_out, hipStream_t s);
    void UpdateModelVars() {}
    void UpdateStress() { stress0_->swap(*stress1_); }        // reference src/mechanics_model.cpp:435-438
    void UpdateStateVars() { matVars0_->swap(*matVars1_); }   // reference src/mechanics_model.cpp:440-443
@@ -123,6 +125,9 @@ class NonlinearMechOperator {
    exa_ctx* ctx_ = nullptr; std::unique_ptr<ExaCMechModel> model_;
    hipStream_t stream_ = nullptr; hipEvent_t ev0_, ev1_;
    int nn_, nd_, E_, npe_ = 8; double dt_ = 1.0;
+   bool records_setup_ = false;   // gradient records written by the constitutive launch (p = 1 fast path, identity preconditioner)
+   bool use_records() const { return records_setup_ && precond == Precond::IDENTITY; }
+   void ensure_mat_grad();
    bool fast_p1_ = true, lvec_grad_ = true, fused_setup_ = true; bool lvec_resid_ = false; bool compact_tangent_ = false;
    bool cap_auto_ = true; int newton_cap_ = 0; double tail_cost_ = 4.0;
    DevBuf<double> tmp_l_, tmp_r_, el_y_, el_x2_;

@@ -23,14 +23,18 @@ using namespace ecmdev;
 // trips instead of one dependent index->value chain per node); NFIX = 0: run-time n.
 // QB: quadrature functions (J, stress, state, tangent) in the element-blocked layout; then a wave is (64 consecutive elements, one
 // point index q) so that every per-value access of the wave is one contiguous 512-byte row.
-template <int KIN, bool LVEC, int NFIX, bool QB>
+// REC (fused p = 1 launch of the stand-alone driver): cmat is the buffer of compact gradient records and the launch writes, instead of the
+// 36 tangent entries, the record the gradient action streams (ecm_device.hpp, point_update<.., REC>): AssembleGradPA rides in the launch.
+template <int KIN, bool LVEC, int NFIX, bool QB, bool REC = false>
 __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatParams mp, const int Q, const int n_rt, const int64_t P, const double dt,
                                                      double* __restrict__ Jio, const double* __restrict__ G,
                                                      const double* __restrict__ vel, const double* __restrict__ xl, const int32_t* __restrict__ conn, const int nnodes,
                                                      const double* __restrict__ stress0,
                                                      const double* __restrict__ state0, double* __restrict__ stress1,
                                                      double* __restrict__ state1, double* __restrict__ cmat, int* __restrict__ fail,
-                                                     const int kcap, int* __restrict__ tail, const int tail_mode) {
+                                                     const int kcap, int* __restrict__ tail, const int tail_mode,
+                                                     const double* __restrict__ Wq = nullptr, const int trd = 0) {
+   static_assert(!REC || (LVEC && QB && NFIX == 8), "record output is built for the fused element-blocked p = 1 launch");
    if (tail_mode && (int64_t)blockIdx.x * blockDim.x >= tail[0]) return;   // tail launch: its grid covers the worst case, blocks beyond the list leave before the table fill
    const int n = NFIX ? NFIX : n_rt;
    constexpr bool P2F = (NFIX == 27);   // triquadratic fused path: G holds the 3 x 6 one-dimensional tables, read through scalar loads
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    const QView vJ = qview<QB>(9, Q, e, q), vS = qview<QB>(6, Q, e, q), vV = qview<QB>(NSTATEV, Q, e, q), vC = qview<QB>(36, Q, e, q);
    const double* Gq = sG + 3 * n * q;
    double J11, J21, J31, J12, J22, J32, J13, J23, J33;
+   double tsc = 0.0;   // REC: dt W_q / detJ
    double L[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
    if constexpr (P2F) {
       static_assert(!P2F || LVEC, "the triquadratic fused path gathers from L-vectors");
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    // inverse Jacobian (reference src/mechanics_kernels.cpp:38-61)
    const double detJ = J11 * (J22 * J33 - J32 * J23) - J21 * (J12 * J33 - J32 * J13) + J31 * (J12 * J23 - J22 * J13);
    const double di = 1.0 / detJ;
+   if (REC) tsc = dt * Wq[q] * di;
    // Ji[s][t] = dxi_s/dx_t
    const double Ji[3][3] = { { di * (J22 * J33 - J23 * J32), di * (J32 * J13 - J12 * J33), di * (J12 * J23 - J22 * J13) },
                              { di * (J31 * J23 - J21 * J33), di * (J11 * J33 - J13 * J31), di * (J21 * J13 - J11 * J23) },
@@ -143,7 +149,9 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    }
    // per-thread stash behind the shape table in LDS: slot s of this thread at stash[s * 256 + threadIdx.x]
    double* st = sG + tab + threadIdx.x;
-   const int rc = point_update<KIN, QS>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, cmat + vC.base, st, kcap, sG + pqo);
+   // REC: the lane's first 16-byte pair of its compact record ([block][q][13 pairs][64 lanes][2])
+   double* tout = REC ? cmat + pac_off<PAC_PAIRS>(e >> 6, Q, q, 0) + 2 * (e & 63) : cmat + vC.base;
+   const int rc = point_update<KIN, QS, REC>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, tout, st, kcap, sG + pqo, tsc, trd != 0);
    if (rc == 2) { const int slot = atomicAdd(&tail[0], 1); tail[1 + slot] = (int)(e * Q + q); }
    else if (rc) atomicAdd(fail, 1);
 }
@@ -225,6 +233,43 @@ static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel
       hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nbt), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
                          ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, 1 << 30, ctx->tail_dev, 1);
    }
+}
+
+// fused p = 1 launch that writes the compact gradient records (exa_model_setup_lvec_records)
+template <int KIN>
+static void launch_model_rec(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
+                             double* stress1, double* state1, hipStream_t s) {
+   const int bs = 256;
+   const int64_t nb = (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64);
+   const size_t lds = sizeof(double) * ((size_t)ctx->n * 3 * ctx->Q + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE + (ecmdev::kin_is_km(KIN) ? (size_t)8 * ecmdev::NSLIP : (size_t)0));
+   const bool split = ctx->newton_cap > 0 && ctx->tail_dev != nullptr;
+   const int trd = ctx->cfg.assembly == EXA_ASSEMBLY_EA;
+   hipLaunchKernelGGL((k_model_setup<KIN, true, 8, true, true>), dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+                      ctx->nnodes, stress0, state0, stress1, state1, ctx->pa_c, ctx->fail_count_dev, split ? ctx->newton_cap : (1 << 30), ctx->tail_dev, 0, ctx->W_dev, trd);
+   if (split) {
+      const int64_t nbt = (ctx->P + bs - 1) / bs;
+      hipLaunchKernelGGL((k_model_setup<KIN, true, 8, true, true>), dim3((unsigned)nbt), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+                         ctx->nnodes, stress0, state0, stress1, state1, ctx->pa_c, ctx->fail_count_dev, 1 << 30, ctx->tail_dev, 1, ctx->W_dev, trd);
+   }
+}
+
+int exa_launch_model_setup_rec(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
+                               double* stress1, double* state1, hipStream_t s) {
+   EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->fail_count_dev, 0, sizeof(int), s));
+   if (ctx->newton_cap > 0) {
+      if (!ctx->tail_dev) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tail_dev, sizeof(int) * ((size_t)ctx->P + 1)));
+      EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->tail_dev, 0, sizeof(int), s));
+   }
+   switch (ctx->mp.kin) {
+      case KIN_VOCE: launch_model_rec<KIN_VOCE>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s); break;
+      case KIN_VOCE_NL: launch_model_rec<KIN_VOCE_NL>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s); break;
+      default:
+         if (ECM_KM_DEFER && ctx->mp.with_g_athermal) launch_model_rec<KIN_KMBALD_GA>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
+         else launch_model_rec<KIN_KMBALD>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
+         break;
+   }
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   return EXA_OK;
 }
 
 template <int KIN, bool LVEC, int NFIX>

@@ -56,6 +56,7 @@ exa_qf_size = _sig("exa_qf_size", C.c_int64, C.c_void_p, C.c_int)
 EXA_QLAYOUT_AOS, EXA_QLAYOUT_EB64 = 0, 1
 exa_init_state = _sig("exa_init_state", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_model_setup = _sig("exa_model_setup", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
+exa_model_setup_lvec_records = _sig("exa_model_setup_lvec_records", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_setup_lvec = _sig("exa_model_setup_lvec", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_set_newton_cap = _sig("exa_set_newton_cap", C.c_int, C.c_void_p, C.c_int)
 exa_model_tail_count = _sig("exa_model_tail_count", C.c_int, C.c_void_p, C.c_void_p)

@@ -88,6 +88,16 @@ int exa_model_setup(exa_ctx* ctx, double dt, const double* jacobian_dev /*(3,3,Q
 int exa_model_setup_lvec(exa_ctx* ctx, double dt, const double* coords_lvec_dev /*(nnodes,3) byNODES*/, const double* vel_lvec_dev,
                          const double* stress0_dev, const double* state0_dev,
                          double* stress1_dev, double* state1_dev, double* ddsdde_dev, double* jacobian_out_dev, exa_stream s);
+/* The same launch with AssembleGradPA (src/mechanics_integrators.cpp:331-414) fused in as well: instead of the 36 tangent entries it
+ * writes, for every point, the compact record the L-vector gradient action streams (EXA_TANGENT_DEV5_BULK: the tangent's 5 x 5
+ * deviatoric block and bulk term times dt W_q / detJ; D^T in element-assembly contexts), so that neither a tangent field nor a
+ * separate exa_grad_setup pass exists on this path.  After it exa_grad_apply_lvec is valid once exa_grad_set_coords has named the
+ * coordinates (the same coords_lvec).  Preconditions: p = 1 full integration, EXA_QLAYOUT_EB64, exa_set_connectivity,
+ * exa_set_tangent_form(EXA_TANGENT_DEV5_BULK), partial assembly or matrix-free element assembly.  The entry points that read the
+ * full 46-double records (exa_grad_apply on E-vectors, exa_grad_diagonal, exa_grad_get_ea) still need exa_grad_setup. */
+int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* coords_lvec_dev, const double* vel_lvec_dev,
+                                 const double* stress0_dev, const double* state0_dev,
+                                 double* stress1_dev, double* state1_dev, double* jacobian_out_dev, exa_stream s);
 /* Tail split of the constitutive launch (0 = off, the default).  The local Newton solve needs 3-6 evaluations at most points and
  * 10-19 at a few per cent of them, and a wave waits for its slowest lane (measured wave max / mean = 1.2 ... 2.7).  With max_evals = K
  * the launch stops a point after K residual evaluations and a second, dense launch of the same kernel redoes exactly those points from

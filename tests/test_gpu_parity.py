@@ -668,6 +668,20 @@ def test_default_product_path_matches_oracle(oracle, name, xtal, kin, pkey, mode
             c2.check(L.exa_grad_set_coords(c2.h, ptr(d_x)))
             d_k = dev.zeros(3 * NN); c2.check(L.exa_grad_apply_lvec(c2.h, ptr(d_xg), ptr(d_k), ptr(d_mask), None))
             assert rel_l2(d_k.cpu().numpy(), k_ref) < 1e-11, (name, step, assembly)
+            # The driver's route: the constitutive launch writes the action's compact records itself (exa_model_setup_lvec_records: no tangent
+            # field, no exa_grad_setup).  Same stress / state as the tangent-writing launch, and the action equals the one built from that
+            # launch's own tangent (1e-12) and the oracle's chain (the GPU and oracle tangents agree to 1e-7).
+            c2.check(L.exa_grad_setup(c2.h, dt, ptr(d_J), ptr(d_cm), None))
+            d_kf = dev.zeros(3 * NN); c2.check(L.exa_grad_apply_lvec(c2.h, ptr(d_xg), ptr(d_kf), ptr(d_mask), None))
+            r_s1 = dev.zeros(sz(6)); r_sv1 = dev.zeros(sz(28)); r_J = dev.zeros(sz(9))
+            c2.check(L.exa_model_setup_lvec_records(c2.h, dt, ptr(d_x), ptr(d_v), ptr(d_s0), ptr(d_sv0), ptr(r_s1), ptr(r_sv1), ptr(r_J), None))
+            assert c2.check(L.exa_model_status(c2.h, None)) == 0
+            assert torch.equal(r_J, d_J)
+            assert rel_l2(r_s1.cpu().numpy(), d_s1.cpu().numpy()) < 1e-13 and rel_l2(r_sv1.cpu().numpy(), d_sv1.cpu().numpy()) < 1e-13
+            d_kr = dev.zeros(3 * NN); c2.check(L.exa_grad_apply_lvec(c2.h, ptr(d_xg), ptr(d_kr), ptr(d_mask), None))
+            assert rel_l2(d_kr.cpu().numpy(), d_kf.cpu().numpy()) < 1e-12, (name, step, assembly)
+            assert rel_l2(d_kr.cpu().numpy(), k_ref) < 2e-7, (name, step, assembly)
+            assert L.exa_grad_diagonal(c2.h, ptr(dev.zeros(3 * n * E)), None) < 0      # the full-record consumers say so instead of reading stale data
         s0, sv0 = s1, sv1
     assert np.abs(sv0.reshape(P, 28)[:, 14:26]).sum(axis=1).min() > 0      # fully plastic at the end
     for c in ctxs.values(): c.close()
