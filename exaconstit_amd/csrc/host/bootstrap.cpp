@@ -1,0 +1,134 @@
+// Process-group bootstrap of the `mechanics` executable: who am I, how many are we, and the 128 bytes of the RCCL unique id on every rank.
+//
+// The reference is `mpirun -np N mechanics -opt options.toml` (src/mechanics_driver.cpp:119-150: MPI_Init, MPI_Comm_rank/size) and uses
+// MPI for every collective.  Here the collectives are RCCL over xGMI (host/driver.hip, class Comm); the only thing a launcher has to
+// provide is a rank number, so the executable runs unchanged under
+//    mpirun / mpiexec.hydra (MPICH: PMI_RANK, PMI_SIZE; Open MPI: OMPI_COMM_WORLD_RANK/SIZE/LOCAL_RANK), srun (SLURM_PROCID, SLURM_NTASKS,
+//    SLURM_LOCALID), torchrun-style environments (RANK, WORLD_SIZE, LOCAL_RANK) or a shell loop (EXA_RANK, EXA_NRANKS)
+// without linking any of them.  The unique id travels over a plain TCP rendez-vous: rank 0 listens on MASTER_ADDR:MASTER_PORT
+// (EXA_MASTER_ADDR / EXA_MASTER_PORT first; default 127.0.0.1:29517, i.e. one node), the others connect (with retries while rank 0
+// is still starting) and read the payload.  No Python, no MPI library in the path.
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/select.h>
+#include <sys/socket.h>
+#include <unistd.h>
+#include <cerrno>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include "../../../include/exaconstit_driver.h"
+
+namespace {
+
+bool env_int(const char* name, int& out) {
+   const char* e = std::getenv(name);
+   if (!e || !*e) return false;
+   char* end = nullptr; const long v = std::strtol(e, &end, 10);
+   if (end == e) return false;
+   out = (int)v; return true;
+}
+
+void set_err(char* err, int errlen, const std::string& m) { if (err && errlen > 0) { std::snprintf(err, (size_t)errlen, "%s", m.c_str()); } }
+
+void send_all(int fd, const void* buf, size_t n) {
+   const char* p = (const char*)buf;
+   while (n) { const ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL); if (k <= 0) { if (errno == EINTR) continue; throw std::runtime_error(std::string("send: ") + std::strerror(errno)); } p += k; n -= (size_t)k; }
+}
+void recv_all(int fd, void* buf, size_t n) {
+   char* p = (char*)buf;
+   while (n) { const ssize_t k = ::recv(fd, p, n, 0); if (k <= 0) { if (k < 0 && errno == EINTR) continue; throw std::runtime_error(k == 0 ? "recv: peer closed the connection" : std::string("recv: ") + std::strerror(errno)); } p += k; n -= (size_t)k; }
+}
+
+struct Endpoint { std::string addr; int port; };
+Endpoint endpoint() {
+   Endpoint e{ "127.0.0.1", 29517 };
+   for (const char* k : { "EXA_MASTER_ADDR", "MASTER_ADDR" }) if (const char* v = std::getenv(k)) if (*v) { e.addr = v; break; }
+   for (const char* k : { "EXA_MASTER_PORT", "MASTER_PORT" }) { int p; if (env_int(k, p) && p > 0 && p < 65536) { e.port = p; break; } }
+   return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+// rank / size / local rank from the launcher's environment; 0 / 1 / 0 when there is none (plain `mechanics -opt ...`)
+int exa_bootstrap_env(int* rank, int* nranks, int* local_rank) {
+   int r = 0, n = 1, l = -1;
+   static const char* const rk[] = { "EXA_RANK", "PMI_RANK", "PMIX_RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID", "RANK" };
+   static const char* const nk[] = { "EXA_NRANKS", "PMI_SIZE", "OMPI_COMM_WORLD_SIZE", "SLURM_NTASKS", "WORLD_SIZE" };
+   static const char* const lk[] = { "EXA_LOCAL_RANK", "MPI_LOCALRANKID", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "LOCAL_RANK" };
+   bool have_r = false, have_n = false;
+   for (const char* k : rk) if (env_int(k, r)) { have_r = true; break; }
+   for (const char* k : nk) if (env_int(k, n)) { have_n = true; break; }
+   for (const char* k : lk) if (env_int(k, l)) break;
+   if (!have_r || !have_n) { r = 0; n = 1; }
+   if (n < 1 || r < 0 || r >= n) return -1;
+   if (l < 0) l = r;   // one node: the local rank is the rank
+   *rank = r; *nranks = n; *local_rank = l;
+   return 0;
+}
+
+// Broadcast `nbytes` from rank 0 to all ranks over TCP (rank 0: listen + accept nranks-1 peers; others: connect with retries).
+// Every peer first sends (magic, rank) so that a stray connection cannot consume a slot.  timeout_s bounds the whole exchange.
+int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double timeout_s, char* err, int errlen) {
+   if (nranks <= 1) return 0;
+   static const uint32_t kMagic = 0x45584131u;   // "EXA1"
+   const Endpoint ep = endpoint();
+   const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s > 0 ? timeout_s : 120.0);
+   try {
+      if (rank == 0) {
+         const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+         if (ls < 0) throw std::runtime_error(std::string("socket: ") + std::strerror(errno));
+         int one = 1; ::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+         sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)ep.port); sa.sin_addr.s_addr = htonl(INADDR_ANY);
+         if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0) { const std::string m = std::string("bind port ") + std::to_string(ep.port) + ": " + std::strerror(errno); ::close(ls); throw std::runtime_error(m); }
+         if (::listen(ls, nranks) != 0) { ::close(ls); throw std::runtime_error(std::string("listen: ") + std::strerror(errno)); }
+         int served = 0;
+         while (served < nranks - 1) {
+            timeval tv{}; const double left = std::chrono::duration<double>(t_end - std::chrono::steady_clock::now()).count();
+            if (left <= 0) { ::close(ls); throw std::runtime_error("rendez-vous timed out: " + std::to_string(served) + " of " + std::to_string(nranks - 1) + " peers connected"); }
+            tv.tv_sec = (long)left; tv.tv_usec = (long)((left - (long)left) * 1e6);
+            fd_set fds; FD_ZERO(&fds); FD_SET(ls, &fds);
+            if (::select(ls + 1, &fds, nullptr, nullptr, &tv) <= 0) continue;
+            const int fd = ::accept(ls, nullptr, nullptr);
+            if (fd < 0) continue;
+            timeval rt{ 10, 0 }; ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rt, sizeof(rt));
+            uint32_t hello[2] = { 0, 0 };
+            try { recv_all(fd, hello, sizeof(hello)); } catch (...) { ::close(fd); continue; }
+            if (hello[0] != kMagic || hello[1] == 0 || hello[1] >= (uint32_t)nranks) { ::close(fd); continue; }
+            send_all(fd, buf, (size_t)nbytes);
+            ::close(fd); served++;
+         }
+         ::close(ls);
+      } else {
+         addrinfo hints{}; hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+         addrinfo* res = nullptr;
+         if (::getaddrinfo(ep.addr.c_str(), std::to_string(ep.port).c_str(), &hints, &res) != 0 || !res) throw std::runtime_error("cannot resolve " + ep.addr);
+         int fd = -1;
+         for (;;) {
+            fd = ::socket(AF_INET, SOCK_STREAM, 0);
+            if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
+            if (fd >= 0) ::close(fd);
+            fd = -1;
+            if (std::chrono::steady_clock::now() > t_end) { ::freeaddrinfo(res); throw std::runtime_error("rendez-vous timed out connecting to " + ep.addr + ":" + std::to_string(ep.port)); }
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+         }
+         ::freeaddrinfo(res);
+         const uint32_t hello[2] = { kMagic, (uint32_t)rank };
+         send_all(fd, hello, sizeof(hello));
+         recv_all(fd, buf, (size_t)nbytes);
+         ::close(fd);
+      }
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, std::string("exa_bootstrap_bcast (rank ") + std::to_string(rank) + "): " + e.what()); return -1; }
+}
+
+}  // extern "C"

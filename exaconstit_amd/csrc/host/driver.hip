@@ -2,6 +2,8 @@
 #include "driver.hpp"
 #include "roctx.hpp"
 #include <rccl/rccl.h>
+#include <chrono>
+#include <sys/stat.h>
 #include <dlfcn.h>
 #include <link.h>
 #include <algorithm>
@@ -580,7 +582,7 @@ int SystemDriver::CGSolveSingleReduction(const double* b, double* x) {
    vk_cg2_dots(nd, nn, op.weight.p, op.ess_mask.p, cg_r_.p, cg_z_.p, cg_s_.p, S + 6, op.partial.p, S + 8, ident, s);
    comm.allreduce_sum(S + 8, 2, s);
    vk_cg2_init(S, opt_.krylov_rel, opt_.krylov_abs, s);
-   double hS[11]; int launched = 0; bool done = false;
+   double hS[12]; int launched = 0; bool done = false;
    while (!done) {
       for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) {
          vk_cg2_update(nd, S, op.dinv.p, x, cg_r_.p, cg_z_.p, cg_d_.p, cg_s_.p, cg_q_.p, ident, s);
@@ -589,7 +591,7 @@ int SystemDriver::CGSolveSingleReduction(const double* b, double* x) {
          comm.allreduce_sum(S + 8, 2, s);
          vk_cg2_scalars(S, opt_.krylov_iter, s);
       }
-      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 11, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 12, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
       done = (hS[6] != 0.0) || launched >= opt_.krylov_iter;
    }
    EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
@@ -598,6 +600,7 @@ int SystemDriver::CGSolveSingleReduction(const double* b, double* x) {
    op.timers.t_krylov_ms += ms; op.timers.krylov_iters += iters;
    last_cg_flag = (int)hS[6]; cg_indefinite_iters += (int64_t)hS[10];
    if (hS[6] != 1.0) cg_not_converged++;
+   note_cg_reduction(hS);
    report_cg(hS, iters);
    return iters;
 }
@@ -609,6 +612,12 @@ void SystemDriver::report_cg(const double* hS, int iters) const {
       if (hS[6] == -1.0) std::cerr << "PCG: (Ad, d) = 0, stopping after " << iters << " iterations\n";
       else if (hS[6] != 1.0) std::cerr << "PCG: No convergence! (" << iters << " iterations)\n";
    }
+}
+
+// achieved reduction of the preconditioned residual, sqrt((r, M^-1 r) / (r0, M^-1 r0)): what a solve that stopped at max_iter reached
+void SystemDriver::note_cg_reduction(const double* hS) {
+   last_cg_reduction = (hS[11] > 0.0) ? std::sqrt(std::fmax(hS[2], 0.0) / hS[11]) : 0.0;
+   if (hS[6] != 1.0) worst_capped_cg_reduction = std::max(worst_capped_cg_reduction, last_cg_reduction);
 }
 
 void SystemDriver::drop_cg_graph() {
@@ -638,7 +647,7 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    vk_dot(nd, nn, op.weight.p, cg_z_.p, cg_d_.p, S + 6, op.partial.p, S + 8, s);
    comm.allreduce_sum(S + 8, 1, s);
    vk_cg_den(S, s);
-   double hS[11]; int launched = 0; bool done = false;
+   double hS[12]; int launched = 0; bool done = false;
    const bool fused = std::getenv("EXA_PCG_UNFUSED") == nullptr;   // A/B switch for measurements
    // One rank: the scalar updates ride in the reductions (no all-reduce in between).  (Summing the denominator d.(K d) element-wise
    // inside the action, with its scatter skipping the essential rows, was measured too: the pass it saves costs what it adds to the
@@ -689,7 +698,7 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    while (!done) {
       if (use_graph) { EXA_HC(hipGraphLaunch((hipGraphExec_t)cg_graph_, s)); launched += cg_check_every; }
       else for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) iteration();
-      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 11, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 12, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
       done = (hS[6] != 0.0) || launched >= opt_.krylov_iter;
    }
    EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
@@ -699,6 +708,7 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    // what MFEM prints (CGSolver::Mult): breakdown, indefinite operator, no convergence within max_iter
    last_cg_flag = (int)hS[6]; cg_indefinite_iters += (int64_t)hS[10];
    if (hS[6] != 1.0) cg_not_converged++;
+   note_cg_reduction(hS);
    report_cg(hS, iters);
    return iters;
 }
@@ -835,6 +845,7 @@ bool SystemDriver::Step(int ti) {
    time += dt_real; dt_class = dt_real;
    op.SetDt(dt_real);
    stats.emplace_back();
+   const auto wall0 = std::chrono::steady_clock::now();   // reference: t1 = MPI_Wtime() ... times[ti - 1] = t2 - t1 (src/mechanics_driver.cpp:865,891-892)
    hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1)); EXA_HC(hipEventRecord(e0, s));
    for (const BCEntry& bc : opt_.bcs) if (bc.step == ti) {
       DevBuf<double> v_prev(nd); v_prev.copy_from(v_sol, s);
@@ -847,6 +858,7 @@ bool SystemDriver::Step(int ti) {
    EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
    float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
    op.timers.t_solve_ms += ms;
+   step_wall_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count());
    if (!ok) return false;
    UpdateModel();
    op.SwapCoords();
@@ -862,7 +874,18 @@ int SystemDriver::RunAll() {
       }
       if (!opt_.dt_cust) { const double dtl = opt_.dt_auto ? last_dt_ : opt_.dt; if (std::fabs(time - opt_.t_final) <= std::fabs(1e-3 * dtl)) break; }
    }
+   WriteStepTimes();
    return steps_done;
+}
+
+// per-rank wall time of every step's solve, one value per line with 8 digits: ./time/time_solve.<rank>.txt of the reference
+// (src/mechanics_driver.cpp:982-998; every rank writes its own file, appended like the reference's)
+void SystemDriver::WriteStepTimes() const {
+   if (!write_files || step_wall_s.empty()) return;
+   const std::string dir = out_dir + "/time";
+   (void)::mkdir(dir.c_str(), 0755);
+   std::ofstream f(dir + "/time_solve." + std::to_string(comm.rank) + ".txt", std::ios::out | std::ios::app);
+   for (double v : step_wall_s) f << std::setprecision(8) << v << "\n";
 }
 
 }  // namespace exa_host

@@ -150,6 +150,8 @@ class SystemDriver {
    bool NewtonSolve(double* x, SolverStats& st);
    int CGSolve(const double* b, double* x);   // device PCG, returns iterations
    int CGSolveSingleReduction(const double* b, double* x);   // more than one rank: one fused 16-byte all-reduce per iteration
+   void note_cg_reduction(const double* hS);
+   double last_cg_reduction = 0.0, worst_capped_cg_reduction = 0.0;   // |r|_M / |r0|_M of the last PCG solve / the worst among the solves that stopped at max_iter
    void drop_cg_graph();                      // forget the captured PCG chunk (its solution buffer is about to go away)
    void report_cg(const double* hS, int iters) const;   // MFEM CGSolver::Mult diagnostics (verbose / EXA_VERBOSE)
    NonlinearMechOperator& oper() { return *oper_; }
@@ -159,6 +161,8 @@ class SystemDriver {
    DevBuf<double> v_sol;
    double time = 0.0, dt_class = 0.0; int steps_done = 0;
    bool write_files = true; std::string out_dir = ".";
+   std::vector<double> step_wall_s;            // wall time of each step (solve part), written to time/time_solve.<rank>.txt by RunAll
+   void WriteStepTimes() const;
    Precond precond = Precond::IDENTITY;
    int cg_check_every = 16;
    int64_t cg_graph_max_dofs = 3 * 33 * 33 * 33;   // PCG iterations replayed from a hipGraph up to this many local dofs (32^3 elements at p = 1: +9 % at 16^3, +3 % at 32^3, a loss from 48^3 on); EXA_PCG_GRAPH=0 | all

@@ -22,6 +22,23 @@ void set_err(char* err, int n, const std::string& m) { if (err && n > 0) { std::
 
 extern "C" {
 
+// rank / size from the launcher's environment, device = local rank mod visible devices, RCCL unique id from rank 0 to everybody over the
+// TCP rendez-vous of host/bootstrap.cpp: everything `mechanics` needs before exa_driver_create (reference: MPI_Init + MPI_Comm_rank/size,
+// src/mechanics_driver.cpp:119-150)
+int exa_bootstrap(int* rank, int* nranks, void* uid128, char* err, int errlen) {
+   int lr = 0;
+   if (exa_bootstrap_env(rank, nranks, &lr) != 0) { set_err(err, errlen, "exa_bootstrap: inconsistent rank / size in the environment"); return -1; }
+   int nd = 0;
+   if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { set_err(err, errlen, "exa_bootstrap: no HIP device"); return -1; }
+   if (hipSetDevice(lr % nd) != hipSuccess) { set_err(err, errlen, "exa_bootstrap: hipSetDevice failed"); return -1; }
+   std::memset(uid128, 0, 128);
+   if (*nranks > 1) {
+      if (*rank == 0 && exa_rccl_unique_id(uid128) != 0) { set_err(err, errlen, "exa_bootstrap: ncclGetUniqueId failed"); return -1; }
+      if (exa_bootstrap_bcast(*rank, *nranks, uid128, 128, 300.0, err, errlen) != 0) return -1;
+   }
+   return 0;
+}
+
 int exa_rccl_unique_id(void* out128) {
    try { Comm::get_unique_id(out128); return 0; } catch (const std::exception& e) { std::fprintf(stderr, "exa_rccl_unique_id: %s\n", e.what()); return -1; }
 }
@@ -107,6 +124,9 @@ void exa_driver_reset_timers(exa_driver* d) { d->sd->oper().timers = Timers(); }
 void exa_driver_get_diagnostics(exa_driver* d, int64_t* out) {
    out[0] = d->sd->oper().model_fail_total; out[1] = d->sd->cg_not_converged; out[2] = d->sd->cg_indefinite_iters; out[3] = d->sd->last_cg_flag;
 }
+
+// out[0] = sqrt((r, M^-1 r) / (r0, M^-1 r0)) reached by the last PCG solve, out[1] = the worst value among the solves that stopped at max_iter
+void exa_driver_get_pcg_reduction(exa_driver* d, double* out2) { out2[0] = d->sd->last_cg_reduction; out2[1] = d->sd->worst_capped_cg_reduction; }
 
 int exa_driver_nfev_hist(exa_driver* d, int* hist64, char* err, int errlen) {
    try {

@@ -1,6 +1,9 @@
 // `mechanics -opt options.toml` — stand-alone equivalent of the reference executable (reference src/mechanics_driver.cpp:112-1022)
-// for its hot-path subset, running on one MI355X (multi-GPU runs are launched through bench.py / the Python binding, which
-// distribute the RCCL unique id).
+// for its hot-path subset.  One process per GPU, like the reference's one MPI rank per device:
+//    mechanics -opt case.toml                      one MI355X
+//    mpirun -np 8 mechanics -opt case.toml         eight ranks (any launcher that exports a rank number: host/bootstrap.cpp)
+// The ranks find each other through exa_bootstrap (rank / size from the launcher's environment, RCCL unique id over a TCP rendez-vous);
+// every collective afterwards is RCCL over xGMI.  Rank 0 prints and writes the avg_* files, every rank writes time/time_solve.<rank>.txt.
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -11,16 +14,20 @@ int main(int argc, char** argv) {
    std::string opt = "options.toml";
    for (int i = 1; i < argc; i++) if ((!std::strcmp(argv[i], "-opt") || !std::strcmp(argv[i], "--option")) && i + 1 < argc) opt = argv[++i];
    char err[512] = { 0 };
+   int rank = 0, nranks = 1; unsigned char uid[128];
+   if (exa_bootstrap(&rank, &nranks, uid, err, sizeof(err)) != 0) { std::fprintf(stderr, "mechanics: %s\n", err); return 1; }
    const auto t0 = std::chrono::steady_clock::now();
-   exa_driver* d = exa_driver_create(opt.c_str(), ".", 0, 1, nullptr, 0, 1, err, sizeof(err));
-   if (!d) { std::fprintf(stderr, "mechanics: %s\n", err); return 1; }
+   exa_driver* d = exa_driver_create(opt.c_str(), ".", rank, nranks, nranks > 1 ? uid : nullptr, 0, 1, err, sizeof(err));
+   if (!d) { std::fprintf(stderr, "mechanics (rank %d): %s\n", rank, err); return 1; }
    const int rc = exa_driver_run(d, err, sizeof(err));
-   if (rc < 0) { std::fprintf(stderr, "mechanics: run failed (%d) %s\n", rc, err); exa_driver_destroy(d); return 2; }
+   if (rc < 0) { std::fprintf(stderr, "mechanics (rank %d): run failed (%d) %s\n", rank, rc, err); exa_driver_destroy(d); return 2; }
    double t[5]; exa_driver_get_timers(d, t);
    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-   std::printf("The process took %lf seconds to run\n", wall);
-   std::printf("steps %d | constitutive kernel %.3f s for %.0f qpt updates (%.3e qpt/s) | krylov %.3f s for %.0f iterations (%.1f it/s)\n", rc,
-               t[0] * 1e-3, t[3], t[3] / (t[0] * 1e-3), t[1] * 1e-3, t[4], t[4] / (t[1] * 1e-3));
+   if (rank == 0) {
+      std::printf("The process took %lf seconds to run\n", wall);
+      std::printf("ranks %d | steps %d | constitutive kernel %.3f s for %.0f qpt updates on rank 0 (%.3e qpt/s) | krylov %.3f s for %.0f iterations (%.1f it/s)\n", nranks, rc,
+                  t[0] * 1e-3, t[3], t[3] / (t[0] * 1e-3), t[1] * 1e-3, t[4], t[4] / (t[1] * 1e-3));
+   }
    exa_driver_destroy(d);
    return 0;
 }

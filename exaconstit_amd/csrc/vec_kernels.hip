@@ -75,7 +75,7 @@ __global__ void k_reduce(int nb, const double* __restrict__ partial, const doubl
 // S[8]=scratch for reductions  S[9]=scratch of the operator's dot  S[10]=number of iterations with (Ad, d) < 0
 __global__ void k_cg_init(double* S, double rel, double abs_) {       // after nom was reduced into S[8]
    const double nom = S[8];
-   S[0] = nom; S[3] = fmax(nom * rel * rel, abs_ * abs_); S[7] = 0.0;
+   S[0] = nom; S[3] = fmax(nom * rel * rel, abs_ * abs_); S[7] = 0.0; S[2] = nom; S[11] = nom;   // S[11]: (r0, z0), S[2]: latest (r, z) - the achieved reduction is reported
    S[6] = (nom < 0.0) ? -1.0 : ((nom <= S[3]) ? 1.0 : 0.0);
 }
 __device__ __forceinline__ void cg_den_update(double* S) {            // den reduced into S[8]
@@ -148,7 +148,7 @@ __global__ void k_cg_step2z(int64_t n, const double* __restrict__ S, double* __r
 // scalars as above; S[8], S[9] hold the reduced pair gamma = (r, u), delta = (A u, u)
 __global__ void k_cg2_init(double* S, double rel, double abs_) {          // after (gamma, delta) were reduced into S[8], S[9]
    const double g = S[8], dl = S[9];
-   S[0] = g; S[1] = dl; S[3] = fmax(g * rel * rel, abs_ * abs_); S[7] = 0.0; S[5] = 0.0;
+   S[0] = g; S[1] = dl; S[3] = fmax(g * rel * rel, abs_ * abs_); S[7] = 0.0; S[5] = 0.0; S[2] = g; S[11] = g;
    S[6] = (g < 0.0) ? -1.0 : ((g <= S[3]) ? 1.0 : 0.0);
    if (S[6] == 0.0) { if (dl == 0.0) S[6] = -1.0; else { if (dl < 0.0) S[10] += 1.0; S[4] = g / dl; } }
 }

@@ -156,6 +156,10 @@ exa_driver_get_timers = _sig("exa_driver_get_timers", None, C.c_void_p, C.POINTE
 exa_driver_reset_timers = _sig("exa_driver_reset_timers", None, C.c_void_p)
 exa_driver_nfev_hist = _sig("exa_driver_nfev_hist", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_int)
 exa_driver_get_diagnostics = _sig("exa_driver_get_diagnostics", None, C.c_void_p, C.POINTER(C.c_int64))
+exa_bootstrap_env = _sig("exa_bootstrap_env", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
+exa_bootstrap_bcast = _sig("exa_bootstrap_bcast", C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_char_p, C.c_int)
+exa_bootstrap = _sig("exa_bootstrap", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_char_p, C.c_int)
+exa_driver_get_pcg_reduction = _sig("exa_driver_get_pcg_reduction", None, C.c_void_p, C.POINTER(C.c_double))
 exa_driver_bench_prepare = _sig("exa_driver_bench_prepare", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_char_p, C.c_int)
 exa_driver_bench_model = _sig("exa_driver_bench_model", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_driver_bench_pcg = _sig("exa_driver_bench_pcg", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
@@ -234,7 +238,10 @@ class Driver:
         import numpy as np
         o = np.zeros(4, np.int64)
         exa_driver_get_diagnostics(self.h, o.ctypes.data_as(C.POINTER(C.c_int64)))
-        return dict(model_failed_points=int(o[0]), pcg_not_converged=int(o[1]), pcg_indefinite_iters=int(o[2]), pcg_last_flag=int(o[3]))
+        r = np.zeros(2)
+        exa_driver_get_pcg_reduction(self.h, r.ctypes.data_as(C.POINTER(C.c_double)))
+        return dict(model_failed_points=int(o[0]), pcg_not_converged=int(o[1]), pcg_indefinite_iters=int(o[2]), pcg_last_flag=int(o[3]),
+                    pcg_last_reduction=float(r[0]), pcg_worst_capped_reduction=float(r[1]))
 
     def bench_prepare(self, dts, perturb=1.0, advance=True):
         """Kinematic drive to the state the timed passes start from; advance=False keeps the virgin state (elastic first step, dt = dts[0])."""

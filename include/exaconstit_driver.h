@@ -30,6 +30,14 @@ typedef struct {
 } exa_synth_config;
 
 int exa_rccl_unique_id(void* out128);
+/* Launcher-agnostic process-group bootstrap of the `mechanics` executable (reference: MPI_Init / MPI_Comm_rank / MPI_Comm_size,
+ * src/mechanics_driver.cpp:119-150).  exa_bootstrap_env reads rank / size / local rank from the environment of mpirun (MPICH PMI_*,
+ * Open MPI OMPI_COMM_WORLD_*), srun (SLURM_*), torchrun-style launchers (RANK / WORLD_SIZE / LOCAL_RANK) or EXA_RANK / EXA_NRANKS;
+ * exa_bootstrap_bcast copies rank 0's buffer to every rank over a TCP rendez-vous on [EXA_]MASTER_ADDR:[EXA_]MASTER_PORT (default
+ * 127.0.0.1:29517); exa_bootstrap = both + device selection (local rank mod visible devices) + the RCCL unique id in uid128. */
+int exa_bootstrap_env(int* rank, int* nranks, int* local_rank);
+int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double timeout_s, char* err, int errlen);
+int exa_bootstrap(int* rank, int* nranks, void* uid128, char* err, int errlen);
 /* Test transport: `nranks` drivers on ONE device, one host thread each, exchanging through an in-process group instead of RCCL
  * (RCCL refuses two ranks on one device).  Pass the 128 bytes as the unique id of every rank; destroy after the drivers. */
 int exa_loopback_group_create(int nranks, void* out128);
@@ -50,6 +58,9 @@ void exa_driver_reset_timers(exa_driver* d);
  * library's ECMECH_FAIL; here Newton reports non-convergence), [1] PCG solves without convergence, [2] PCG iterations with
  * (Ad, d) < 0 (MFEM: "The operator is not positive definite"), [3] flag of the last PCG solve (1 ok, 2 max_iter, -1 (Ad, d) = 0). */
 void exa_driver_get_diagnostics(exa_driver* d, int64_t* out4);
+/* Residual reduction |r|_M / |r0|_M the PCG reached: out2[0] last solve, out2[1] the worst among the solves that stopped at max_iter
+ * (MFEM's CGSolver prints "No convergence!" with the final norms, linalg/solvers.cpp; the reference's Newton loop goes on regardless). */
+void exa_driver_get_pcg_reduction(exa_driver* d, double* out2);
 /* 64-bin histogram of the local-solver evaluation counts (ExaCMech's nFEval state variable) of the last constitutive launch */
 int exa_driver_nfev_hist(exa_driver* d, int* hist64, char* err, int errlen);
 int exa_driver_bench_prepare(exa_driver* d, int nsteps, const double* dts, double perturb, char* err, int errlen);

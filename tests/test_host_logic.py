@@ -183,3 +183,41 @@ def test_file_mesh_partition_invariants(mesh, nranks):
             assert np.array_equal(dofs[m:2 * m] - dofs[:m], np.full(m, p["NN"]))
     err = C.create_string_buffer(256); info = (C.c_int64 * 8)()
     assert L.exa_mesh_partition_query(b"/nonexistent.mesh", 0, 2, info, None, None, None, None, None, None, None, err, 256) == -1 and b"Cannot open" in err.value
+
+
+@pytest.mark.parametrize("style", ["mpich", "torchrun", "exa"])
+def test_launcher_bootstrap_rendezvous(style):
+    """`mpirun -np N mechanics -opt ...` without MPI in the executable (reference src/mechanics_driver.cpp:119-150): rank and size are read
+    from whatever the launcher exports, the RCCL unique id travels from rank 0 to every rank over the TCP rendez-vous of
+    csrc/host/bootstrap.cpp.  Three real processes, started in reverse order (peers before rank 0: they must retry), no GPU."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bootstrap_worker.py")
+    names = {"mpich": ("PMI_RANK", "PMI_SIZE", "MPI_LOCALRANKID"), "torchrun": ("RANK", "WORLD_SIZE", "LOCAL_RANK"), "exa": ("EXA_RANK", "EXA_NRANKS", "EXA_LOCAL_RANK")}[style]
+    procs = []
+    for rank in (2, 1, 0):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PMI_RANK", "PMI_SIZE", "EXA_RANK", "EXA_NRANKS", "MASTER_PORT", "MASTER_ADDR")}
+        env.update({names[0]: str(rank), names[1]: "3", names[2]: str(rank), "EXA_MASTER_PORT": str(port)})
+        procs.append((rank, subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        if rank == 1:
+            time.sleep(0.3)
+    for rank, p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, (rank, out, err)
+        assert "rank %d of 3 local %d payload_ok 1" % (rank, rank) in out
+
+
+def test_bootstrap_without_launcher():
+    import ctypes as C
+    import exaconstit_amd.lib as L
+    saved = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "PMI_RANK", "PMI_SIZE", "EXA_RANK", "EXA_NRANKS", "SLURM_PROCID", "SLURM_NTASKS", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE") if k in os.environ}
+    try:
+        r, n, l = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        assert L.exa_bootstrap_env(C.byref(r), C.byref(n), C.byref(l)) == 0 and (r.value, n.value, l.value) == (0, 1, 0)
+        os.environ["EXA_RANK"] = "5"; os.environ["EXA_NRANKS"] = "4"
+        assert L.exa_bootstrap_env(C.byref(r), C.byref(n), C.byref(l)) != 0      # rank outside the group
+    finally:
+        os.environ.pop("EXA_RANK", None); os.environ.pop("EXA_NRANKS", None); os.environ.update(saved)
