@@ -37,6 +37,7 @@ APPLY_MOVED_BYTES_COMPACT = 248.0 # ... with the tangent in its deviatoric-block
 PCG_VEC_BYTES_PER_DOF = 128.0
 MODEL_NAMES = {"fcc_voce": "FCC Voce power-law", "bcc_voce": "BCC Voce power-law", "fcc_voce_nl": "FCC non-linear Voce",
                "fcc_kmdd": "FCC Kocks-Mecking dislocation density", "bcc_kmdd": "BCC Kocks-Mecking dislocation density"}
+SETTLE_PASSES = 60                # untimed constitutive passes before the timed region (>= --warmup), see main()
 PREP_DTS = [0.005, 0.195, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1]   # first 10 steps of the reference schedule: 0.1 % strain, plastic
 
 
@@ -50,6 +51,16 @@ def host_cores():
     except Exception:
         pass
     return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(props, seconds_target=12.0):
@@ -95,7 +106,7 @@ def cpu_baseline(props, seconds_target=12.0):
     orc.lib().orc_set_threads(cores)
     nc, elc = timed(0.4 * seconds_target)
     orc.lib().orc_set_threads(1)
-    return {"value": P * nc / elc, "unit": "qpt-updates/s", "cores": cores, "kind": "port", "single_thread_value": P * n1 / el1,
+    return {"value": P * nc / elc, "unit": "qpt-updates/s", "cores": cores, "cpu": cpu_model(), "kind": "port", "single_thread_value": P * n1 / el1,
             "sample": f"{N}^3-element FCC-Voce RVE ({P} qpts), same kinematic drive to the plastic regime; constitutive passes of the oracle "
                       f"(element/qpt loops of the reference's CPU path): {n1} serial passes in {el1:.1f} s (rtmodel=CPU analogue) and {nc} passes "
                       f"in {elc:.1f} s with an OpenMP loop over all {cores} host threads (rtmodel=OPENMP analogue; `value`)"}
@@ -171,8 +182,12 @@ def main():
     P_local = L.exa_driver_local_qpts(drv.h)
     P_global = 8 * N ** 3
     # ---- timed region 1: constitutive passes -------------------------------------------------------------------------
-    if args.warmup > 0:
-        drv.bench_model(args.warmup)
+    # untimed passes before the timed region: the --warmup passes of the contract, and at least SETTLE_PASSES in total so that a short
+    # timed region (the driver runs --steps 20) starts at the clock a long one runs at (the first dozens of launches after the prepare
+    # phase read ~4 % slow: 6.95 ms in a 20-pass run against 6.70 ms in a 300-pass one on the round-2 build)
+    settle = max(args.warmup, SETTLE_PASSES)
+    if settle > 0:
+        drv.bench_model(settle)
     barrier()
     t0 = time.perf_counter()
     m = drv.bench_model(args.steps)
@@ -207,6 +222,11 @@ def main():
                  "model_calls": [int(x) for x in mc], "qpt_updates_per_s_in_kernel": 8 * N ** 3 * int(sum(mc)) / (max_over_ranks(tm["model_ms"]) * 1e-3),
                  "pcg_iters_per_s": tm["krylov_iters"] / (max_over_ranks(tm["krylov_ms"]) * 1e-3),
                  "avg_stress_zz": [float(x) for x in drv.avgs(0, 6)[:, 2]]}
+        dg = drv.diagnostics()
+        solve.update({"model_failed_points": dg["model_failed_points"], "pcg_solves_at_iteration_cap": dg["pcg_not_converged"],
+                      "pcg_worst_residual_reduction_at_cap": dg["pcg_worst_capped_reduction"], "pcg_rel_tol": 1e-7,
+                      "note": "the reference's settings (1000 PCG iterations, identity 'Jacobi') do not converge the linear solves of this size to rel_tol; "
+                              "pcg_worst_residual_reduction_at_cap = |r|/|r0| the capped solves reached (Newton converges regardless: newton_iters)"})
     if rank == 0:
         ndof_local = L.exa_driver_local_dofs(drv.h)
         # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench): bytes/qpt x local qpts
@@ -214,7 +234,14 @@ def main():
         try:
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
             if cands:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["bytes_per_qpt"]
+                raw = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["bytes_per_qpt"]
+                # per kernel either one number (measured on the fcc_voce instantiation) or {model: bytes}: never quote one model's counters for another
+                for k, v in raw.items():
+                    if isinstance(v, dict):
+                        if args.model in v:
+                            traffic[k] = v[args.model]
+                    elif args.model == "fcc_voce" or k != "k_model_setup":
+                        traffic[k] = v
                 traffic["_file"] = "profiles/" + cands[-1]
         except Exception:
             traffic = {}
@@ -227,6 +254,7 @@ def main():
         except Exception:
             flops = None
         model_gbs = MODEL_BYTES_PER_QPT * P_local / (kern_ms * 1e-3) / 1e9
+        records = args.assembly.upper() in ("PA", "EA") and os.environ.get("EXA_TANGENT_RECORDS") != "off" and not args.jacobi
         ea_streamed = args.assembly.upper() == "EA" and os.environ.get("EXA_EA_ASSEMBLED") == "1"   # 24 x 24 matrices from HBM
         geo = os.environ.get("EXA_APPLY_GEO", "on") != "off" and not ea_streamed
         compact = geo and os.environ.get("EXA_TANGENT_FORM", "compact") != "full"
@@ -251,6 +279,8 @@ def main():
                          "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS,
                          "traffic": traffic["k_model_setup"] * P_local if "k_model_setup" in traffic else None, "traffic_source": traffic.get("_file"),
                          "bytes_per_qpt": MODEL_BYTES_PER_QPT, "avg_kernel_ms": kern_ms,
+                         "bytes_written_per_qpt_note": ("this launch writes the 26-number gradient record instead of the 36 tangent entries (848 B/qpt moved; "
+                                                        "AssembleGradPA fused in); frac stays priced at SURVEY 8(d)'s 928 B/qpt") if records else None,
                          "fp64_flop_per_qpt": flops, "fp64_tflops": (flops * P_local / (kern_ms * 1e-3) / 1e12) if flops else None,
                          "fp64_vector_frac": (flops * P_local / (kern_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TFLOPS) if flops else None,
                          # FP64 issue roofline: a wave64 FP64 VALU instruction occupies its SIMD for 4 cycles (16 FMA lanes per clock and SIMD = the

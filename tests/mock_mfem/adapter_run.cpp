@@ -2,7 +2,7 @@
 // NonlinearMechOperator does: ModelSetup, then AssemblePA/AddMultPA (residual), AssembleGradPA/AddMultGradPA/AssembleGradDiagonalPA (PA
 // gradient) and AssembleEA.  Inputs come from a flat binary file written by the test, outputs go to another one; the test compares them
 // with the same calls made directly on the C ABI.
-//   in : int32 E, model, nprops, assembly (0 PA, 1 EA); double dt; props[nprops]; geomJ[Q*9*E] (Q,3,3,E); vel[n*3*E]; quats[4*E]; x[n*3*E] (E-vector for the action)
+//   in : int32 E, model, nprops, assembly (0 PA, 1 EA), order (1 | 2), bbar (0 | 1); double dt; props[nprops]; geomJ[Q*9*E] (Q,3,3,E); vel[n*3*E]; quats[4*E]; x[n*3*E] (E-vector for the action)
 //   out: stress1[6P] state1[28P] matGrad[36P] y_res[3nE] y_grad[3nE] diag[3nE] emat[(3n)^2 E] dp[9P]
 #define EXA_ADAPTER_MOCK_MFEM
 #include "exaconstit_mfem_adapters.hpp"
@@ -16,21 +16,21 @@ int main(int argc, char** argv) {
    if (argc < 3) return 2;
    try {
       FILE* fi = fopen(argv[1], "rb"); if (!fi) return 3;
-      int hdr[4]; if (fread(hdr, 4, 4, fi) != 4) return 3;
-      const int E = hdr[0], model_id = hdr[1], nprops = hdr[2]; const bool ea = hdr[3] != 0;
+      int hdr[6]; if (fread(hdr, 4, 6, fi) != 6) return 3;
+      const int E = hdr[0], model_id = hdr[1], nprops = hdr[2]; const bool ea = hdr[3] != 0; const int order = hdr[4]; const bool bbar = hdr[5] != 0;
       double dt; if (fread(&dt, 8, 1, fi) != 1) return 3;
-      const int n = 8, Q = 8, P = E * Q;
+      const int n = (order + 1) * (order + 1) * (order + 1), Q = n, P = E * Q;
       std::vector<double> props = rd(fi, nprops), gj = rd(fi, (size_t)Q * 9 * E), vel = rd(fi, (size_t)n * 3 * E), quats = rd(fi, (size_t)4 * E), x = rd(fi, (size_t)n * 3 * E);
       fclose(fi);
       mfem::Vector vprops(nprops); vprops.FromHost(props.data());
       mfem::QuadratureFunction s0(P, 6), s1(P, 6), mg(P, 36), v0(P, 28), v1(P, 28), dp(P, 9);
       mfem::ParGridFunction bc(3 * 27), ec(3 * 27);
-      HipExaModel model(&s0, &s1, &mg, &v0, &v1, &bc, &ec, &vprops, nprops, 28, 298.0, model_id, 1, E, ea ? Assembly::EA : Assembly::PA);
+      HipExaModel model(&s0, &s1, &mg, &v0, &v1, &bc, &ec, &vprops, nprops, 28, 298.0, model_id, order, E, ea ? Assembly::EA : Assembly::PA, bbar);
       mfem::Vector vq(4 * E); vq.FromHost(quats.data());
       model.InitStateVars(vq);
       model.SetModelDt(dt);
       mfem::Mesh mesh; mesh.factors().J.SetSize(Q * 9 * E); mesh.factors().J.FromHost(gj.data());
-      mfem::FiniteElementSpace fes(&mesh, 1);
+      mfem::FiniteElementSpace fes(&mesh, order);
       HipExaNLFIntegrator integ(&model);
       // NonlinearMechOperator::Setup hands ModelSetup the (3,3,Q,E) Jacobians (src/mechanics_operator.cpp:377-391)
       mfem::Vector jac(Q * 9 * E), locgrad(1), vvel(n * 3 * E); vvel.FromHost(vel.data());

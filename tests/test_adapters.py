@@ -34,8 +34,12 @@ def test_adapter_header_refuses_to_compile_without_mfem(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model,pfile,ea", [(0, "props_cp_voce.txt", 0), (5, "props_cp_mts.txt", 0), (0, "props_cp_voce.txt", 1)])
-def test_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, ea):
+@pytest.mark.parametrize("model,pfile,ea,order,bbar", [(0, "props_cp_voce.txt", 0, 1, 0), (5, "props_cp_mts.txt", 0, 1, 0), (0, "props_cp_voce.txt", 1, 1, 0),
+                                                        (0, "props_cp_voce.txt", 1, 1, 1), (0, "props_cp_voce.txt", 1, 2, 0), (0, "props_cp_voce.txt", 1, 2, 1),
+                                                        (0, "props_cp_voce.txt", 0, 2, 0)])
+def test_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, ea, order, bbar):
+    """order = 2 and bbar = true (ICExaNLFIntegrator users, reference src/mechanics_integrators.hpp:78-124: element assembly only, like the
+    reference's B-bar integrator) go through the same adapter classes: HipExaModel(..., order, nelems, assembly, bbar)."""
     import exaconstit_amd.lib as L
     import hipref
     from hipref import ptr
@@ -43,15 +47,16 @@ def test_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, ea):
     exe = str(tmp_path / "adapter_run")
     _build(exe)
     dev = hipref.Dev()
-    rve = hipref.make_rve(orc, 2, distort=0.2, seed=3)
-    E, Q, n = rve["E"], 8, 8; P = E * Q
+    rve = hipref.make_rve(orc, 2, p=order, distort=0.2 if order == 1 else 0.1, seed=3)
+    E, Q, n = rve["E"], rve["Q"], rve["n"]; P = E * Q
+    assert Q == (order + 1) ** 3 and n == Q
     props = np.loadtxt(os.path.join(orc.REFDATA, pfile)).ravel()
     quats = hipref.random_quats(E, seed=9)
     dt = 0.4
     vel_e = hipref.l_to_e(rve, hipref.velocity_field(rve, scale=3.0))
     xe = hipref.l_to_e(rve, rve["X"])
     x_act = np.random.default_rng(1).uniform(-1, 1, 3 * n * E)
-    ctx = L.Context(model, props, 298.0, 1, E, assembly=L.EXA_ASSEMBLY_EA if ea else L.EXA_ASSEMBLY_PA)
+    ctx = L.Context(model, props, 298.0, order, E, assembly=L.EXA_ASSEMBLY_EA if ea else L.EXA_ASSEMBLY_PA, integ=L.EXA_INTEG_BBAR if bbar else L.EXA_INTEG_FULL)
     d_J = dev.zeros(9 * P)
     ctx.check(L.exa_jacobians(ctx.h, ptr(dev.up(xe)), ptr(d_J), None))
     J = d_J.cpu().numpy().reshape(E, Q, 9)                       # (3,3,Q,E), first index fastest
@@ -78,7 +83,7 @@ def test_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, ea):
     # ---- the same through the adapter classes
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(fin, "wb") as f:
-        f.write(struct.pack("iiii", E, model, len(props), ea)); f.write(struct.pack("d", dt))
+        f.write(struct.pack("iiiiii", E, model, len(props), ea, order, bbar)); f.write(struct.pack("d", dt))
         for a in (props, gj, vel_e, quats.ravel(), x_act):
             f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
