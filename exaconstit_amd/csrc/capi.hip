@@ -16,7 +16,7 @@ int exa_launch_residual_setup(exa_ctx*, const double*, const double*, hipStream_
 int exa_launch_residual_apply(exa_ctx*, double*, hipStream_t);
 int exa_launch_residual_p1(exa_ctx*, const double*, const double*, double*, bool, hipStream_t);
 int exa_launch_grad_setup_pa(exa_ctx*, double, const double*, const double*, hipStream_t);
-int exa_launch_grad_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t, bool trans = false);
+int exa_launch_grad_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t, bool trans = false, int blk0 = 0, int nblk_range = -1);
 int exa_launch_grad_diag_p1(exa_ctx*, double*, hipStream_t);
 int exa_launch_assemble_ea_p1(exa_ctx*, hipStream_t);
 int exa_launch_ea_apply_p1(exa_ctx*, const double*, double*, bool, const uint8_t*, const double*, hipStream_t);
@@ -369,6 +369,20 @@ extern "C" {
 
 // driver-internal variant: `gate` (nullable) is a device flag; a non-zero value turns the launch into a no-op so that a
 // PCG loop whose scalars live on the device can be enqueued without host synchronisation.
+// driver-internal: the p = 1 record-based action on the 64-element blocks [blk0, blk0 + nblk) only (partial assembly and element assembly
+// from records; atomic scatter).  Returns EXA_ERR_UNSUPPORTED for contexts that have no such kernel: the caller then runs the whole action.
+int exa_grad_apply_lvec_blocks(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, int blk0, int nblk, exa_stream s) {
+   if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply_lvec_blocks: null pointer");
+   if (!ctx->conn || !ctx->have_grad) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec_blocks: connectivity / gradient data not set");
+   if (ctx->grad_records_only && !ctx->coords_lvec) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec_blocks: name the nodal coordinates with exa_grad_set_coords");
+   if (ctx->det || ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL) return EXA_ERR_UNSUPPORTED;
+   if (ctx->cfg.assembly == EXA_ASSEMBLY_EA) {
+      if (!ea_from_records(ctx)) return EXA_ERR_UNSUPPORTED;
+      return exa_launch_grad_apply_p1(ctx, x, y, true, mask, gate, S(s), true, blk0, nblk);
+   }
+   return exa_launch_grad_apply_p1(ctx, x, y, true, mask, gate, S(s), false, blk0, nblk);
+}
+
 int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, exa_stream s) {
    if (!ctx || !x || !y) return fail(ctx, EXA_ERR_ARG, "exa_grad_apply_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_grad_apply_lvec: connectivity not set");

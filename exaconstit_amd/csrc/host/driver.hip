@@ -16,6 +16,7 @@
 #include <iomanip>
 #include <iostream>
 
+extern "C" int exa_grad_apply_lvec_blocks(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, int blk0, int nblk, exa_stream s);
 extern "C" int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, exa_stream s);
 
 
@@ -115,7 +116,10 @@ void Comm::init(int rank_, int nranks_, const void* uid) {
    }
    tmp_.alloc(64);
 }
-Comm::~Comm() { if (comm_) rccl().CommDestroy((ncclComm_t)comm_); }
+Comm::~Comm() {
+   if (comm_) rccl().CommDestroy((ncclComm_t)comm_);
+   if (cs_) { (void)hipStreamDestroy(cs_); (void)hipEventDestroy(ev_ready_); (void)hipEventDestroy(ev_done_); }
+}
 
 // op: 0 sum, 1 min, 2 max; host-synchronous, rank-ordered (deterministic)
 void Comm::loopback_reduce(double* dev, int n, int op, hipStream_t s) {
@@ -146,6 +150,27 @@ double Comm::max_over_ranks(double v) {
    return v;
 }
 
+void Comm::microbench(int iters, int n, double* us_allreduce, double* us_sendrecv) {
+   if (!comm_) throw std::runtime_error("Comm::microbench needs a RCCL communicator (EXA_FORCE_RCCL=1 on one rank)");
+   DevBuf<double> a(2), sb((size_t)n), rb((size_t)n); a.zero(); sb.zero(); rb.zero();
+   hipStream_t s; EXA_HC(hipStreamCreate(&s));
+   hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1));
+   auto timed = [&](auto&& body) {
+      for (int i = 0; i < 10; i++) body();
+      EXA_HC(hipEventRecord(e0, s));
+      for (int i = 0; i < iters; i++) body();
+      EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
+      float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); return 1e3 * ms / iters;
+   };
+   *us_allreduce = timed([&] { nccl_check(rccl().AllReduce(a.p, a.p, 2, ncclDouble, ncclSum, (ncclComm_t)comm_, s), "ncclAllReduce"); });
+   *us_sendrecv = timed([&] {
+      nccl_check(rccl().GroupStart(), "ncclGroupStart");
+      nccl_check(rccl().Send(sb.p, (size_t)n, ncclDouble, rank, (ncclComm_t)comm_, s), "ncclSend");
+      nccl_check(rccl().Recv(rb.p, (size_t)n, ncclDouble, rank, (ncclComm_t)comm_, s), "ncclRecv");
+      nccl_check(rccl().GroupEnd(), "ncclGroupEnd"); });
+   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+}
+
 // One pack and one unpack launch per exchange: the neighbours' dof lists are concatenated (segment i = neighbour i), the send /
 // receive buffers are one allocation each.  (A launch per neighbour is 14 tiny kernels per operator action on a 2 x 2 x 2 grid -
 // more than the exchange itself.)  A dof shared with several neighbours appears in several segments: the unpack adds atomically.
@@ -159,12 +184,34 @@ void Comm::setup_halo(const Partition& part) {
 
 void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
    if (nranks == 1 && !force_) return;
+   vk_pack((int64_t)seg_off_.back(), idx_all_.p, y, sbuf_all_.p, s);
+   exchange(part, s);
+   unpack(y, s);
+}
+
+// Overlapped form: everything enqueued on s before halo_begin (the element blocks that touch shared dofs) is waited for by the
+// communication stream, which packs and exchanges while s goes on with the interior blocks; halo_end makes s wait for the exchange and
+// adds the received segments.  Same arithmetic as halo_sum: only the stream the pack / exchange run on differs.
+void Comm::halo_begin(const Partition& part, double* y, hipStream_t s) {
+   if (nranks == 1 && !force_) return;
+   if (!cs_) { EXA_HC(hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking)); EXA_HC(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming)); EXA_HC(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming)); }
+   EXA_HC(hipEventRecord(ev_ready_, s));
+   EXA_HC(hipStreamWaitEvent(cs_, ev_ready_, 0));
+   vk_pack((int64_t)seg_off_.back(), idx_all_.p, y, sbuf_all_.p, cs_);
+   exchange(part, cs_);
+   EXA_HC(hipEventRecord(ev_done_, cs_));
+}
+void Comm::halo_end(const Partition&, double* y, hipStream_t s) {
+   if (nranks == 1 && !force_) return;
+   EXA_HC(hipStreamWaitEvent(s, ev_done_, 0));
+   unpack(y, s);
+}
+
+void Comm::exchange(const Partition& part, hipStream_t s) {
    const size_t nb = part.nbrs.size();
-   const int64_t ntot = (int64_t)seg_off_.back();
    auto sb = [&](size_t i) { return sbuf_all_.p + seg_off_[i]; };
    auto rb = [&](size_t i) { return rbuf_all_.p + seg_off_[i]; };
    auto cnt = [&](size_t i) { return seg_off_[i + 1] - seg_off_[i]; };
-   vk_pack(ntot, idx_all_.p, y, sbuf_all_.p, s);
    if (loop_) {
       LoopbackGroup* g = (LoopbackGroup*)loop_;
       g->sendbuf[rank].resize(nb); g->nbr_rank[rank].resize(nb);
@@ -182,7 +229,6 @@ void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
       }
       EXA_HC(hipStreamSynchronize(s));
       g->barrier();
-      unpack(y, s);
       return;
    }
    nccl_check(rccl().GroupStart(), "ncclGroupStart");
@@ -191,7 +237,6 @@ void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
       nccl_check(rccl().Recv(rb(i), cnt(i), ncclDouble, part.nbrs[i].rank, (ncclComm_t)comm_, s), "ncclRecv");
    }
    nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
-   unpack(y, s);
 }
 
 // adds the received segments to y.  A dof on an edge or corner of the block occurs in several segments: one launch over all of them adds
@@ -292,6 +337,14 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    { DevBuf<double> q; q.upload(quats_per_elem); abi_check(ctx_, exa_init_state(ctx_, matVars0.p, q.p, stream_), "exa_init_state"); EXA_HC(hipStreamSynchronize(stream_)); }
    model_.reset(new ExaCMechModel(ctx_, &stress0, &stress1, &matGrad, &matVars0, &matVars1));
    comm_.setup_halo(part);
+   // Halo exchange overlapped with the interior blocks: several ranks, the atomic p = 1 record-based action (PA, and EA computed from the
+   // records).  The deterministic mode keeps the plain sequence (its ordered E->L gather runs over all elements at once); EXA_HALO_OVERLAP=off
+   // is the A/B switch.  part.E_bdr > 0 only after Partition::order_boundary_first (SystemDriver).
+   {
+      const bool ea_rec = opt.assembly == Assembly::EA && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1");
+      overlap_ = fast_p1_ && lvec_grad_ && !det && part.E_bdr > 0 && !part.nbrs.empty() && (opt.assembly == Assembly::PA || ea_rec) && !env_is_off("EXA_HALO_OVERLAP");
+      nblk_bdr_ = (part.E_bdr + 63) / 64;
+   }
 }
 
 void NonlinearMechOperator::ensure_mat_grad() { if (matGrad.n == 0) { matGrad.alloc((size_t)exa_qf_size(ctx_, 36)); matGrad.zero(stream_); } }
@@ -414,6 +467,17 @@ void NonlinearMechOperator::GetGradient() {
 
 void NonlinearMechOperator::GradMult(const double* x, double* y, bool constrained, const double* done_flag, bool y_prezeroed, bool skip_out_mask) {
    if (!y_prezeroed) vk_fill_if(nd_, done_flag, 0.0, y, stream_);
+   if (lvec_grad_ && overlap_) {
+      // blocks that touch shared nodes, exchange of the shared dofs on the communication stream, interior blocks meanwhile, unpack last
+      const uint8_t* m = constrained ? ess_mask.p : nullptr;
+      const int nball = (E_ + 63) / 64;
+      abi_check(ctx_, exa_grad_apply_lvec_blocks(ctx_, x, y, m, done_flag, 0, nblk_bdr_, stream_), "exa_grad_apply_lvec_blocks");
+      comm_.halo_begin(part_, y, stream_);
+      abi_check(ctx_, exa_grad_apply_lvec_blocks(ctx_, x, y, m, done_flag, nblk_bdr_, nball - nblk_bdr_, stream_), "exa_grad_apply_lvec_blocks");
+      comm_.halo_end(part_, y, stream_);
+      if (constrained && !skip_out_mask) vk_mask_zero(nd_, ess_mask.p, y, stream_);
+      return;
+   }
    if (lvec_grad_) abi_check(ctx_, exa_grad_apply_lvec_gated(ctx_, x, y, constrained ? ess_mask.p : nullptr, done_flag, stream_), "exa_grad_apply_lvec");
    else {   // generic-order partial assembly: mask, L->E, AddMultGradPA, E->L (spec reference src/mechanics_operator_ext.cpp:143-157)
       EXA_HC(hipMemcpyAsync(tmp_l_.p, x, sizeof(double) * nd_, hipMemcpyDeviceToDevice, stream_));
@@ -494,6 +558,7 @@ SystemDriver::SystemDriver(const ExaOptions& opt, int rank, int nranks, const vo
       const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
       part.build(N, opt.length, rank, nranks, opt.order);
    } else part.build_from_mfem_mesh(opt.resolve(opt.mesh_file), rank, nranks);
+   if (opt.order == 1) part.order_boundary_first();   // several ranks: elements at shared nodes first (exchange overlapped with the interior, GradMult)
    std::vector<double> props, quats; load_case_data(opt, part, props, quats);
    init(props, quats);
 }
@@ -502,6 +567,7 @@ SystemDriver::SystemDriver(const ExaOptions& opt, const std::vector<double>& pro
    comm.init(rank, nranks, uid);
    const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
    part.build(N, opt.length, rank, nranks, opt.order);
+   if (opt.order == 1) part.order_boundary_first();
    std::vector<double> quats((size_t)4 * part.E);
    for (int e = 0; e < part.E; e++) for (int q = 0; q < 4; q++) quats[4 * (size_t)e + q] = quats_global[4 * (size_t)part.elem_gid[e] + q];
    init(props, quats);

@@ -33,8 +33,14 @@ class Comm {
    void allreduce_min(double* dev, int n, hipStream_t s);
    // y(shared dofs) <- sum over all ranks holding them
    void halo_sum(const Partition& part, double* y, hipStream_t s);
+   // the same in two halves for overlap with work on stream s: begin = pack + exchange on the communication stream once everything
+   // enqueued on s so far has finished; end = s waits for the exchange, then adds the received segments
+   void halo_begin(const Partition& part, double* y, hipStream_t s);
+   void halo_end(const Partition& part, double* y, hipStream_t s);
    void setup_halo(const Partition& part);
    double max_over_ranks(double v);
+   // us per call of the fused 16-byte all-reduce and of a grouped send/recv of `n` doubles to the own rank (one-rank communicator: latency floor of the RCCL calls)
+   void microbench(int iters, int n, double* us_allreduce, double* us_sendrecv);
    bool deterministic = false;               // halo contributions added segment by segment (fixed order) instead of one atomic pass
    bool forced() const { return force_; }   // EXA_FORCE_RCCL=1: the one-rank communicator runs the multi-rank code paths and every RCCL call
  private:
@@ -43,6 +49,8 @@ class Comm {
    void* comm_ = nullptr; void* loop_ = nullptr; bool force_ = false;
    DevBuf<int32_t> idx_all_; DevBuf<double> sbuf_all_, rbuf_all_; std::vector<size_t> seg_off_{ 0 };   // concatenated neighbour segments
    DevBuf<double> tmp_;
+   hipStream_t cs_ = nullptr; hipEvent_t ev_ready_ = nullptr, ev_done_ = nullptr;   // communication stream of halo_begin / halo_end
+   void exchange(const Partition& part, hipStream_t s);   // send buffers -> neighbours' receive buffers (RCCL grouped send/recv or loopback copies) on stream s
 };
 
 enum class Precond { IDENTITY, JACOBI };
@@ -128,6 +136,7 @@ class NonlinearMechOperator {
    bool records_setup_ = false;   // gradient records written by the constitutive launch (p = 1 fast path, identity preconditioner)
    bool use_records() const { return records_setup_ && precond == Precond::IDENTITY; }
    void ensure_mat_grad();
+   bool overlap_ = false; int nblk_bdr_ = 0;   // halo exchange overlapped with the interior element blocks (several ranks, atomic p = 1 record action)
    bool fast_p1_ = true, lvec_grad_ = true, fused_setup_ = true; bool lvec_resid_ = false; bool compact_tangent_ = false;
    bool cap_auto_ = true; int newton_cap_ = 0; double tail_cost_ = 4.0;
    DevBuf<double> tmp_l_, tmp_r_, el_y_, el_x2_;

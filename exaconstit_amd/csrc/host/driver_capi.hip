@@ -39,6 +39,17 @@ int exa_bootstrap(int* rank, int* nranks, void* uid128, char* err, int errlen) {
    return 0;
 }
 
+// latency floor of the two RCCL calls of a PCG iteration on this device (one-rank communicator): out2 = { us per 16-byte all-reduce,
+// us per grouped send/recv of n doubles to the own rank }; input of the scaling prediction in DESIGN.md section 7
+int exa_rccl_microbench(int iters, int n, double* out2, char* err, int errlen) {
+   try {
+      setenv("EXA_FORCE_RCCL", "1", 1);
+      Comm c; c.init(0, 1, nullptr);
+      c.microbench(iters, n, out2, out2 + 1);
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
 int exa_rccl_unique_id(void* out128) {
    try { Comm::get_unique_id(out128); return 0; } catch (const std::exception& e) { std::fprintf(stderr, "exa_rccl_unique_id: %s\n", e.what()); return -1; }
 }
@@ -252,6 +263,17 @@ int exa_partition_query(const int* N, int rank, int nranks, int64_t* info, int32
    const int order = (info[7] == 2) ? 2 : 1;   // info[7] is in/out: H1 order on input (0/1 -> 1), nodes per element on output
    p.build(N, L, rank, nranks, order);
    export_partition(p, info, conn, X, elem_gid, weight, nbr_rank, nbr_count, nbr_dofs);
+   return 0;
+}
+
+// the element order the driver runs with on several ranks (Partition::order_boundary_first): out2 = { E, E_bdr }; conn (n, E) and gid (E) may be null
+int exa_partition_query_boundary_first(const int* N, int rank, int nranks, int order, int64_t* out2, int32_t* conn, int64_t* elem_gid) {
+   Partition p; const double L[3] = { 1.0, 1.0, 1.0 };
+   p.build(N, L, rank, nranks, order == 2 ? 2 : 1);
+   p.order_boundary_first();
+   out2[0] = p.E; out2[1] = p.E_bdr;
+   if (conn) std::memcpy(conn, p.conn.data(), sizeof(int32_t) * p.conn.size());
+   if (elem_gid) std::memcpy(elem_gid, p.elem_gid.data(), sizeof(int64_t) * p.elem_gid.size());
    return 0;
 }
 

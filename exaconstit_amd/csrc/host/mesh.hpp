@@ -114,6 +114,31 @@ struct Partition {
       }
    }
 
+   // Elements that touch a node shared with another rank first (stable within the two groups).  The operator action then runs those
+   // blocks, hands the shared dofs to the halo exchange, and computes the interior elements while the exchange is on the wire
+   // ("easily overlapped with interior elements"; reference coupling sites src/mechanics_operator_ext.cpp:149-157).
+   // Everything per element (connectivity, global id, attribute) moves together; nothing else is indexed by local element number.
+   int E_bdr = 0;   // number of leading elements that touch shared nodes (0 until order_boundary_first ran, and on one rank)
+   void order_boundary_first() {
+      E_bdr = 0;
+      if (nbrs.empty() || E == 0) return;
+      std::vector<uint8_t> shared((size_t)NN, 0);
+      for (const Neighbor& nb : nbrs) for (int32_t d : nb.dofs) shared[(size_t)(d % NN)] = 1;
+      std::vector<int> perm; perm.reserve(E);
+      std::vector<uint8_t> isb((size_t)E, 0);
+      for (int e = 0; e < E; e++) { for (int a = 0; a < n; a++) if (shared[(size_t)conn[a + (size_t)n * e]]) { isb[e] = 1; break; } }
+      for (int e = 0; e < E; e++) if (isb[e]) perm.push_back(e);
+      E_bdr = (int)perm.size();
+      for (int e = 0; e < E; e++) if (!isb[e]) perm.push_back(e);
+      std::vector<int32_t> c2(conn.size()); std::vector<int64_t> g2(elem_gid.size()); std::vector<int> a2(elem_attr.size());
+      for (int e = 0; e < E; e++) {
+         for (int a = 0; a < n; a++) c2[a + (size_t)n * e] = conn[a + (size_t)n * perm[e]];
+         if (!elem_gid.empty()) g2[e] = elem_gid[perm[e]];
+         if (!elem_attr.empty()) a2[e] = elem_attr[perm[e]];
+      }
+      conn.swap(c2); elem_gid.swap(g2); elem_attr.swap(a2);
+   }
+
    // MFEM mesh v1.0 reader for trilinear hexahedra (what the reference gets from `Mesh(mesh_file, 1, 1, true)`, src/mechanics_driver.cpp:239-241;
    // format of workflows/Stage3/main_simulations/simulation.mesh): sections `dimension`, `elements` (attr geom=5 v0..v7, MFEM vertex order =
    // this repo's native order), `boundary` (attr geom=3 v0..v3), `vertices` with inline coordinates or a `nodes` grid function (H1 order 1).

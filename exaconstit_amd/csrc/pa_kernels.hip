@@ -211,8 +211,11 @@ __device__ __forceinline__ int64_t xcd_block(const unsigned b, const unsigned nb
 template <bool LVEC, bool GEO, bool CMP = false, bool TRANS = false>
 __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const double* __restrict__ pa, const double* __restrict__ x, double* __restrict__ y,
                                                           const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
-                                                          const double* __restrict__ gate, const double* __restrict__ coords, double* __restrict__ ev = nullptr) {
-   const int lane = threadIdx.x; const int64_t blk = xcd_block(blockIdx.x, gridDim.x); const int64_t e = blk * PA_BLK + lane;
+                                                          const double* __restrict__ gate, const double* __restrict__ coords, double* __restrict__ ev = nullptr,
+                                                          const int blk0 = 0) {
+   // blk0: first 64-element block of this launch (the multi-rank action runs the blocks that touch shared nodes first, then the interior
+   // ones while the halo exchange of the first part is on the wire: host/driver.hip, NonlinearMechOperator::GradMult)
+   const int lane = threadIdx.x; const int64_t blk = blk0 + xcd_block(blockIdx.x, gridDim.x); const int64_t e = blk * PA_BLK + lane;
    if (e >= E) return;
    if (gate != nullptr && gate[0] != 0.0) return;   // device-side "solver already converged" flag
    double X[3][8], Y[3][8];
@@ -615,11 +618,17 @@ int exa_launch_grad_setup_pa(exa_ctx* ctx, double dt, const double* J, const dou
 #undef GS_LAUNCH
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
-int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s, bool trans) {
-   const unsigned nb = nblk(ctx->E, PA_BLK);
+// blk0 / nblk_range: sub-range of the 64-element blocks (nblk_range < 0: all of them)
+int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s, bool trans, int blk0, int nblk_range) {
+   const unsigned nball = nblk(ctx->E, PA_BLK);
+   const bool ranged = nblk_range >= 0;
+   if (ranged && (!lvec || ctx->det || blk0 < 0 || (unsigned)(blk0 + nblk_range) > nball)) { ctx->err = "exa_launch_grad_apply_p1: block ranges are for the atomic L-vector action"; return EXA_ERR_ARG; }
+   const unsigned nb = ranged ? (unsigned)nblk_range : nball;
+   if (!ranged) blk0 = 0;
+   if (nb == 0) return EXA_OK;
    double* ev = nullptr;
    if (lvec && ctx->det) { if (int rc = exa_det_prepare(ctx)) return rc; ev = ctx->ev_det; }
-#define GA_LAUNCH(G, CM, T, REC, CRD) hipLaunchKernelGGL((k_grad_apply_p1<true, G, CM, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, REC, x, y, ctx->conn, ctx->nnodes, mask, gate, CRD, ev)
+#define GA_LAUNCH(G, CM, T, REC, CRD) hipLaunchKernelGGL((k_grad_apply_p1<true, G, CM, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, REC, x, y, ctx->conn, ctx->nnodes, mask, gate, CRD, ev, blk0)
    const double* none = nullptr;
    if (lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) GA_LAUNCH(true, true, false, ctx->pa_c, ctx->coords_lvec);   // D or D^T in the record
    else if (lvec && ctx->coords_lvec) { if (trans) GA_LAUNCH(true, false, true, ctx->pa, ctx->coords_lvec); else GA_LAUNCH(true, false, false, ctx->pa, ctx->coords_lvec); }

@@ -156,6 +156,7 @@ exa_driver_get_timers = _sig("exa_driver_get_timers", None, C.c_void_p, C.POINTE
 exa_driver_reset_timers = _sig("exa_driver_reset_timers", None, C.c_void_p)
 exa_driver_nfev_hist = _sig("exa_driver_nfev_hist", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_int)
 exa_driver_get_diagnostics = _sig("exa_driver_get_diagnostics", None, C.c_void_p, C.POINTER(C.c_int64))
+exa_rccl_microbench = _sig("exa_rccl_microbench", C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_bootstrap_env = _sig("exa_bootstrap_env", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 exa_bootstrap_bcast = _sig("exa_bootstrap_bcast", C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_char_p, C.c_int)
 exa_bootstrap = _sig("exa_bootstrap", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_char_p, C.c_int)
@@ -166,6 +167,7 @@ exa_driver_bench_pcg = _sig("exa_driver_bench_pcg", C.c_int, C.c_void_p, C.c_int
 exa_choose_newton_cap = _sig("exa_choose_newton_cap", C.c_int, C.POINTER(C.c_int), C.c_double)
 exa_options_query = _sig("exa_options_query", C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_mesh_partition_query = _sig("exa_mesh_partition_query", C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int)
+exa_partition_query_boundary_first = _sig("exa_partition_query_boundary_first", C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p)
 exa_partition_query = _sig("exa_partition_query", C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 
 

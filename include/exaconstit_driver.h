@@ -30,6 +30,9 @@ typedef struct {
 } exa_synth_config;
 
 int exa_rccl_unique_id(void* out128);
+/* latency floor of the RCCL calls of one PCG iteration on this device (one-rank communicator): out2 = { us per 16-byte all-reduce,
+ * us per grouped send/recv of n doubles to the own rank } */
+int exa_rccl_microbench(int iters, int n, double* out2, char* err, int errlen);
 /* Launcher-agnostic process-group bootstrap of the `mechanics` executable (reference: MPI_Init / MPI_Comm_rank / MPI_Comm_size,
  * src/mechanics_driver.cpp:119-150).  exa_bootstrap_env reads rank / size / local rank from the environment of mpirun (MPICH PMI_*,
  * Open MPI OMPI_COMM_WORLD_*), srun (SLURM_*), torchrun-style launchers (RANK / WORLD_SIZE / LOCAL_RANK) or EXA_RANK / EXA_NRANKS;
@@ -85,6 +88,9 @@ int exa_partition_query(const int* N, int rank, int nranks, int64_t* info8, int3
 /* the same view of the partition of an MFEM mesh v1.0 file (Mesh.type = "other"): every rank reads the file, elements are split by
  * recursive coordinate bisection of their centroids (reference: METIS through ParMesh, src/mechanics_driver.cpp:312), elem_gid = index
  * of the element in the file, nodes renumbered per rank in ascending global order.  Returns 0 or -1 (err). */
+/* The element order the driver runs with on several ranks: elements touching a node shared with another rank first (their 64-element
+ * blocks are computed before the halo exchange starts, the interior ones while it is on the wire).  out2 = { E, E_bdr }. */
+int exa_partition_query_boundary_first(const int* N, int rank, int nranks, int order, int64_t* out2, int32_t* conn, int64_t* elem_gid);
 int exa_mesh_partition_query(const char* mesh_path, int rank, int nranks, int64_t* info8, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
                              int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs, char* err, int errlen);
 #ifdef __cplusplus

@@ -55,6 +55,24 @@ def test_partitioned_run_matches_single_rank(oracle, tmp_path, case, nranks):
         assert list(st[0]) == list(ref[1][0])              # Newton iterations
 
 
+@pytest.mark.parametrize("case,nranks", [("voce_pa", 8), ("voce_ea", 4)])
+def test_halo_overlap_switch(oracle, tmp_path, monkeypatch, case, nranks):
+    """Several ranks: the action runs the element blocks that touch shared nodes first, starts the halo exchange on a second stream and
+    computes the interior blocks meanwhile (NonlinearMechOperator::GradMult, Comm::halo_begin / halo_end).  EXA_HALO_OVERLAP=off runs
+    the plain sequence (whole action, then exchange) on the same boundary-first element order: same Newton history, same averages."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    toml = os.path.join(orc.REFDATA, case + ".toml")
+    ref = _run_ranks(L, toml, 1, 5, tmp_path / "r1")[0]
+    on = _run_ranks(L, toml, nranks, 5, tmp_path / "on")
+    monkeypatch.setenv("EXA_HALO_OVERLAP", "off")
+    off = _run_ranks(L, toml, nranks, 5, tmp_path / "off")
+    for (s, st), (s2, st2) in zip(on, off):
+        assert np.max(np.abs(s - s2)) < 1e-10 * np.abs(s).max()
+        assert list(st[0]) == list(st2[0]) == list(ref[1][0])
+        assert np.max(np.abs(s - ref[0])) < 1e-9 * np.abs(ref[0]).max()
+
+
 def test_partitioned_order2_bbar_matches_single_rank(oracle, tmp_path):
     """BASELINE config 5 ingredients (p = 2, B-bar, element assembly, NRLS) on 2 and 4 ranks vs one rank."""
     import exaconstit_amd.lib as L

@@ -221,3 +221,34 @@ def test_bootstrap_without_launcher():
         assert L.exa_bootstrap_env(C.byref(r), C.byref(n), C.byref(l)) != 0      # rank outside the group
     finally:
         os.environ.pop("EXA_RANK", None); os.environ.pop("EXA_NRANKS", None); os.environ.update(saved)
+
+
+@pytest.mark.parametrize("nranks", [2, 8, 12])
+def test_boundary_first_element_order(nranks):
+    """Several ranks: the driver permutes its local elements so that those touching a node shared with another rank come first
+    (Partition::order_boundary_first) - the operator action computes these blocks, starts the halo exchange and overlaps it with the
+    interior blocks.  The permutation keeps the set of elements, and the split is exact."""
+    import ctypes as C
+    import exaconstit_amd.lib as L
+    N = (8, 8, 12)
+    Nc = (C.c_int * 3)(*N)
+    for r in range(nranks):
+        base = pu.query(N, r, nranks)
+        out = (C.c_int64 * 2)()
+        conn = np.zeros(8 * base["E"], np.int32); gid = np.zeros(base["E"], np.int64)
+        assert L.exa_partition_query_boundary_first(Nc, r, nranks, 1, out, conn.ctypes.data_as(C.c_void_p), gid.ctypes.data_as(C.c_void_p)) == 0
+        E, Eb = out[0], out[1]
+        assert E == base["E"] and sorted(gid.tolist()) == sorted(base["gid"].tolist())
+        shared = np.zeros(base["NN"], bool)
+        for _, dofs in base["nbrs"]:
+            shared[dofs % base["NN"]] = True
+        touches = shared[conn.reshape(E, 8)].any(axis=1)
+        assert touches[:Eb].all() and not touches[Eb:].any() and 0 < Eb < E
+        # connectivity rows moved with their elements
+        lookup = {int(g): base["conn"][i] for i, g in enumerate(base["gid"])}
+        assert all(np.array_equal(conn.reshape(E, 8)[i], lookup[int(g)]) for i, g in enumerate(gid))
+        # stable: the original relative order is kept inside both groups
+        pos = {int(g): i for i, g in enumerate(base["gid"])}
+        for seg in (gid[:Eb], gid[Eb:]):
+            p = [pos[int(g)] for g in seg]
+            assert p == sorted(p)
