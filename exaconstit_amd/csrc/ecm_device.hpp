@@ -108,6 +108,7 @@ struct MatParams {
    int xn_int;              // 1/m - 1 when it is a small integer (m = 0.02 -> 49): power by repeated multiplication, else 0
    double qsign;            // +1 FCC, -1 BCC: sign of the plastic-spin vectors
    double kd0, kd2;         // Kirchhoff' = diag(kd0,kd0,kd2,kd2,kd2) e'
+   double ikd0, ikd2;       // their reciprocals (host-computed: the Newton step would otherwise divide by them in every sweep)
    double bulk, gmod, gamma, tK0, dtde, tol;
    // Voce power law
    double xnn, xn, gam_w, h0, tausi, taus0, xmprime, xms, gamss0, t_min, t_max;
@@ -220,13 +221,39 @@ ECM_DI void voce_gdot(const MatParams& mp, double g_i, double tau, double& gdot,
    }
 }
 
+// |t|^E for the 12 systems with the exponent known at compile time: the square-and-multiply chain fully unrolled (x^49 = 7 multiplications
+// per system, no loop, no exponent bits in registers).  The usual rate sensitivities m = 0.1, 0.05, 0.02, 0.01 give E = 1/m - 1 = 9, 19, 49, 99;
+// any other integer exponent takes the rolled loop below, non-integers exp(xn log|t|).  Same multiplication order as the loop: same bits.
+template <int E>
+ECM_DI void pow12_ct(const double tf[NSLIP], double pw[NSLIP]) {
+   static_assert(E >= 1, "positive exponent");
+   double b[NSLIP];
+#pragma unroll
+   for (int a = 0; a < NSLIP; a++) { b[a] = fabs(tf[a]); pw[a] = 1.0; }
+#pragma unroll
+   for (int e = E; e; e >>= 1) {
+      if (e & 1) {
+#pragma unroll
+         for (int a = 0; a < NSLIP; a++) pw[a] *= b[a];
+      }
+      if (e >> 1) {
+#pragma unroll
+         for (int a = 0; a < NSLIP; a++) b[a] *= b[a];
+      }
+   }
+}
+
 // Voce power law for all 12 systems at once (independent chains -> the FP64 pipeline stays full).  WITHD: also d gdot / d tau.
 template <bool WITHD, bool CUT>
 ECM_DI void voce_gdot12(const MatParams& mp, double g_i, const double tau[NSLIP], double gd[NSLIP], double dg[NSLIP]) {
    double tf[NSLIP], pw[NSLIP];
 #pragma unroll
    for (int a = 0; a < NSLIP; a++) tf[a] = tau[a] * g_i;
-   if (mp.xn_int > 0) {
+   if (mp.xn_int == 49) pow12_ct<49>(tf, pw);
+   else if (mp.xn_int == 99) pow12_ct<99>(tf, pw);
+   else if (mp.xn_int == 19) pow12_ct<19>(tf, pw);
+   else if (mp.xn_int == 9) pow12_ct<9>(tf, pw);
+   else if (mp.xn_int > 0) {
       double b[NSLIP];
 #pragma unroll
       for (int a = 0; a < NSLIP; a++) { pw[a] = 1.0; b[a] = fabs(tf[a]); }
@@ -444,6 +471,12 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 // The rotation data of an evaluation (Tr, d_lat, w_lat) is never live across one and stays in registers (struct Jac).  Rule measured
 // on MI355X: inside a thread's lifetime nothing written to global memory is still in L2 when it is read back, and a reload waits for
 // every earlier store of the wave (vmcnt), so anything that must survive the Newton loop belongs in LDS, not in global memory.
+#ifndef ECM_DEFER_DIS
+#define ECM_DEFER_DIS 0   // Voce: dissipation / effective shear rate from the converged point only (voce_slip_rates)
+#endif
+#ifndef ECM_SWEEP_UNROLL
+#define ECM_SWEEP_UNROLL 0   // block Gauss-Seidel sweeps of the Newton step rolled (1: unrolled; A/B on MI355X)
+#endif
 #ifndef ECM_STASH_STRIDE
 #define ECM_STASH_STRIDE 256
 #endif
@@ -517,8 +550,9 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       }
       }
       voce_gdot12<WITHJ, false>(mp, g_i, tau, gd, dg);
+      // the dissipation rate is an output of the converged point only: voce_slip_rates computes it there (12 FMAs fewer per evaluation)
 #pragma unroll
-      for (int a = 0; a < NSLIP; a++) { dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
+      for (int a = 0; a < NSLIP; a++) { if (!ECM_DEFER_DIS) dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
       ok = isfinite(shr);   // any non-finite rate poisons the sum
       if (ECM_SLIP_FORMS_CSE) {
          double dps[5], wps[3];
@@ -744,7 +778,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 }
 
 // slip rates at the converged point (Voce family): written once, instead of one global store per system and evaluation
-ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out) {
+ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out, double& dis_rate, double& shrate) {
    const double ks[5] = { PSC[0] * mp.kd0 * e_f[0], PSC[1] * mp.kd0 * e_f[1], PSC[2] * mp.kd2 * e_f[2], PSC[3] * mp.kd2 * e_f[3], PSC[4] * mp.kd2 * e_f[4] };
    double tau[NSLIP], gd[NSLIP];
    if (ECM_SLIP_FORMS_CSE) slip_tau12(ks, tau);
@@ -758,8 +792,10 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
    }
    }
    voce_gdot12<false, true>(mp, pb.g_i, tau, gd, nullptr);
+   double dis = 0.0, shr = 0.0;
 #pragma unroll
-   for (int a = 0; a < NSLIP; a++) stg(&gdot_out[a * pb.gs], gd[a]);
+   for (int a = 0; a < NSLIP; a++) { stg(&gdot_out[a * pb.gs], gd[a]); dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
+   if (ECM_DEFER_DIS) { dis_rate = dis * pb.detV_ri; shrate = shr; }   // (rates below t_min = (1e-60)^m count as 0 here: below 1e-60 of the reference rate)
 }
 
 // ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
@@ -823,7 +859,7 @@ ECM_DI bool rot_block_inverse(const Prob& pb, const Jac& J, double Ri[9]) {
 }
 
 ECM_DI void jac_factor(const MatParams& mp, const Prob& pb, Jac& J, Fact& F) {
-   const double kdi0 = pb.dt_ri / mp.kd0, kdi2 = pb.dt_ri / mp.kd2;
+   const double kdi0 = pb.dt_ri * mp.ikd0, kdi2 = pb.dt_ri * mp.ikd2;
    J.A[sidx(0, 0)] += kdi0; J.A[sidx(1, 1)] += kdi0; J.A[sidx(2, 2)] += kdi2; J.A[sidx(3, 3)] += kdi2; J.A[sidx(4, 4)] += kdi2;
    bool ok = true;
 #pragma unroll
@@ -858,7 +894,7 @@ ECM_DI void jee_solve(const MatParams& mp, const Jac& J, double b[5]) {
    for (int k = 4; k >= 0; k--)
 #pragma unroll
       for (int j = k + 1; j < 5; j++) b[k] -= J.A[sidx(k, j)] * b[j];
-   const double i0 = 1.0 / mp.kd0, i2 = 1.0 / mp.kd2;
+   const double i0 = mp.ikd0, i2 = mp.ikd2;
    b[0] *= i0; b[1] *= i0; b[2] *= i2; b[3] *= i2; b[4] *= i2;
 }
 
@@ -920,7 +956,11 @@ ECM_DI void jac_solve(const MatParams& mp, const Prob& pb, const Jac& J, const F
       for (int i = 0; i < 3; i++) xr[i] = F.Ri[3 * i] * rhs[5] + F.Ri[3 * i + 1] * rhs[6] + F.Ri[3 * i + 2] * rhs[7];
    }
    double xe[5];
+#if ECM_SWEEP_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
    for (int sweep = 0; sweep < NSWEEP; sweep++) {
       double t[5]; jer_mult(J, xr, t);
 #pragma unroll
@@ -940,6 +980,7 @@ ECM_DI void jac_solve(const MatParams& mp, const Prob& pb, const Jac& J, const F
 }
 
 ECM_DI double norm8(const double v[8]) { double s = 0; for (int i = 0; i < 8; i++) s += v[i] * v[i]; return sqrt(s); }
+ECM_DI double norm8sq(const double v[8]) { double s = 0; for (int i = 0; i < 8; i++) s += v[i] * v[i]; return s; }
 
 // ------------------------------------------------------------------------------------------------------------
 // one quadrature point: reference kernel_setup -> getResponseECM -> kernel_postprocessing, fused
@@ -1018,8 +1059,12 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    double* gdot_out = kin_is_km(KIN) ? sv1 + H_GDOT * QS : nullptr;
    int nfev = 1; bool conv = false;
    bool ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);
-   double res_0 = norm8(r);
-   if (ok && res_0 < mp.tol) conv = true;
+   // Norms are carried SQUARED: the common iteration (full Newton step inside the trust region) only compares them - |r| < tol, |dx| <= delta,
+   // |r_new| > 0.65 |r_old| (SNLS: rho = actual / predicted < 0.35 with predicted = -|r_old|), |r_new| > |r_old| - and the two square roots per
+   // iteration (~20 instructions each in FP64) are only taken on the dog-leg path, which needs the values.
+   const double tol2 = mp.tol * mp.tol;
+   double res2_0 = norm8sq(r);
+   if (ok && res2_0 < tol2) conv = true;
    if (ok && !conv) {
       double delta = 1.0;
       for (int it = 0; it < 200; it++) {
@@ -1029,16 +1074,17 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          // Newton step first; the steepest-descent data (grad = Js^T r, Jg = Js grad) only when the step leaves the trust region
          double nr[8], t[8];
          jac_factor(mp, pb, J, F);
-         double nr2norm;
+         double nr2sq;
          if (F.ok) {
             double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i] * pb.sc_i;
             jac_solve<false, 2>(mp, pb, J, F, rhs, t);
             for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? pb.esc_i : (1.0 / R_SCALE));
-            nr2norm = norm8(nr);
-         } else { nr2norm = 1e300; for (int i = 0; i < 8; i++) nr[i] = 0; }
+            nr2sq = norm8sq(nr);
+         } else { nr2sq = 1e300; for (int i = 0; i < 8; i++) nr[i] = 0; }
          double delx[8], pred_resid; bool use_nr = false;
-         if (nr2norm <= delta) { use_nr = true; for (int i = 0; i < 8; i++) delx[i] = nr[i]; pred_resid = 0.0; }
+         if (nr2sq <= delta * delta) { use_nr = true; for (int i = 0; i < 8; i++) delx[i] = nr[i]; pred_resid = 0.0; }
          else {
+            const double res_0 = sqrt(res2_0);
             double grad[8], u[8];
             jac_mult_T(mp, pb, J, r, t);
             for (int i = 0; i < 8; i++) { const double cs = (i < 5) ? pb.esc : R_SCALE; grad[i] = pb.sc * cs * t[i]; u[i] = cs * grad[i]; }
@@ -1069,17 +1115,23 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          bool reject;
          if (!ok) { reject = true; delta = fmax(delta * 0.25, 1e-12); }
          else {
-            const double res = norm8(r);
-            if (res < mp.tol) { conv = true; break; }
-            const double actual = res - res_0, pred = pred_resid - res_0;
-            if (pred == 0.0) delta = fmin(delta * 1.5, 1e4);
-            else {
-               const double rho = actual / pred;
-               if (rho > 0.75 && actual < 0.0 && !use_nr) delta = fmin(delta * 1.5, 1e4);
-               else if (rho < 0.35) delta = fmax(delta * 0.25, 1e-12);
+            const double res2 = norm8sq(r);
+            if (res2 < tol2) { conv = true; break; }
+            if (use_nr) {      // predicted residual 0: rho = 1 - |r| / |r_old| (never > 0.75 with a smaller residual AND a dog-leg step: no growth)
+               if (res2_0 == 0.0) delta = fmin(delta * 1.5, 1e4);
+               else if (res2 > (0.65 * 0.65) * res2_0) delta = fmax(delta * 0.25, 1e-12);
+            } else {
+               const double res = sqrt(res2), res_0 = sqrt(res2_0);
+               const double actual = res - res_0, pred = pred_resid - res_0;
+               if (pred == 0.0) delta = fmin(delta * 1.5, 1e4);
+               else {
+                  const double rho = actual / pred;
+                  if (rho > 0.75 && actual < 0.0) delta = fmin(delta * 1.5, 1e4);
+                  else if (rho < 0.35) delta = fmax(delta * 0.25, 1e-12);
+               }
             }
-            reject = (actual > 0.0);
-            if (!reject) res_0 = res;
+            reject = (res2 > res2_0);
+            if (!reject) res2_0 = res2;
          }
          if (reject) {
             for (int i = 0; i < 8; i++) x[i] = ECM_ST(st, ST_XS + i);
@@ -1119,12 +1171,12 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       const double vNew = ECM_CD(CD_VNEW);
       double eNew = ECM_CD(CD_ENEW);
       { double wrk = 0; for (int k = 0; k < 5; k++) wrk += (ECM_CD(CD_SOLD + k) + s_sm[k]) * ECM_CD(CD_DSM + k); eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * wrk; }
+      if constexpr (!kin_is_km(KIN)) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS, dis_rate, shrate);
       stg(&sv1[(H_SHRATE) * QS], shrate);
       stg(&sv1[(H_SHR) * QS], ldg(&sv0[(H_SHR) * QS]) + shrate * dt);
       stg(&sv1[(H_FLOW) * QS], ((ECM_CD(CD_DEFF) > TINY_SQRT) ? dis_rate * dt : 0.0) + ldg(&sv0[(H_FLOW) * QS]));   // accumulated plastic work
       stg(&sv1[(H_NFEV) * QS], (double)nfev);
       { const double a_V = E_SCALE * pb.esc_i; for (int i = 0; i < 5; i++) stg(&sv1[(H_E + i) * QS], e_f[i] * a_V); }   // state e = a_V E
-      if constexpr (!kin_is_km(KIN)) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS);
       stg(&sv1[(H_H) * QS], ECM_CD(CD_HU));
       stg(&sv1[(IND_VOL) * QS], vNew); stg(&sv1[(IND_EINT) * QS], eNew);
       const double pNew = mp.bulk * (1.0 / vNew - 1.0) + mp.gamma * eNew;
@@ -1152,7 +1204,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          {
             double dl[5]; load_dl(J, dl);
             double Md[5][3]; m35(dl, Md);
-            const double kdi0 = pb.dt_ri / mp.kd0, kdi2 = pb.dt_ri / mp.kd2;
+            const double kdi0 = pb.dt_ri * mp.ikd0, kdi2 = pb.dt_ri * mp.ikd2;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                double E[3];
