@@ -471,6 +471,9 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 // The rotation data of an evaluation (Tr, d_lat, w_lat) is never live across one and stays in registers (struct Jac).  Rule measured
 // on MI355X: inside a thread's lifetime nothing written to global memory is still in L2 when it is read back, and a reload waits for
 // every earlier store of the wave (vmcnt), so anything that must survive the Newton loop belongs in LDS, not in global memory.
+#ifndef ECM_TANGENT_FIRST
+#define ECM_TANGENT_FIRST 1   // epilogue order: tangent before the state / stress outputs (see point_update)
+#endif
 #ifndef ECM_DEFER_DIS
 #define ECM_DEFER_DIS 0   // Voce: dissipation / effective shear rate from the converged point only (voce_slip_rates)
 #endif
@@ -480,9 +483,13 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #ifndef ECM_STASH_STRIDE
 #define ECM_STASH_STRIDE 256
 #endif
-constexpr int ST_EN = 0, ST_DN = 5, ST_WN = 10, ST_XS = 13, ST_CD = 21, ST_SLOTS = 38;   // ST_XS: restore copy of the unknowns; ST_CD: parking slots
-constexpr int ST_NCD = ST_SLOTS - ST_CD;
-constexpr int CD_DSM = 0, CD_SOLD = 5, CD_QN = 10, CD_VOLD = 14, CD_VNEW = 15, CD_ENEW = 16, CD_DEFF = 17, CD_BULK = 18, CD_HU = 19, CD_TSC = 20;
+constexpr int ST_EN = 0, ST_DN = 5, ST_WN = 10, ST_XS = 13, ST_CD = 21, ST_PB = 33, ST_SLOTS = 38;   // ST_XS: restore copy of the unknowns; ST_CD: parking slots; ST_PB: rarely used scalars of the point problem
+constexpr int PB_SCI = 0, PB_ESCI = 1, PB_DETVRI = 2;   // 1/sc, 1/esc, 1/detV: read once per Newton step / in the epilogue only
+constexpr int ST_NCD = ST_PB - ST_CD;
+// (the deviatoric stress work of the step needs D' and the old stress only through  sum (s_old + s_new) . D' = s_old . D' + s_lat . d_lat:
+//  the first scalar is parked, the second uses the lattice-frame D' of the converged evaluation - 10 slots fewer than parking both vectors)
+constexpr int CD_QN = 0, CD_VOLD = 4, CD_VNEW = 5, CD_ENEW = 6, CD_DEFF = 7, CD_BULK = 8, CD_HU = 9, CD_TSC = 10, CD_WRKOLD = 11;
+static_assert(CD_WRKOLD < ST_NCD, "every parked value lives in the LDS stash");
 #define ECM_ST(p, slot) (p)[(slot) * ECM_STASH_STRIDE]
 // compiler-only barrier: what was parked must be re-loaded later instead of being kept alive in registers
 #define ECM_PARK_BARRIER() asm volatile("" ::: "memory")
@@ -495,8 +502,8 @@ constexpr int CD_DSM = 0, CD_SOLD = 5, CD_QN = 10, CD_VOLD = 14, CD_VNEW = 15, C
 // solve everything is in terms of E and x only needs the factor esc = E_SCALE / a_V (oracle/ecmech_port.hpp, struct Problem)
 // ------------------------------------------------------------------------------------------------------------
 struct Prob {
-   double dt_ri, detV_ri, sc, sc_i, g_i;   // sc = epsdot_scale_inv, sc_i = 1/sc, g_i = 1/g
-   double esc, esc_i;                      // E_SCALE / a_V and its inverse
+   double dt_ri, sc, g_i;                  // sc = epsdot_scale_inv, g_i = 1/g   (1/sc, 1/esc, 1/detV: stash slots ST_PB + PB_*)
+   double esc;                             // E_SCALE / a_V
    double* st;                             // per-thread stash
    const double* pqt;                      // Kocks-Mecking: slip table in LDS (12 rows of 8), nullptr -> PQ_TAB in global memory
    int gs;                                 // stride of the slip-rate outputs (1 or 64, see point_update's QS)
@@ -737,7 +744,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       ok = isfinite(shr);
    }
    }
-   dis_rate = dis * pb.detV_ri; shrate = shr;
+   dis_rate = dis; shrate = shr;   // (un-scaled: the caller divides the converged value by detV)
    if (WITHJ && mp.qsign < 0.0) {
 #pragma unroll
       for (int i = 0; i < 3; i++)
@@ -795,7 +802,7 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
    double dis = 0.0, shr = 0.0;
 #pragma unroll
    for (int a = 0; a < NSLIP; a++) { stg(&gdot_out[a * pb.gs], gd[a]); dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
-   if (ECM_DEFER_DIS) { dis_rate = dis * pb.detV_ri; shrate = shr; }   // (rates below t_min = (1e-60)^m count as 0 here: below 1e-60 of the reference rate)
+   if (ECM_DEFER_DIS) { dis_rate = dis * ECM_ST(pb.st, ST_PB + PB_DETVRI); shrate = shr; }   // (rates below t_min = (1e-60)^m count as 0 here: below 1e-60 of the reference rate)
 }
 
 // ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
@@ -1027,13 +1034,15 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       double shrate_o = 0; for (int a = 0; a < NSLIP; a++) shrate_o += fabs(ldg(&sv0[(H_GDOT + a) * QS]));
       const double h_u = kin_update_h<KIN>(mp, ldg(&sv0[(H_H) * QS]), dt, shrate_o);
       // ---- point problem set-up
-      pb.detV_ri = 1.0 / vNew;
+      const double detV_ri = 1.0 / vNew; ECM_ST(st, ST_PB + PB_DETVRI) = detV_ri;
       const double a_V_ri = 1.0 / cbrt(vNew);
-      pb.esc = E_SCALE * a_V_ri; pb.esc_i = 1.0 / pb.esc;
+      pb.esc = E_SCALE * a_V_ri; ECM_ST(st, ST_PB + PB_ESCI) = 1.0 / pb.esc;
       double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += ldg(&sv0[(H_Q + i) * QS]) * ldg(&sv0[(H_Q + i) * QS]); const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = ldg(&sv0[(H_Q + i) * QS]) * ni; }
       double Cn[9]; quat_to_mat(qn, Cn);
       double dn[5]; rot_vecd_T(Cn, d_sm, dn);
-      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = ldg(&sv0[(H_E + i) * QS]) * a_V_ri; ECM_CD(CD_DSM + i) = d_sm[i]; ECM_CD(CD_SOLD + i) = s_old[i]; }
+      double wrk_old = 0.0;
+      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = ldg(&sv0[(H_E + i) * QS]) * a_V_ri; wrk_old += s_old[i] * d_sm[i]; }
+      ECM_CD(CD_WRKOLD) = wrk_old;
       for (int i = 0; i < 3; i++) ECM_ST(st, ST_WN + i) = Cn[i] * w_sm[0] + Cn[3 + i] * w_sm[1] + Cn[6 + i] * w_sm[2];
       for (int i = 0; i < 4; i++) ECM_CD(CD_QN + i) = qn[i];
       ECM_CD(CD_VOLD) = vOld; ECM_CD(CD_VNEW) = vNew; ECM_CD(CD_ENEW) = eNew; ECM_CD(CD_DEFF) = dEff; ECM_CD(CD_BULK) = bulkNew; ECM_CD(CD_HU) = h_u;
@@ -1044,12 +1053,22 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          pb.kv.g = mp.go + mp.s * sq; pb.kv.gam_w = mp.gam_wo / sq; pb.kv.gam_r = mp.gam_ro * sq * sq; pb.kv.c_e = (mp.c_1 / tK) * mp.mu_ref;
          adots_ref = pb.kv.gam_w;
       } else { pb.kv.g = h_u; pb.kv.gam_w = mp.gam_w; pb.kv.gam_r = 0; pb.kv.c_e = 0; adots_ref = mp.gam_w; }
-      if (dnorm < EPS_SQRT * adots_ref) { pb.sc_i = adots_ref; pb.sc = 1.0 / adots_ref; }
-      else { pb.sc = fmin(1.0 / dnorm, 1.0e6 * dt); pb.sc_i = 1.0 / pb.sc; }
+      if (dnorm < EPS_SQRT * adots_ref) { ECM_ST(st, ST_PB + PB_SCI) = adots_ref; pb.sc = 1.0 / adots_ref; }
+      else { pb.sc = fmin(1.0 / dnorm, 1.0e6 * dt); ECM_ST(st, ST_PB + PB_SCI) = 1.0 / pb.sc; }
       pb.g_i = 1.0 / pb.kv.g;
    }
    ECM_PARK_BARRIER();
 
+#ifdef ECM_EXP_IO_ONLY   // timing experiment only: the launch's memory traffic without the constitutive arithmetic
+   {
+      double acc = 0.0;
+      for (int i = 0; i < NSTATEV; i++) { const double v = ldg(&sv0[i * QS]); acc += v; stg(&sv1[i * QS], v + L[i % 9]); }
+      for (int i = 0; i < 6; i++) stg(&s1[i * QS], ldg(&s0[i * QS]) + acc);
+      if (REC) { double2* rc = reinterpret_cast<double2*>(cmat); for (int pr = 0; pr < 13; pr++) rc[pr * 64] = make_double2(acc + pr, tsc); }
+      else for (int i = 0; i < 36; i++) stg(&cmat[i * QS], acc + i);
+      return 0;
+   }
+#endif
    // ---- trust-region dog-leg Newton (SNLS "TrDlDenseG" defaults).  Every evaluation leaves (r, J, slip rates, dissipation) of
    // the point it was asked for; a rejected trial is followed by a re-evaluation at the restored point (rare), so nothing but x
    // and a few scalars has to survive an evaluation and the converged evaluation doubles as the one the tangent needs.
@@ -1065,6 +1084,9 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    const double tol2 = mp.tol * mp.tol;
    double res2_0 = norm8sq(r);
    if (ok && res2_0 < tol2) conv = true;
+#ifdef ECM_EXP_SKIP_SOLVE   // timing experiment only (scripts/tune_model.sh): no Newton iterations, the rest of the launch unchanged
+   conv = true;
+#endif
    if (ok && !conv) {
       double delta = 1.0;
       for (int it = 0; it < 200; it++) {
@@ -1076,9 +1098,11 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          jac_factor(mp, pb, J, F);
          double nr2sq;
          if (F.ok) {
-            double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i] * pb.sc_i;
+            const double sc_i = ECM_ST(st, ST_PB + PB_SCI);
+            double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i] * sc_i;
             jac_solve<false, 2>(mp, pb, J, F, rhs, t);
-            for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? pb.esc_i : (1.0 / R_SCALE));
+            const double esc_i = ECM_ST(st, ST_PB + PB_ESCI);
+            for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? esc_i : (1.0 / R_SCALE));
             nr2sq = norm8sq(nr);
          } else { nr2sq = 1e300; for (int i = 0; i < 8; i++) nr[i] = 0; }
          double delx[8], pred_resid; bool use_nr = false;
@@ -1144,7 +1168,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    double e_f[5], xi[3];
    for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(st, ST_EN + i) + x[i] * pb.esc;
    for (int i = 0; i < 3; i++) xi[i] = x[5 + i] * R_SCALE;
-   double Cf[9];
+   double Cf[9], qout[4];
    {
       const double qn[4] = { ECM_CD(CD_QN), ECM_CD(CD_QN + 1), ECM_CD(CD_QN + 2), ECM_CD(CD_QN + 3) };
       double qf[4];
@@ -1160,30 +1184,41 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       quat_to_mat(qf, Cf);
       double dq = 0; for (int i = 0; i < 4; i++) dq += qf[i] * qn[i];
       const double sg = dq < 0 ? -1.0 : 1.0;
-      for (int i = 0; i < 4; i++) stg(&sv1[(H_Q + i) * QS], sg * qf[i]);
+      for (int i = 0; i < 4; i++) qout[i] = sg * qf[i];
    }
-   const double kdj[5] = { mp.kd0 * pb.detV_ri, mp.kd0 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri, mp.kd2 * pb.detV_ri };
+   const double detV_ri = ECM_ST(st, ST_PB + PB_DETVRI);
+   dis_rate *= detV_ri;   // per current volume
+   const double kdj[5] = { mp.kd0 * detV_ri, mp.kd0 * detV_ri, mp.kd2 * detV_ri, mp.kd2 * detV_ri, mp.kd2 * detV_ri };
    double s_lat[5];
    for (int i = 0; i < 5; i++) s_lat[i] = kdj[i] * e_f[i];
    const double bulkNew = ECM_CD(CD_BULK);
-   {
+   // The tangent goes FIRST (ECM_TANGENT_FIRST): it is the only consumer of the 47 Jacobian values of the converged evaluation, so they die
+   // before the state / stress outputs are computed instead of being carried (and spilled) through them; and no scratch reload of the
+   // tangent arithmetic has to wait behind the 34 output stores (on gfx9 a reload waits for every earlier store of the wave).  The two
+   // parked values the outputs need from the slot the tangent overwrites are read before.
+   const double hu_keep = ECM_CD(CD_HU), deff_keep = ECM_CD(CD_DEFF);
+   double wrk_new = 0.0;   // s_new . D' in the lattice frame of the converged evaluation (the inner product of the 5-vectors is frame-invariant)
+   for (int k = 0; k < 5; k++) wrk_new += s_lat[k] * J.dl[k];
+   auto write_state = [&]() {
+      for (int i = 0; i < 4; i++) stg(&sv1[(H_Q + i) * QS], qout[i]);
       double s_sm[5]; rot_vecd(Cf, s_lat, s_sm);
       const double vNew = ECM_CD(CD_VNEW);
       double eNew = ECM_CD(CD_ENEW);
-      { double wrk = 0; for (int k = 0; k < 5; k++) wrk += (ECM_CD(CD_SOLD + k) + s_sm[k]) * ECM_CD(CD_DSM + k); eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * wrk; }
+      eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * (ECM_CD(CD_WRKOLD) + wrk_new);
       if constexpr (!kin_is_km(KIN)) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS, dis_rate, shrate);
       stg(&sv1[(H_SHRATE) * QS], shrate);
       stg(&sv1[(H_SHR) * QS], ldg(&sv0[(H_SHR) * QS]) + shrate * dt);
-      stg(&sv1[(H_FLOW) * QS], ((ECM_CD(CD_DEFF) > TINY_SQRT) ? dis_rate * dt : 0.0) + ldg(&sv0[(H_FLOW) * QS]));   // accumulated plastic work
+      stg(&sv1[(H_FLOW) * QS], ((deff_keep > TINY_SQRT) ? dis_rate * dt : 0.0) + ldg(&sv0[(H_FLOW) * QS]));   // accumulated plastic work
       stg(&sv1[(H_NFEV) * QS], (double)nfev);
-      { const double a_V = E_SCALE * pb.esc_i; for (int i = 0; i < 5; i++) stg(&sv1[(H_E + i) * QS], e_f[i] * a_V); }   // state e = a_V E
-      stg(&sv1[(H_H) * QS], ECM_CD(CD_HU));
+      { const double a_V = E_SCALE * ECM_ST(st, ST_PB + PB_ESCI); for (int i = 0; i < 5; i++) stg(&sv1[(H_E + i) * QS], e_f[i] * a_V); }   // state e = a_V E
+      stg(&sv1[(H_H) * QS], hu_keep);
       stg(&sv1[(IND_VOL) * QS], vNew); stg(&sv1[(IND_EINT) * QS], eNew);
       const double pNew = mp.bulk * (1.0 / vNew - 1.0) + mp.gamma * eNew;
       const double t1 = SQR2I * s_sm[0], t2 = SQR6I * s_sm[1];
       stg(&s1[(0) * QS], t1 - t2 - pNew); stg(&s1[(1) * QS], -t1 - t2 - pNew); stg(&s1[(2) * QS], SQR2B3 * s_sm[1] - pNew);
       stg(&s1[(3) * QS], SQR2I * s_sm[4]); stg(&s1[(4) * QS], SQR2I * s_sm[3]); stg(&s1[(5) * QS], SQR2I * s_sm[2]);
-   }
+   };
+   if (!ECM_TANGENT_FIRST) write_state();
 #ifndef ECM_NO_TANGENT
    // ---- tangent (last: it overwrites the parking area): lattice-frame d sigma'/d D' by implicit differentiation on the converged
    // factorisation, rotated to the sample frame, then to Voigt (engineering shear) + bulk term, column-major
@@ -1236,7 +1271,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
 #pragma unroll
                for (int j = 0; j < 3; j++) H[j] = Ms[k][0] * Tr[j] + Ms[k][1] * Tr[3 + j] + Ms[k][2] * Tr[6 + j];
 #pragma unroll
-               for (int j = 0; j < 5; j++) Kt[k][j] = ((k == j) ? pb.detV_ri : 0.0) + H[0] * G[0][j] + H[1] * G[1][j] + H[2] * G[2][j];
+               for (int j = 0; j < 5; j++) Kt[k][j] = ((k == j) ? detV_ri : 0.0) + H[0] * G[0][j] + H[1] * G[1][j] + H[2] * G[2][j];
             }
          }
 #pragma unroll
@@ -1292,8 +1327,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          double2* rc = reinterpret_cast<double2*>(cmat);
 #pragma unroll
          for (int pr = 0; pr < 13; pr++) rc[pr * 64] = make_double2(Dm[2 * pr], Dm[2 * pr + 1]);
-         return (conv && ok) ? 0 : 1;
-      }
+      } else {
       const double dti = pb.dt_ri * (okT ? 1.0 : 0.0);
 #pragma unroll
       for (int k = 0; k < 5; k++) {
@@ -1319,8 +1353,10 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          stg(&cmat[(0 + 6 * j) * QS], t1 - t2 + bk); stg(&cmat[(1 + 6 * j) * QS], -t1 - t2 + bk); stg(&cmat[(2 + 6 * j) * QS], SQR2B3 * T2[1] + bk);
          stg(&cmat[(3 + 6 * j) * QS], SQR2I * T2[4]); stg(&cmat[(4 + 6 * j) * QS], SQR2I * T2[3]); stg(&cmat[(5 + 6 * j) * QS], SQR2I * T2[2]);
       }
+      }
    }
 #endif
+   if (ECM_TANGENT_FIRST) write_state();
    return (conv && ok) ? 0 : 1;
 }
 
