@@ -174,7 +174,8 @@ def test_auto_time_stepping_case_rows_with_inferred_steps(oracle):
 
 @pytest.mark.xfail(reason="OPEN: thermally activated Kocks-Mecking regime (p = 0.8, q = 1.4, c_e = 26) is not pinned: the last row of the golden file is at "
                           "t = t_final = 10 exactly, where the oracle's sigma_33 is -725 MPa against the file's -773 MPa (the response there does not depend on "
-                          "the step sizes: 20 or 200 steps agree to 0.1 MPa); replay experiments in DESIGN.md section 5", strict=False)
+                          "the step sizes: 20 or 200 steps agree to 0.1 MPa).  Bounded, not closed: structural variants of the law, replays and a stress-space fit "
+                          "(no parameter set of this law traces the golden curve: 0.23 MPa rms at best) in DESIGN.md section 5, tools under scripts/auto_case_study", strict=False)
 def test_auto_time_stepping_case_plastic_branch(oracle):
     orc = oracle
     g = orc.golden("mtsdd_full_auto_stress.txt")
