@@ -471,6 +471,12 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 // The rotation data of an evaluation (Tr, d_lat, w_lat) is never live across one and stays in registers (struct Jac).  Rule measured
 // on MI355X: inside a thread's lifetime nothing written to global memory is still in L2 when it is read back, and a reload waits for
 // every earlier store of the wave (vmcnt), so anything that must survive the Newton loop belongs in LDS, not in global memory.
+#ifndef ECM_KM_GDOT_AT_END
+#define ECM_KM_GDOT_AT_END 1   // Kocks-Mecking: slip rates written once from the converged point (A/B switch)
+#endif
+#ifndef ECM_KM_FORMS_CSE
+#define ECM_KM_FORMS_CSE 0   // athermal-threshold Kocks-Mecking kernel: cheap classes through the factored slip forms - measured at 128^3: 12.7 ms against 12.3 (448 B of scratch instead of 320: this kernel is bound by spill latency, not by issue), so off
+#endif
 #ifndef ECM_TANGENT_FIRST
 #define ECM_TANGENT_FIRST 1   // epilogue order: tangent before the state / stress outputs (see point_update)
 #endif
@@ -626,6 +632,51 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       // sums changes (round-off).
       const double g_ia = 1.0 / mp.tau_a, gAth = pb.kv.g, wi = 1.0 / mp.wrD;
       unsigned pend = 0;
+#if ECM_KM_FORMS_CSE
+      // cheap classes of all 12 systems with static indices: resolved shear stresses through the shared partial sums (slip_tau12), one exp
+      // per drag-limited system, then D^p / W^p and the Jacobian blocks of these systems through the factored forms (slip_dpwp,
+      // slip_jac_blocks: 114 instead of ~540 multiply-adds per evaluation); the window systems are added by the pending loop below
+      {
+         double ks[5];
+#pragma unroll
+         for (int c = 0; c < 5; c++) ks[c] = PSC[c] * k[c];
+         double tau[NSLIP], gd[NSLIP], dg[NSLIP], xr[NSLIP];
+         slip_tau12(ks, tau);
+         bool any_drag = false;
+#pragma unroll
+         for (int a = 0; a < NSLIP; a++) {
+            const double at = fabs(tau[a]);
+            xr[a] = (at - gAth) * wi;
+            const bool live = (tau[a] != 0.0) && (xr[a] > 0.0), over = fmax(0.0, at - gAth) * g_ia > mp.t_max;
+            gd[a] = 0.0; dg[a] = 0.0;
+            if (live && !over) pend |= 1u << a;
+            // xr <- -1 marks "not drag-limited" for the second pass
+            if (!(live && over)) xr[a] = -1.0; else any_drag = true;
+         }
+         if (any_drag) {
+#pragma unroll
+            for (int a = 0; a < NSLIP; a++) {
+               const double ex = exp(-fmax(xr[a], 0.0));
+               const bool small = xr[a] < EPS_SQRT;
+               const double gr = small ? pb.kv.gam_r * xr[a] : pb.kv.gam_r * (1.0 - ex);
+               const double dgr = (small ? pb.kv.gam_r : pb.kv.gam_r * ex) * wi;
+               if (xr[a] >= 0.0) { gd[a] = copysign(gr, tau[a]); dg[a] = dgr; }
+            }
+         }
+#pragma unroll
+         for (int a = 0; a < NSLIP; a++) {
+            if (gdot_out) gdot_out[a * pb.gs] = gd[a];
+            dis += tau[a] * gd[a]; shr += fabs(gd[a]);
+         }
+         double dps[5], wps[3];
+         slip_dpwp(gd, dps, wps);
+#pragma unroll
+         for (int c = 0; c < 5; c++) dp[c] = PSC[c] * dps[c];
+#pragma unroll
+         for (int c = 0; c < 3; c++) wp[c] = PB * wps[c];
+         if (WITHJ) slip_jac_blocks(dg, jac.A, jac.B);
+      }
+#else
 #pragma unroll 1
       for (int a0 = 0; a0 < NSLIP; a0 += KD) {
          double pq[KD][8], tau[KD], gd[KD], dg[KD], xr[KD];
@@ -677,6 +728,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
             }
          }
       }
+#endif
       while (__ballot(pend != 0) != 0ull) {      // one pending window system per lane and pass
          if (pend != 0) {
             const int a = __ffs((int)pend) - 1; pend &= pend - 1;
@@ -803,6 +855,21 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
 #pragma unroll
    for (int a = 0; a < NSLIP; a++) { stg(&gdot_out[a * pb.gs], gd[a]); dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
    if (ECM_DEFER_DIS) { dis_rate = dis * ECM_ST(pb.st, ST_PB + PB_DETVRI); shrate = shr; }   // (rates below t_min = (1e-60)^m count as 0 here: below 1e-60 of the reference rate)
+}
+
+// slip rates at the converged point (Kocks-Mecking family, ECM_KM_GDOT_AT_END): one more pass through the kinetics (no derivatives) instead
+// of 12 global stores per evaluation - on gfx9 every scratch reload of the Newton loop otherwise waits for those stores (vmcnt)
+ECM_DI void km_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out) {
+   const double k[5] = { mp.kd0 * e_f[0], mp.kd0 * e_f[1], mp.kd2 * e_f[2], mp.kd2 * e_f[3], mp.kd2 * e_f[4] };
+#pragma unroll 1
+   for (int a0 = 0; a0 < NSLIP; a0 += KW) {
+      double tau[KW], gd[KW];
+#pragma unroll
+      for (int a = 0; a < KW; a++) tau[a] = PQ_TAB[a0 + a][0] * k[0] + PQ_TAB[a0 + a][1] * k[1] + PQ_TAB[a0 + a][2] * k[2] + PQ_TAB[a0 + a][3] * k[3] + PQ_TAB[a0 + a][4] * k[4];
+      kmbald_gdot4<false>(mp, pb.kv, tau, gd, nullptr);
+#pragma unroll
+      for (int a = 0; a < KW; a++) stg(&gdot_out[(a0 + a) * pb.gs], gd[a]);
+   }
 }
 
 // ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
@@ -1075,7 +1142,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    double x[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
    double r[8], dis_rate, shrate;
    Jac J; Fact F;
-   double* gdot_out = kin_is_km(KIN) ? sv1 + H_GDOT * QS : nullptr;
+   double* gdot_out = (kin_is_km(KIN) && !ECM_KM_GDOT_AT_END) ? sv1 + H_GDOT * QS : nullptr;
    int nfev = 1; bool conv = false;
    bool ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);
    // Norms are carried SQUARED: the common iteration (full Newton step inside the trust region) only compares them - |r| < tol, |dx| <= delta,
@@ -1206,6 +1273,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       double eNew = ECM_CD(CD_ENEW);
       eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * (ECM_CD(CD_WRKOLD) + wrk_new);
       if constexpr (!kin_is_km(KIN)) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS, dis_rate, shrate);
+      else if (ECM_KM_GDOT_AT_END) km_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS);
       stg(&sv1[(H_SHRATE) * QS], shrate);
       stg(&sv1[(H_SHR) * QS], ldg(&sv0[(H_SHR) * QS]) + shrate * dt);
       stg(&sv1[(H_FLOW) * QS], ((deff_keep > TINY_SQRT) ? dis_rate * dt : 0.0) + ldg(&sv0[(H_FLOW) * QS]));   // accumulated plastic work
