@@ -1101,10 +1101,11 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       double shrate_o = 0; for (int a = 0; a < NSLIP; a++) shrate_o += fabs(ldg(&sv0[(H_GDOT + a) * QS]));
       const double h_u = kin_update_h<KIN>(mp, ldg(&sv0[(H_H) * QS]), dt, shrate_o);
       // ---- point problem set-up
-      const double detV_ri = 1.0 / vNew; ECM_ST(st, ST_PB + PB_DETVRI) = detV_ri;
-      const double a_V_ri = 1.0 / cbrt(vNew);
-      pb.esc = E_SCALE * a_V_ri; ECM_ST(st, ST_PB + PB_ESCI) = 1.0 / pb.esc;
-      double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += ldg(&sv0[(H_Q + i) * QS]) * ldg(&sv0[(H_Q + i) * QS]); const double ni = 1.0 / sqrt(n2); for (int i = 0; i < 4; i++) qn[i] = ldg(&sv0[(H_Q + i) * QS]) * ni; }
+      // (reciprocals of well-scaled positive numbers through frcp / rsqrt: 5 instructions instead of the ~13 of an IEEE division)
+      const double detV_ri = frcp(vNew); ECM_ST(st, ST_PB + PB_DETVRI) = detV_ri;
+      const double a_V = cbrt(vNew), a_V_ri = frcp(a_V);
+      pb.esc = E_SCALE * a_V_ri; ECM_ST(st, ST_PB + PB_ESCI) = a_V * (1.0 / E_SCALE);
+      double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += ldg(&sv0[(H_Q + i) * QS]) * ldg(&sv0[(H_Q + i) * QS]); const double ni = rsqrt(n2); for (int i = 0; i < 4; i++) qn[i] = ldg(&sv0[(H_Q + i) * QS]) * ni; }
       double Cn[9]; quat_to_mat(qn, Cn);
       double dn[5]; rot_vecd_T(Cn, d_sm, dn);
       double wrk_old = 0.0;
@@ -1121,8 +1122,11 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          adots_ref = pb.kv.gam_w;
       } else { pb.kv.g = h_u; pb.kv.gam_w = mp.gam_w; pb.kv.gam_r = 0; pb.kv.c_e = 0; adots_ref = mp.gam_w; }
       if (dnorm < EPS_SQRT * adots_ref) { ECM_ST(st, ST_PB + PB_SCI) = adots_ref; pb.sc = 1.0 / adots_ref; }
-      else { pb.sc = fmin(1.0 / dnorm, 1.0e6 * dt); ECM_ST(st, ST_PB + PB_SCI) = 1.0 / pb.sc; }
-      pb.g_i = 1.0 / pb.kv.g;
+      else {
+         const double s1 = frcp(dnorm), cap = 1.0e6 * dt;
+         if (s1 <= cap) { pb.sc = s1; ECM_ST(st, ST_PB + PB_SCI) = dnorm; } else { pb.sc = cap; ECM_ST(st, ST_PB + PB_SCI) = 1.0 / cap; }
+      }
+      pb.g_i = frcp(pb.kv.g);
    }
    ECM_PARK_BARRIER();
 
