@@ -481,7 +481,7 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #define ECM_TANGENT_FIRST 1   // epilogue order: tangent before the state / stress outputs (see point_update)
 #endif
 #ifndef ECM_DEFER_DIS
-#define ECM_DEFER_DIS 0   // Voce: dissipation / effective shear rate from the converged point only (voce_slip_rates)
+#define ECM_DEFER_DIS 1   // Voce: dissipation / effective shear rate from the converged point only (voce_slip_rates)
 #endif
 #ifndef ECM_SWEEP_UNROLL
 #define ECM_SWEEP_UNROLL 0   // block Gauss-Seidel sweeps of the Newton step rolled (1: unrolled; A/B on MI355X)
@@ -564,9 +564,11 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       }
       voce_gdot12<WITHJ, false>(mp, g_i, tau, gd, dg);
       // the dissipation rate is an output of the converged point only: voce_slip_rates computes it there (12 FMAs fewer per evaluation)
+      if (!ECM_DEFER_DIS) {
 #pragma unroll
-      for (int a = 0; a < NSLIP; a++) { if (!ECM_DEFER_DIS) dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
-      ok = isfinite(shr);   // any non-finite rate poisons the sum
+         for (int a = 0; a < NSLIP; a++) { dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
+         ok = isfinite(shr);   // any non-finite rate poisons the sum
+      }   // deferred: the caller tests the residual norm for finiteness (a non-finite rate poisons D^p and with it the residual)
       if (ECM_SLIP_FORMS_CSE) {
          double dps[5], wps[3];
          slip_dpwp(gd, dps, wps);
@@ -819,7 +821,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       rot_vecd_T(A, dn, d_lat);
 #pragma unroll
       for (int c = 0; c < 5; c++) {
-         r[c] = (x[c] * (pb.esc * pb.dt_ri) + dp[c] - d_lat[c]) * pb.sc;
+         r[c] = x[c] * (pb.esc * pb.dt_ri) + dp[c] - d_lat[c];   // UN-scaled residual: the caller carries the scale sc (SNLS scales by epsdot_scale_inv)
          if (WITHJ) jac.dl[c] = d_lat[c];
       }
    }
@@ -828,7 +830,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 #pragma unroll
       for (int c = 0; c < 3; c++) {
          const double w_lat = A[c] * w0 + A[3 + c] * w1 + A[6 + c] * w2;
-         r[5 + c] = (xi[c] * pb.dt_ri + mp.qsign * wp[c] - w_lat) * pb.sc;
+         r[5 + c] = xi[c] * pb.dt_ri + mp.qsign * wp[c] - w_lat;
          if (WITHJ) jac.wl[c] = w_lat;
       }
    }
@@ -1152,8 +1154,11 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    // Norms are carried SQUARED: the common iteration (full Newton step inside the trust region) only compares them - |r| < tol, |dx| <= delta,
    // |r_new| > 0.65 |r_old| (SNLS: rho = actual / predicted < 0.35 with predicted = -|r_old|), |r_new| > |r_old| - and the two square roots per
    // iteration (~20 instructions each in FP64) are only taken on the dog-leg path, which needs the values.
-   const double tol2 = mp.tol * mp.tol;
-   double res2_0 = norm8sq(r);
+   // eval_rj returns the UN-scaled residual; SNLS works with r * sc (sc = epsdot_scale_inv): the squared norm carries sc^2, the Newton right-hand
+   // side needs no scale at all (16 multiplications per evaluation fewer), the dog-leg path scales its own copy.
+   const double tol2 = mp.tol * mp.tol, sc2 = pb.sc * pb.sc;
+   double res2_0 = sc2 * norm8sq(r);
+   ok = ok && isfinite(res2_0);
    if (ok && res2_0 < tol2) conv = true;
 #ifdef ECM_EXP_SKIP_SOLVE   // timing experiment only (scripts/tune_model.sh): no Newton iterations, the rest of the launch unchanged
    conv = true;
@@ -1169,8 +1174,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          jac_factor(mp, pb, J, F);
          double nr2sq;
          if (F.ok) {
-            const double sc_i = ECM_ST(st, ST_PB + PB_SCI);
-            double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i] * sc_i;
+            double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i];
             jac_solve<false, 2>(mp, pb, J, F, rhs, t);
             const double esc_i = ECM_ST(st, ST_PB + PB_ESCI);
             for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? esc_i : (1.0 / R_SCALE));
@@ -1180,8 +1184,9 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          if (nr2sq <= delta * delta) { use_nr = true; for (int i = 0; i < 8; i++) delx[i] = nr[i]; pred_resid = 0.0; }
          else {
             const double res_0 = sqrt(res2_0);
-            double grad[8], u[8];
-            jac_mult_T(mp, pb, J, r, t);
+            double grad[8], u[8], rs[8];
+            for (int i = 0; i < 8; i++) rs[i] = r[i] * pb.sc;
+            jac_mult_T(mp, pb, J, rs, t);
             for (int i = 0; i < 8; i++) { const double cs = (i < 5) ? pb.esc : R_SCALE; grad[i] = pb.sc * cs * t[i]; u[i] = cs * grad[i]; }
             jac_mult(mp, pb, J, u, t);
             double Jg_2 = 0, norm2_grad = 0;
@@ -1195,7 +1200,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
                pred_resid = sqrt(fmax(res_0 * res_0 - 2.0 * delta * norm_grad + delta * delta * Jg_2 / norm2_grad, 0.0));
             } else {
                // |r + Js sd|, sd = -fac grad: the Newton point zeroes the linear model, so the dog-leg point predicts (1-beta) of it
-               double s2 = 0; for (int i = 0; i < 8; i++) { const double v = r[i] - fac * pb.sc * t[i]; s2 += v * v; }
+               double s2 = 0; for (int i = 0; i < 8; i++) { const double v = rs[i] - fac * pb.sc * t[i]; s2 += v * v; }
                double qa = 0, qb = 0;
                for (int i = 0; i < 8; i++) { const double sd = -grad[i] * fac, p = nr[i] - sd; qa += p * p; qb += p * sd; }
                const double qc = norm_s_sd_opt * norm_s_sd_opt - delta * delta;
@@ -1207,10 +1212,11 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          for (int i = 0; i < 8; i++) { ECM_ST(st, ST_XS + i) = x[i]; x[i] += delx[i]; }
          ECM_PARK_BARRIER();
          ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate); nfev++;
+         const double res2 = sc2 * norm8sq(r);
+         ok = ok && isfinite(res2);
          bool reject;
          if (!ok) { reject = true; delta = fmax(delta * 0.25, 1e-12); }
          else {
-            const double res2 = norm8sq(r);
             if (res2 < tol2) { conv = true; break; }
             if (use_nr) {      // predicted residual 0: rho = 1 - |r| / |r_old| (never > 0.75 with a smaller residual AND a dog-leg step: no growth)
                if (res2_0 == 0.0) delta = fmin(delta * 1.5, 1e4);
