@@ -108,6 +108,7 @@ struct MatParams {
    int xn_int;              // 1/m - 1 when it is a small integer (m = 0.02 -> 49): power by repeated multiplication, else 0
    double qsign;            // +1 FCC, -1 BCC: sign of the plastic-spin vectors
    double kd0, kd2;         // Kirchhoff' = diag(kd0,kd0,kd2,kd2,kd2) e'
+   double pk0, pk1, pk2;    // PSC[0] kd0, PSC[1] kd0, PSC[2] kd2: Kirchhoff stress in the scaled integer slip basis straight from the strain
    double ikd0, ikd2;       // their reciprocals (host-computed: the Newton step would otherwise divide by them in every sweep)
    double bulk, gmod, gamma, tK0, dtde, tol;
    // Voce power law
@@ -537,20 +538,17 @@ template <int KIN, bool WITHJ>
 ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], double r[8], Jac& jac,
                     double* __restrict__ gdot_out, double& dis_rate, double& shrate) {
    // resolved shear stress from the Kirchhoff stress K e'
-   double k[5];
-   { double e_f[5];
+   double k[5], e_f[5];
 #pragma unroll
-     for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(pb.st, ST_EN + i) + x[i] * pb.esc;
-     k[0] = mp.kd0 * e_f[0]; k[1] = mp.kd0 * e_f[1]; k[2] = mp.kd2 * e_f[2]; k[3] = mp.kd2 * e_f[3]; k[4] = mp.kd2 * e_f[4]; }
+   for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(pb.st, ST_EN + i) + x[i] * pb.esc;
+   k[0] = mp.kd0 * e_f[0]; k[1] = mp.kd0 * e_f[1]; k[2] = mp.kd2 * e_f[2]; k[3] = mp.kd2 * e_f[3]; k[4] = mp.kd2 * e_f[4];   // (Voce: unused, see ks)
    const double g_i = pb.g_i;
    double dis = 0.0, shr = 0.0;
    double dp[5] = { 0, 0, 0, 0, 0 }, wp[3] = { 0, 0, 0 };
    bool ok = true;
    if constexpr (!kin_is_km(KIN)) {
       // fully unrolled, integer-coefficient form (see SP/SQ): resolved shear stresses, batched kinetics, then the Jacobian blocks
-      double ks[5];
-#pragma unroll
-      for (int c = 0; c < 5; c++) ks[c] = PSC[c] * k[c];
+      const double ks[5] = { mp.pk0 * e_f[0], mp.pk1 * e_f[1], mp.pk2 * e_f[2], mp.pk2 * e_f[3], mp.pk2 * e_f[4] };   // PSC[c] * Kirchhoff component c
       double tau[NSLIP], gd[NSLIP], dg[NSLIP];
       if (ECM_SLIP_FORMS_CSE) slip_tau12(ks, tau);
       else {
@@ -840,7 +838,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 
 // slip rates at the converged point (Voce family): written once, instead of one global store per system and evaluation
 ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out, double& dis_rate, double& shrate) {
-   const double ks[5] = { PSC[0] * mp.kd0 * e_f[0], PSC[1] * mp.kd0 * e_f[1], PSC[2] * mp.kd2 * e_f[2], PSC[3] * mp.kd2 * e_f[3], PSC[4] * mp.kd2 * e_f[4] };
+   const double ks[5] = { mp.pk0 * e_f[0], mp.pk1 * e_f[1], mp.pk2 * e_f[2], mp.pk2 * e_f[3], mp.pk2 * e_f[4] };
    double tau[NSLIP], gd[NSLIP];
    if (ECM_SLIP_FORMS_CSE) slip_tau12(ks, tau);
    else {
@@ -1307,12 +1305,20 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       bool okT;
       {
          double Ri[9]; okT = rot_block_inverse(pb, J, Ri);
+         // G <- Tr Jrr^-1 B: both couplings enter as M35(.) Tr G, so Tr is folded into G once (27 + 45 multiply-adds) instead of into each M35
          double G[3][5];
+         {
+            double Tr[9]; load_tr(J, Tr);
+            double TRi[9];
 #pragma unroll
-         for (int i = 0; i < 3; i++)
+            for (int m = 0; m < 3; m++)
 #pragma unroll
-            for (int j = 0; j < 5; j++) G[i][j] = Ri[3 * i] * J.B[0][j] + Ri[3 * i + 1] * J.B[1][j] + Ri[3 * i + 2] * J.B[2][j];
-         double Tr[9]; load_tr(J, Tr);
+               for (int i = 0; i < 3; i++) TRi[3 * m + i] = Tr[3 * m] * Ri[i] + Tr[3 * m + 1] * Ri[3 + i] + Tr[3 * m + 2] * Ri[6 + i];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+               for (int j = 0; j < 5; j++) G[i][j] = TRi[3 * i] * J.B[0][j] + TRi[3 * i + 1] * J.B[1][j] + TRi[3 * i + 2] * J.B[2][j];
+         }
          double S[5][5];
          {
             double dl[5]; load_dl(J, dl);
@@ -1320,11 +1326,8 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
             const double kdi0 = pb.dt_ri * mp.ikd0, kdi2 = pb.dt_ri * mp.ikd2;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-               double E[3];
 #pragma unroll
-               for (int j = 0; j < 3; j++) E[j] = Md[k][0] * Tr[j] + Md[k][1] * Tr[3 + j] + Md[k][2] * Tr[6 + j];
-#pragma unroll
-               for (int j = 0; j < 5; j++) S[k][j] = J.A[sidx(k, j)] + ((k == j) ? (k < 2 ? kdi0 : kdi2) : 0.0) + E[0] * G[0][j] + E[1] * G[1][j] + E[2] * G[2][j];
+               for (int j = 0; j < 5; j++) S[k][j] = J.A[sidx(k, j)] + ((k == j) ? (k < 2 ? kdi0 : kdi2) : 0.0) + Md[k][0] * G[0][j] + Md[k][1] * G[1][j] + Md[k][2] * G[2][j];
             }
          }
          // un-pivoted LU of S (M is SPD and dominates the O(|D| dt) coupling), then Y = S^-1 column by column
@@ -1340,16 +1343,13 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
                for (int j = k + 1; j < 5; j++) S[i][j] -= l * S[k][j];
             }
          }
-         double Kt[5][5];   // detV_ri I + M35(s_lat) Tr G
+         double Kt[5][5];   // detV_ri I + M35(s_lat) (Tr G)
          {
             double Ms[5][3]; m35(s_lat, Ms);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-               double H[3];
 #pragma unroll
-               for (int j = 0; j < 3; j++) H[j] = Ms[k][0] * Tr[j] + Ms[k][1] * Tr[3 + j] + Ms[k][2] * Tr[6 + j];
-#pragma unroll
-               for (int j = 0; j < 5; j++) Kt[k][j] = ((k == j) ? detV_ri : 0.0) + H[0] * G[0][j] + H[1] * G[1][j] + H[2] * G[2][j];
+               for (int j = 0; j < 5; j++) Kt[k][j] = ((k == j) ? detV_ri : 0.0) + Ms[k][0] * G[0][j] + Ms[k][1] * G[1][j] + Ms[k][2] * G[2][j];
             }
          }
 #pragma unroll

@@ -127,6 +127,7 @@ bool exa_fill_mat_params(const exa_config& cfg, ecmdev::MatParams& mp, double* h
    const double cvav = p[i++]; mp.tol = p[i++];
    const double c11 = p[i++], c12 = p[i++], c44 = p[i++];
    mp.kd0 = c11 - c12; mp.kd2 = 2.0 * c44; mp.ikd0 = 1.0 / mp.kd0; mp.ikd2 = 1.0 / mp.kd2;
+   mp.pk0 = ecmdev::PSC[0] * mp.kd0; mp.pk1 = ecmdev::PSC[1] * mp.kd0; mp.pk2 = ecmdev::PSC[2] * mp.kd2;   // PSC[2] == PSC[3] == PSC[4]
    mp.bulk = (c11 + 2.0 * c12) / 3.0; mp.gmod = (2.0 * mp.kd0 + 3.0 * mp.kd2) / 10.0;
    double hdn_init, xm;
    if (mp.kin != KIN_KMBALD) {
