@@ -288,11 +288,10 @@ def main():
                          "fp64_issue": ({"valu_insts_per_wave": valu_per_wave, "ms_at_full_issue": valu_per_wave * 4.0 * (P_local / 64.0 / 1024.0) / 2.4e9 * 1e3,
                                          "frac": valu_per_wave * 4.0 * (P_local / 64.0 / 1024.0) / 2.4e9 * 1e3 / kern_ms} if valu_per_wave else None),
                          "note": "the contract's HBM fraction of the ALGORITHMIC bytes (928 B/qpt) is reported in frac; the launch itself is bound by FP64 VALU "
-                                 "issue: SQ counters (profiles/r02_pmc_sq_summary.txt) show the VALU busy 87 % of the wave cycles, and the wave-cycle count "
-                                 "of a launch (12.9 M per SIMD in 6.98 ms) says the chip sustains ~1.85 GHz under this FP64 load, not the nominal 2.4 GHz the "
-                                 "fp64_issue figures are priced at (a pure v_fma_f64 loop reaches 63.7 TFLOP/s = 81 % of the 78.6 TFLOP/s nominal peak, "
-                                 "profiles/r02_mfma_tangent_experiment.txt); traffic = L2-boundary bytes from the PMC passes (spill stores make it ~1.6x the "
-                                 "algorithmic bytes, DESIGN 4.1); roofline_pcg_apply is the HBM-bound half of the metric"},
+                                 "issue: SQ counters (profiles/r03_sq_fcc_voce.txt) show the VALU busy 85 % of the wave cycles at 7 705 VALU instructions per wave "
+                                 "(10 709 at the start of round 3, profiles/r03_kernel_experiments.txt), and the chip sustains ~1.85 GHz under this FP64 load, not the "
+                                 "nominal 2.4 GHz the fp64_issue figures are priced at; traffic = L2-boundary bytes from the PMC passes of THIS kernel instantiation "
+                                 "(profiles/r03_pmc_traffic.json; null when not measured for the model); roofline_pcg_apply is the HBM-bound half of the metric"},
             "roofline_pcg_apply": {"kernel": ("k_ea_apply_p1 (element mat-vec)" if ea_streamed else "k_grad_apply_p1<LVEC,GEO,CMP> (AddMultGradPA / matrix-free element-assembly action + gather/scatter)"), "bound": "hbm",
                                    "achieved": moved * P_local / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": moved * P_local / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
