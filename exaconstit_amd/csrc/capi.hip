@@ -147,6 +147,9 @@ int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* x_lvec, 
    return rc;
 }
 
+// driver-internal: device address of the failed-point counter of the last constitutive launch (consumed on the device by the residual norm)
+const int* exa_model_fail_counter_dev(exa_ctx* ctx) { return ctx ? ctx->fail_count_dev : nullptr; }
+
 int exa_model_status(exa_ctx* ctx, exa_stream s) {
    if (!ctx) return EXA_ERR_ARG;
    int h = 0;

@@ -1216,6 +1216,9 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          if (!ok) { reject = true; delta = fmax(delta * 0.25, 1e-12); }
          else {
             if (res2 < tol2) { conv = true; break; }
+#ifdef ECM_EXP_MAXEVAL   // timing experiment only: what the launch would cost if no lane needed more than ECM_EXP_MAXEVAL evaluations
+            if (nfev >= ECM_EXP_MAXEVAL) { conv = true; break; }
+#endif
             if (use_nr) {      // predicted residual 0: rho = 1 - |r| / |r_old| (never > 0.75 with a smaller residual AND a dog-leg step: no growth)
                if (res2_0 == 0.0) delta = fmin(delta * 1.5, 1e4);
                else if (res2 > (0.65 * 0.65) * res2_0) delta = fmax(delta * 0.25, 1e-12);

@@ -37,6 +37,7 @@ struct DevBuf {
    void swap(DevBuf<T>& o) { std::swap(p, o.p); std::swap(n, o.n); }
 };
 
+void vk_poison_if_failed(const int* fail_count, double* sum, double* count_out, hipStream_t s);
 void vk_update_coords(int64_t n, const double* xb, const double* v, double dt, double* xe, hipStream_t s);
 void vk_mask_zero(int64_t n, const uint8_t* m, double* y, hipStream_t s);
 void vk_mask_set(int64_t n, const uint8_t* m, const double* val, double* y, hipStream_t s);

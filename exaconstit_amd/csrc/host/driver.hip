@@ -16,6 +16,7 @@
 #include <iomanip>
 #include <iostream>
 
+extern "C" const int* exa_model_fail_counter_dev(exa_ctx* ctx);
 extern "C" int exa_grad_apply_lvec_blocks(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, int blk0, int nblk, exa_stream s);
 extern "C" int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, exa_stream s);
 
@@ -349,7 +350,11 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
 
 void NonlinearMechOperator::ensure_mat_grad() { if (matGrad.n == 0) { matGrad.alloc((size_t)exa_qf_size(ctx_, 36)); matGrad.zero(stream_); } }
 
-NonlinearMechOperator::~NonlinearMechOperator() { exa_destroy(ctx_); (void)hipEventDestroy(ev0_); (void)hipEventDestroy(ev1_); (void)hipStreamDestroy(stream_); }
+NonlinearMechOperator::~NonlinearMechOperator() {
+   exa_destroy(ctx_); (void)hipEventDestroy(ev0_); (void)hipEventDestroy(ev1_);
+   for (EvPair& e : ev_ring_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+   (void)hipStreamDestroy(stream_);
+}
 
 void NonlinearMechOperator::UpdateEssTDofs(const std::vector<uint8_t>& mask) { ess_mask.upload(mask); }
 
@@ -389,7 +394,11 @@ template <bool upd_crds>
 void NonlinearMechOperator::Setup(const double* k) {
    if (upd_crds) vk_update_coords(nd_, x_beg.p, k, dt_, x_cur.p, stream_);   // ExaModel::UpdateEndCoords (halo copies stay consistent)
    ProfRegion prof("ecmech_kernel");   // reference: CALI_MARK_BEGIN("ecmech_kernel"), src/mechanics_ecmech.cpp:237
-   EXA_HC(hipEventRecord(ev0_, stream_));
+   // No host synchronisation in here: the launch is timed by a ring of event pairs that is read back lazily (FlushModelTimers) and a failed
+   // local solve poisons the residual norm ON THE DEVICE (ResidualNorm), which is also where the count reaches the host.  At 64^3 elements
+   // per rank the launch is 0.6 ms: an event wait plus a status read-back per evaluation (round 2) was ~10 % of it.
+   EvPair& ev = NextModelTimer();
+   EXA_HC(hipEventRecord(ev.a, stream_));
    if (use_records()) model_->ModelSetupLVecRecords(x_cur.p, k, el_jac.p, stream_);   // ... and AssembleGradPA: the launch writes the action's point records
    else if (fused_setup_) { ensure_mat_grad(); model_->ModelSetupLVec(x_cur.p, k, el_jac.p, stream_); }   // L->E of x and v + SetupJacobianTerms inside the constitutive launch
    else {
@@ -399,13 +408,9 @@ void NonlinearMechOperator::Setup(const double* k) {
       abi_check(ctx_, exa_restrict(ctx_, k, el_v.p, stream_), "exa_restrict");
       model_->ModelSetup(el_jac.p, el_v.p, stream_);
    }
-   EXA_HC(hipEventRecord(ev1_, stream_));
-   EXA_HC(hipEventSynchronize(ev1_));
-   float ms = 0; EXA_HC(hipEventElapsedTime(&ms, ev0_, ev1_));
-   timers.t_model_ms += ms; timers.qpt_updates += (int64_t)E_ * npe_; model_calls++;
-   model_fail = exa_model_status(ctx_, stream_);   // the launch has completed (ev1_): one 4-byte read-back
-   if (model_fail < 0) abi_check(ctx_, model_fail, "exa_model_status");
-   model_fail_total += model_fail;
+   EXA_HC(hipEventRecord(ev.b, stream_)); ev.pending = true;
+   timers.qpt_updates += (int64_t)E_ * npe_; model_calls++;
+   model_status_pending_ = true;
    if (cap_auto_ && (model_calls <= 4 || model_calls % 4 == 0)) {   // tail split: next cap from the evaluation counts of this launch (the distribution drifts slowly)
       int h[64]; abi_check(ctx_, exa_model_nfev_hist(ctx_, matVars1.p, h, stream_), "exa_model_nfev_hist");
       newton_cap_ = choose_newton_cap(h, tail_cost_);
@@ -414,6 +419,24 @@ void NonlinearMechOperator::Setup(const double* k) {
 }
 template void NonlinearMechOperator::Setup<true>(const double*);
 template void NonlinearMechOperator::Setup<false>(const double*);
+
+NonlinearMechOperator::EvPair& NonlinearMechOperator::NextModelTimer() {
+   if (ev_ring_.empty()) { ev_ring_.resize(64); for (EvPair& e : ev_ring_) { EXA_HC(hipEventCreate(&e.a)); EXA_HC(hipEventCreate(&e.b)); } }
+   EvPair& e = ev_ring_[ev_head_]; ev_head_ = (ev_head_ + 1) % (int)ev_ring_.size();
+   if (e.pending) { EXA_HC(hipEventSynchronize(e.b)); float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e.a, e.b)); timers.t_model_ms += ms; e.pending = false; }
+   return e;
+}
+// adds the launches timed since the last call to timers.t_model_ms (waits for the last of them)
+void NonlinearMechOperator::FlushModelTimers() {
+   for (EvPair& e : ev_ring_) if (e.pending) { EXA_HC(hipEventSynchronize(e.b)); float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e.a, e.b)); timers.t_model_ms += ms; e.pending = false; }
+}
+// failed local solves of the last constitutive launch, for callers that do not go through ResidualNorm (one 4-byte read-back + sync)
+void NonlinearMechOperator::ReadModelStatus() {
+   if (!model_status_pending_) return;
+   model_fail = exa_model_status(ctx_, stream_);
+   if (model_fail < 0) abi_check(ctx_, model_fail, "exa_model_status");
+   model_fail_total += model_fail; model_status_pending_ = false;
+}
 
 void NonlinearMechOperator::ResidualAction(double* y) {
    EXA_HC(hipMemsetAsync(y, 0, sizeof(double) * nd_, stream_));
@@ -493,6 +516,7 @@ void NonlinearMechOperator::GradMult(const double* x, double* y, bool constraine
 
 void NonlinearMechOperator::GetUpdateBCsAction(const double* k, const double* x, double* y) {
    Setup<false>(k);
+   ReadModelStatus();                          // (no residual norm follows this evaluation)
    GetGradient();                              // Hform->Setup + gradient data
    GradMult(x, y, false);                      // local action without essential constraints
    ResidualAction(tmp_r_.p);                   // Hform->Mult(k, resid), essential rows zeroed
@@ -510,10 +534,13 @@ double NonlinearMechOperator::dot(const double* a, const double* b) {
 // ||r|| over all ranks; +inf everywhere if any rank saw an unconverged constitutive point in the launch that produced r
 double NonlinearMechOperator::ResidualNorm(const double* r) {
    vk_dot(nd_, nn_, weight.p, r, r, nullptr, partial.p, scal.p + 9, stream_);
-   if (model_fail > 0) { const double inf = std::numeric_limits<double>::infinity(); EXA_HC(hipMemcpyAsync(scal.p + 9, &inf, sizeof(double), hipMemcpyHostToDevice, stream_)); EXA_HC(hipStreamSynchronize(stream_)); }
+   // device side: fail count of the launch that produced r -> scal[15]; a non-zero count turns the local sum into +inf before the all-reduce
+   if (model_status_pending_) vk_poison_if_failed(exa_model_fail_counter_dev(ctx_), scal.p + 9, scal.p + 15, stream_);
    comm_.allreduce_sum(scal.p + 9, 1, stream_);
-   double h; EXA_HC(hipMemcpyAsync(&h, scal.p + 9, sizeof(double), hipMemcpyDeviceToHost, stream_)); EXA_HC(hipStreamSynchronize(stream_));
-   return std::sqrt(h);
+   double h[7]; EXA_HC(hipMemcpyAsync(h, scal.p + 9, sizeof(double) * 7, hipMemcpyDeviceToHost, stream_)); EXA_HC(hipStreamSynchronize(stream_));
+   if (model_status_pending_) { model_fail = (int)h[6]; model_fail_total += model_fail; model_status_pending_ = false; }
+   FlushModelTimers();   // everything on the stream has finished: no wait
+   return std::sqrt(h[0]);
 }
 
 void NonlinearMechOperator::UpdateModel() { model_->UpdateModelVars(); model_->UpdateStress(); model_->UpdateStateVars(); }

@@ -125,6 +125,9 @@ class NonlinearMechOperator {
    // in that case (ECMECH_FAIL in getResponseSngl); here a non-zero count poisons the next residual norm on every rank, so that
    // Newton reports non-convergence: Time.Auto then cuts dt, otherwise the run stops.
    int model_fail = 0; int64_t model_fail_total = 0;
+   bool model_status_pending_ = false;       // a constitutive launch whose failure count has not reached the host yet (ResidualNorm / ReadModelStatus)
+   struct EvPair { hipEvent_t a = nullptr, b = nullptr; bool pending = false; };
+   EvPair& NextModelTimer(); void FlushModelTimers(); void ReadModelStatus();
    double ResidualNorm(const double* r);
    double dot(const double* a, const double* b);   // weighted, all-reduced, synchronising
    DevBuf<double> partial, scal;
@@ -132,6 +135,7 @@ class NonlinearMechOperator {
    ExaOptions opt_; const Partition& part_; Comm& comm_;
    exa_ctx* ctx_ = nullptr; std::unique_ptr<ExaCMechModel> model_;
    hipStream_t stream_ = nullptr; hipEvent_t ev0_, ev1_;
+   std::vector<EvPair> ev_ring_; int ev_head_ = 0;   // event pairs around the constitutive launches, read back lazily
    int nn_, nd_, E_, npe_ = 8; double dt_ = 1.0;
    bool records_setup_ = false;   // gradient records written by the constitutive launch (p = 1 fast path, identity preconditioner)
    bool use_records() const { return records_setup_ && precond == Precond::IDENTITY; }

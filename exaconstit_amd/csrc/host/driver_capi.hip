@@ -126,6 +126,7 @@ int exa_driver_get_stats(exa_driver* d, int* newton, int* krylov, int* model_cal
 
 // out[0] ms in the fused constitutive kernel, out[1] ms in PCG, out[2] ms in Solve (+SolveInit), out[3] qpt updates, out[4] PCG iterations
 void exa_driver_get_timers(exa_driver* d, double* out) {
+   d->sd->oper().FlushModelTimers();
    const Timers& t = d->sd->oper().timers;
    out[0] = t.t_model_ms; out[1] = t.t_krylov_ms; out[2] = t.t_solve_ms; out[3] = (double)t.qpt_updates; out[4] = (double)t.krylov_iters;
 }
@@ -133,6 +134,7 @@ void exa_driver_reset_timers(exa_driver* d) { d->sd->oper().timers = Timers(); }
 // out[0] quadrature points whose local solve failed (sum over all constitutive launches, this rank), out[1] linear solves that
 // did not converge, out[2] PCG iterations that saw (Ad, d) < 0, out[3] flag of the last PCG solve (1 converged, 2 max_iter, -1 den == 0)
 void exa_driver_get_diagnostics(exa_driver* d, int64_t* out) {
+   d->sd->oper().ReadModelStatus();
    out[0] = d->sd->oper().model_fail_total; out[1] = d->sd->cg_not_converged; out[2] = d->sd->cg_indefinite_iters; out[3] = d->sd->last_cg_flag;
 }
 
@@ -185,6 +187,7 @@ int exa_driver_bench_model(exa_driver* d, int steps, double* out, char* err, int
       SystemDriver& sd = *d->sd; NonlinearMechOperator& op = sd.oper();
       hipStream_t s = op.stream();
       hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1));
+      op.FlushModelTimers();
       const double t0 = op.timers.t_model_ms;
       const std::string rname = "timed_region_model[passes=" + std::to_string(steps) + "]";   // the bench's warm-up / elastic / plastic loops differ in length
       ProfRegion prof(rname.c_str());
@@ -192,7 +195,8 @@ int exa_driver_bench_model(exa_driver* d, int steps, double* out, char* err, int
       for (int i = 0; i < steps; i++) op.Setup<true>(sd.v_sol.p);
       EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
       float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-      out[0] = ms; out[1] = op.timers.t_model_ms - t0; out[2] = (double)exa_model_status(op.GetModel()->ctx(), s);
+      op.FlushModelTimers(); op.ReadModelStatus();
+      out[0] = ms; out[1] = op.timers.t_model_ms - t0; out[2] = (double)op.model_fail;
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }

@@ -199,7 +199,9 @@ __global__ void k_cg2_dots(int64_t n, int64_t nn, const double* __restrict__ w, 
 }
 __global__ void k_reduce2(int nb, const double* __restrict__ partial, const double* __restrict__ flag, double* __restrict__ out2) {
    __shared__ double sm[RBLK];
-   if (flag[0] != 0.0) return;
+   // solver finished: the remaining iterations of the chunk are no-ops, but their all-reduce still runs - feed it zeros instead of the stale
+   // pair (which every further all-reduce would multiply by the number of ranks)
+   if (flag[0] != 0.0) { if (threadIdx.x == 0) { out2[0] = 0.0; out2[1] = 0.0; } return; }
    double a0 = 0, a1 = 0;
    for (int i = threadIdx.x; i < nb; i += RBLK) { a0 += partial[i]; a1 += partial[nb + i]; }
    const double s0 = block_sum(a0, sm); __syncthreads();
@@ -314,6 +316,14 @@ void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const
    if (fuse_den_S) hipLaunchKernelGGL(k_reduce_cg<2>, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, fuse_den_S, 0.0);
    else hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out);
 }
+// failed local solves of the constitutive launch behind a residual: the count goes to count_out (as a double, next to the norm in the read-back)
+// and a non-zero count makes the local sum +inf, so that Newton sees a non-finite residual on every rank after the all-reduce
+__global__ void k_poison_if_failed(const int* __restrict__ fail_count, double* __restrict__ sum, double* __restrict__ count_out) {
+   const int f = fail_count[0];
+   count_out[0] = (double)f;
+   if (f > 0) sum[0] = __longlong_as_double(0x7ff0000000000000ll);
+}
+void vk_poison_if_failed(const int* fail_count, double* sum, double* count_out, hipStream_t s) { hipLaunchKernelGGL(k_poison_if_failed, dim3(1), dim3(1), 0, s, fail_count, sum, count_out); }
 void vk_cg_init(double* S, double rel, double abs_, hipStream_t s) { hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1), 0, s, S, rel, abs_); }
 void vk_cg_den(double* S, hipStream_t s) { hipLaunchKernelGGL(k_cg_den, dim3(1), dim3(1), 0, s, S); }
 void vk_cg_beta(double* S, int max_iter, hipStream_t s) { hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1), 0, s, S, (double)max_iter); }

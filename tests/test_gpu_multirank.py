@@ -42,7 +42,7 @@ def _run_ranks(L, toml, nranks, nsteps, tmp_path, jacobi=False):
     return out
 
 
-@pytest.mark.parametrize("case,nranks", [("voce_pa", 2), ("voce_pa", 3), ("voce_pa", 8), ("voce_ea_cs", 4), ("voce_full_cyclic", 2)])
+@pytest.mark.parametrize("case,nranks", [("voce_pa", 2), ("voce_pa", 3), ("voce_pa", 8), ("voce_ea_cs", 4), ("voce_full_cyclic", 2), ("mtsdd_bcc", 4), ("mtsdd_full", 2)])
 def test_partitioned_run_matches_single_rank(oracle, tmp_path, case, nranks):
     import exaconstit_amd.lib as L
     orc = oracle
