@@ -303,7 +303,8 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
       if (std::string(nc) == "auto") cap_auto_ = true;
       else { cap_auto_ = false; newton_cap_ = (std::string(nc) == "off") ? 0 : std::atoi(nc); }
    }
-   tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.5 : 4.0;
+   tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.0 : 4.0;   // (Kocks-Mecking: re-measured in round 3 after the slip-rate stores left the Newton loop: 1.5 -> 1.0 picks cap 5 for FCC, 38.7 instead of 40.2 ms; BCC unchanged)
+   if (const char* tc = std::getenv("EXA_TAIL_COST")) { const double v = std::atof(tc); if (v > 0.0) tail_cost_ = v; }   // A/B switch of the controller's cost model
    // element assembly: the element matrices are 2x (p = 1) to 5x (p = 2) the bytes of the records they are built from, so the action is
    // computed from the records and the matrices only exist if somebody asks for them (diagonal, export); EXA_EA_ASSEMBLED=1 streams them instead
    if (!det_unfused && opt.assembly == Assembly::EA && (part.p == 2 || fast_p1_) && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1"))
@@ -364,7 +365,7 @@ void NonlinearMechOperator::UpdateEssTDofs(const std::vector<uint8_t>& mask) { e
 // w = measured cost of a point in the second launch relative to the first (its lanes are scattered points: 8-byte accesses into the
 // blocked rows): 4 for the Voce kernels, whose first launch is close to the memory system's limits, 1.5 for the compute-heavy
 // Kocks-Mecking kernel; 0.2 = the second launch's fixed cost.  Measured at 128^3: BCC KM-DD 31.6 -> 16.0 ms, FCC KM-DD 70.9 -> 55.9 ms,
-// Voce stays uncapped (6.9 ms; K = 5 would cost 10.2 ms, which the model reproduces).
+// Voce stays uncapped (6.9 ms; K = 5 would cost 10.2 ms, which the model reproduces).  Round 3: w = 1.0 for Kocks-Mecking (EXA_TAIL_COST overrides).
 // Returns the K minimising C, or 0 (off) when it does not beat the uncapped launch by 3 %.
 int choose_newton_cap(const int* hist, double tail_cost_) {
    double tot = 0; for (int i = 0; i < 64; i++) tot += hist[i];
