@@ -288,7 +288,7 @@ def main():
                          "fp64_issue": ({"valu_insts_per_wave": valu_per_wave, "ms_at_full_issue": valu_per_wave * 4.0 * (P_local / 64.0 / 1024.0) / 2.4e9 * 1e3,
                                          "frac": valu_per_wave * 4.0 * (P_local / 64.0 / 1024.0) / 2.4e9 * 1e3 / kern_ms} if valu_per_wave else None),
                          "note": "the contract's HBM fraction of the ALGORITHMIC bytes (928 B/qpt) is reported in frac; the launch itself is bound by FP64 VALU "
-                                 "issue: SQ counters (profiles/r03_sq_fcc_voce.txt) show the VALU busy 85 % of the wave cycles at 7 705 VALU instructions per wave "
+                                 "issue: SQ counters (profiles/r03_sq_fcc_voce.txt) show the VALU busy 85 % of the wave cycles at 7 660 VALU instructions per wave "
                                  "(10 709 at the start of round 3, profiles/r03_kernel_experiments.txt), and the chip sustains ~1.85 GHz under this FP64 load, not the "
                                  "nominal 2.4 GHz the fp64_issue figures are priced at; traffic = L2-boundary bytes from the PMC passes of THIS kernel instantiation "
                                  "(profiles/r03_pmc_traffic.json; null when not measured for the model); roofline_pcg_apply is the HBM-bound half of the metric"},
