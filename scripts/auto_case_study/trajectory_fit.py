@@ -7,7 +7,7 @@ multipliers then answers: is there ANY parameter set of the implemented law that
 did, the props file would simply not be the one the golden file was made with.)
 
 usage: python scripts/auto_case_study/trajectory_fit.py eval name=value ...       one run, prints the misfit
-       python scripts/auto_case_study/trajectory_fit.py fit name,name,... [iters]  LM fit over the named properties (4 runs at a time)
+       python scripts/auto_case_study/trajectory_fit.py fit name[=start],name,... [iters]  LM fit over the named properties (4 runs at a time)
 names: c_1 tau_a p q gam_wo gam_ro wrD go s k1 k2o ninv gamma_o rho0   (values are multipliers; tau_a/go also accept +x additive as 'a+x')
 """
 import multiprocessing as mp
@@ -68,12 +68,13 @@ def main():
         print(mods, "rms shear misfit %.3f MPa, max %.3f, rows beyond range %d, sigma_33(t=10) misfit %.2f MPa" %
               (np.sqrt(np.mean(sh[:, :3] ** 2)), np.abs(sh[:, :3]).max(), int(np.sum(sh[:, 3] > 0)), r[-1] / 0.2))
         return
-    names = sys.argv[2].split(",")
+    spec = sys.argv[2].split(",")      # name or name=start (multiplier)
+    names = [s.split("=")[0] for s in spec]
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-    x = np.zeros(len(names))   # log multipliers
+    x = np.array([np.log(float(s.split("=")[1])) if "=" in s else 0.0 for s in spec])   # log multipliers
     lam = 1e-2
     pool = mp.Pool(4)
-    r0 = residual({})
+    r0 = residual(dict(zip(names, np.exp(x))))
     print("start cost", float(r0 @ r0), flush=True)
     for it in range(iters):
         h = 0.05
