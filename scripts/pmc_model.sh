@@ -11,6 +11,11 @@ for f in glob.glob("gpurun_out/$tag/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if "k_model_setup" in r["Kernel_Name"]:
             d[int(r["Dispatch_Id"])][r["Counter_Name"]]=float(r["Counter_Value"]); d[int(r["Dispatch_Id"])]["grid"]=float(r["Grid_Size"])
-    gmax=max(v["grid"] for v in d.values()); k=max(i for i,v in d.items() if v["grid"]==gmax); c=d[k]; waves=c["grid"]/64   # last full-size launch (not a tail launch)
-    print("per-wave: VALU %.0f SALU %.0f FLAT %.1f | wave_cycles %.0f  valu_active %.1f%%  wait_any %.1f%%  wait_inst %.1f%%" % (c["SQ_INSTS_VALU"]/waves, c["SQ_INSTS_SALU"]/waves, c["SQ_INSTS_FLAT"]/waves, 4*c["SQ_WAVE_CYCLES"]/waves, 100*c["SQ_ACTIVE_INST_VALU"]/c["SQ_WAVE_CYCLES"]*2, 100*c["SQ_WAIT_ANY"]/c["SQ_WAVE_CYCLES"], 100*c["SQ_WAIT_INST_ANY"]/c["SQ_WAVE_CYCLES"]))
+    gmax=max(v["grid"] for v in d.values()); full=sorted(i for i,v in d.items() if v["grid"]==gmax)
+    # a capped launch and its tail launch have the same kernel name and grid (Kocks-Mecking): of the last two full-size dispatches the one with
+    # more VALU work is the main launch, the other one the tail launch; without a tail split both are plastic-regime passes of the same launch
+    last2=full[-2:]; main=max(last2, key=lambda i: d[i]["SQ_INSTS_VALU"]); rest=[i for i in last2 if i!=main]
+    for label,k in [("main launch",main)]+[("tail launch (or previous pass)",i) for i in rest]:
+        c=d[k]; waves=c["grid"]/64
+        print(label+": per-wave VALU %.0f SALU %.0f FLAT %.1f | wave_cycles %.0f  valu_active %.1f%%  wait_any %.1f%%  wait_inst %.1f%%" % (c["SQ_INSTS_VALU"]/waves, c["SQ_INSTS_SALU"]/waves, c["SQ_INSTS_FLAT"]/waves, 4*c["SQ_WAVE_CYCLES"]/waves, 100*c["SQ_ACTIVE_INST_VALU"]/c["SQ_WAVE_CYCLES"]*2, 100*c["SQ_WAIT_ANY"]/c["SQ_WAVE_CYCLES"], 100*c["SQ_WAIT_INST_ANY"]/c["SQ_WAVE_CYCLES"]))
 PY
