@@ -54,8 +54,12 @@ constexpr int H_SHRATE = 0, H_SHR = 1, H_FLOW = 2, H_NFEV = 3, H_E = 4, H_Q = 9,
 constexpr int NUM_HIST = 26, NSTATEV = 28, IND_VOL = 26, IND_EINT = 27;
 
 enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2,
-       KIN_KMBALD_GA = 3 };   // compile-time variant of KIN_KMBALD for with_g_athermal (BCC): same arithmetic, window systems deferred (eval_rj)
-constexpr bool kin_is_km(int k) { return k == KIN_KMBALD || k == KIN_KMBALD_GA; }
+       KIN_KMBALD_GA = 3,     // compile-time variant of KIN_KMBALD for with_g_athermal (BCC): same arithmetic, window systems deferred (eval_rj)
+       KIN_PQ1 = 4 };         // flag on the two Kocks-Mecking kinds: thermal-activation exponents p == q == 1 known at compile time (no pow()
+                              // code in the kinetics: 7-11 % fewer cycles at 128^3 through lower register pressure; same arithmetic)
+constexpr int kin_base(int k) { return k & 3; }
+constexpr bool kin_pq1(int k) { return (k & KIN_PQ1) != 0; }
+constexpr bool kin_is_km(int k) { return kin_base(k) == KIN_KMBALD || kin_base(k) == KIN_KMBALD_GA; }
 
 // Schmid tensors of the 12 FCC {111}<110> systems: P = vecd(sym(s x m)), Q = axial(skew(s x m)).
 // a = sqrt(3)/6, b = sqrt(6)/12.
@@ -297,18 +301,25 @@ ECM_DI void voce_gdot12(const MatParams& mp, double g_i, const double tau[NSLIP]
 // keeps a uniform branch a branch: without it the compiler speculates the (pure) pow() of the general case and selects afterwards,
 // i.e. every call pays two full pow() expansions (~400 instructions) even when p == q == 1
 #define ECM_NO_SPECULATE() asm volatile("" ::: "memory")
+#ifndef ECM_EXP_PQ1
+#define ECM_EXP_PQ1 0   // timing experiment: p == q == 1 known at compile time (no pow() code in the kinetics at all)
+#endif
+#ifndef ECM_KM_SKIP_BACK
+#define ECM_KM_SKIP_BACK 1   // p == q == 1: backward-jump term dropped where it is below half an ulp of the forward term (A/B switch)
+#endif
+template <bool PQ1>
 ECM_DI void mts_dG(const MatParams& mp, double c_e, double t_frac, double& exp_arg, double& dfac) {
    exp_arg = 0.0; dfac = 0.0;
    if (t_frac >= 1.0) return;
    double p_func, dp_func;
    const double at = fabs(t_frac);
-   if (mp.p == 1.0) { p_func = t_frac; dp_func = 1.0; }
+   if (PQ1 || ECM_EXP_PQ1 || mp.p == 1.0) { p_func = t_frac; dp_func = 1.0; }
    else if (at < TINY_SQRT) { p_func = 0.0; dp_func = 0.0; }
    else { ECM_NO_SPECULATE(); const double pw = pow(at, mp.p); p_func = copysign(pw, t_frac); dp_func = mp.p * pw / at; }
    const double q_arg = 1.0 - p_func;
    if (q_arg <= TINY_SQRT) return;
    double q_func, dq_func;
-   if (mp.q == 1.0) { q_func = q_arg; dq_func = 1.0; }
+   if (PQ1 || ECM_EXP_PQ1 || mp.q == 1.0) { q_func = q_arg; dq_func = 1.0; }
    else { ECM_NO_SPECULATE(); q_func = pow(q_arg, mp.q); dq_func = mp.q * q_func / q_arg; }
    exp_arg = -c_e * q_func; dfac = c_e * dq_func * dp_func;
 }
@@ -330,7 +341,7 @@ constexpr int KD = ECM_KD;   // systems per group of the cheap classes in the de
 #define ECM_KM_DEFER 1   // athermal-threshold (BCC) variant: window systems are treated one per lane after the group loop (eval_rj)
 #endif
 constexpr int KW = ECM_KW;   // slip systems evaluated together by the Kocks-Mecking kinetics (ILP vs registers; tuned on MI355X)
-template <bool WITHD, int KW = ECM_KW>
+template <bool WITHD, int KW = ECM_KW, bool PQ1 = false>
 ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double tau[KW], double gdot[KW], double dg[KW]) {
    const double g_i = mp.with_g_athermal ? 1.0 / mp.tau_a : 1.0 / kv.g;
    const double gAth = mp.with_g_athermal ? kv.g : mp.tau_a;
@@ -361,22 +372,32 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
       bool inwin[KW], any_win = false, any_tail = false;
 #pragma unroll
       for (int a = 0; a < KW; a++) {
-         mts_dG(mp, kv.c_e, (at[a] - gAth) * g_i, eaf[a], dff[a]);
+         mts_dG<PQ1>(mp, kv.c_e, (at[a] - gAth) * g_i, eaf[a], dff[a]);
          inwin[a] = live[a] && !over[a] && !(eaf[a] < LN_GAM_RATIO_MIN);
          any_win = any_win || inwin[a];
          any_tail = any_tail || (inwin[a] && at0[a] > mp.t_min);
       }
       if (any_win) {
          double eab[KW], dfb[KW], ef[KW], eb[KW], pw[KW];
+         // backward jumps.  With p == q == 1 the exponents are eaf = -c_e (1 - t), eab = -c_e (1 + t_b), t_b >= 0, and dff == dfb == c_e; an
+         // in-window system has eaf >= ln(1e-60) = -138.2, so for c_e > 180 the backward term is below e^-41.8 = 7e-19 < 2^-54 of the forward
+         // one in both gw = gam_w (ef - eb) and its derivative: dropping it leaves every bit as it was (the shipped material sets have
+         // c_e ~ 300).  In general (and always for exp(x) == 0, x < -745.2) the call is skipped when no lane of the wave needs it.
+         const bool pq1 = ECM_KM_SKIP_BACK && (PQ1 || ECM_EXP_PQ1 || (mp.p == 1.0 && mp.q == 1.0));
+         bool any_b = false;
+         if (pq1) {
 #pragma unroll
-         for (int a = 0; a < KW; a++) mts_dG(mp, kv.c_e, (-at[a] - gAth) * g_i, eab[a], dfb[a]);
+            for (int a = 0; a < KW; a++) { eab[a] = -800.0; dfb[a] = 0.0; any_b = any_b || (inwin[a] && !(kv.c_e > 180.0)); }
+         } else any_b = true;
+         if (any_b) {
+#pragma unroll
+            for (int a = 0; a < KW; a++) mts_dG<PQ1>(mp, kv.c_e, (-at[a] - gAth) * g_i, eab[a], dfb[a]);
+            any_b = (KW != 1);     // (the grouped form keeps the unconditional call: its exp chains interleave with the forward ones)
+#pragma unroll
+            for (int a = 0; a < KW; a++) any_b = any_b || (inwin[a] && eab[a] > -746.0);
+         }
 #pragma unroll
          for (int a = 0; a < KW; a++) ef[a] = exp(eaf[a]);
-         // backward jumps: exp(x) is exactly 0 in double for x < -745.2, which is the case for every in-window system of the athermal-threshold
-         // variant ((-|tau| - g) / tau_a << -1): the call is skipped when no lane of the wave needs it (bit-identical)
-         bool any_b = (KW != 1);     // (the grouped form keeps the unconditional call: its exp chains interleave with the forward ones)
-#pragma unroll
-         for (int a = 0; a < KW; a++) any_b = any_b || (inwin[a] && eab[a] > -746.0);
          if (any_b) {
 #pragma unroll
             for (int a = 0; a < KW; a++) eb[a] = exp(eab[a]);
@@ -475,8 +496,16 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #ifndef ECM_KM_GDOT_AT_END
 #define ECM_KM_GDOT_AT_END 1   // Kocks-Mecking: slip rates written once from the converged point (A/B switch)
 #endif
+#ifndef ECM_KM_BATCH
+#define ECM_KM_BATCH 1   // p == q == 1 FCC Kocks-Mecking instantiation: batched straight-line slip loop (A/B switch)
+#endif
+#ifndef ECM_KB
+#define ECM_KB 6         // systems per batch of that form
+#endif
 #ifndef ECM_KM_FORMS_CSE
-#define ECM_KM_FORMS_CSE 0   // athermal-threshold Kocks-Mecking kernel: cheap classes through the factored slip forms - measured at 128^3: 12.7 ms against 12.3 (448 B of scratch instead of 320: this kernel is bound by spill latency, not by issue), so off
+#define ECM_KM_FORMS_CSE 2   // athermal-threshold Kocks-Mecking kernel: cheap classes through the factored slip forms: 0 never, 1 always, 2 in the
+                             // p == q == 1 instantiation only.  Measured at 128^3: general instantiation 12.7 ms against 12.3 (448 B of scratch
+                             // instead of 320: spill latency), p == q == 1 instantiation 9.6 ms against 10.4 (profiles/r03_kernel_experiments.txt)
 #endif
 #ifndef ECM_TANGENT_FIRST
 #define ECM_TANGENT_FIRST 1   // epilogue order: tangent before the state / stress outputs (see point_update)
@@ -622,7 +651,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
    }
    // (the runtime flag is always set in the KIN_KMBALD_GA instantiation; with the test compiled away the register allocator of ROCm 7.2
    //  spills 850 B/lane instead of 330 and the kernel runs 2.5x slower, so the never-taken alternative stays in that instantiation)
-   if (ECM_KM_DEFER && KIN == KIN_KMBALD_GA && mp.with_g_athermal) {
+   if (ECM_KM_DEFER && kin_base(KIN) == KIN_KMBALD_GA && mp.with_g_athermal) {
       // Athermal-threshold variant (BCC): a system is dormant (|tau| <= g), drag-limited (at_0 > t_max: one exp) or - for |tau| - g inside
       // the narrow thermally activated window (0, t_max tau_a] - needs the full balanced kinetics (four more exp/log).  About 1 % of
       // the (point, system) pairs are in the window, but a wave of 64 points x KW systems nearly always holds one, so the grouped form
@@ -632,7 +661,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       // sums changes (round-off).
       const double g_ia = 1.0 / mp.tau_a, gAth = pb.kv.g, wi = 1.0 / mp.wrD;
       unsigned pend = 0;
-#if ECM_KM_FORMS_CSE
+      if constexpr (ECM_KM_FORMS_CSE == 1 || (ECM_KM_FORMS_CSE == 2 && kin_pq1(KIN))) {
       // cheap classes of all 12 systems with static indices: resolved shear stresses through the shared partial sums (slip_tau12), one exp
       // per drag-limited system, then D^p / W^p and the Jacobian blocks of these systems through the factored forms (slip_dpwp,
       // slip_jac_blocks: 114 instead of ~540 multiply-adds per evaluation); the window systems are added by the pending loop below
@@ -676,7 +705,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
          for (int c = 0; c < 3; c++) wp[c] = PB * wps[c];
          if (WITHJ) slip_jac_blocks(dg, jac.A, jac.B);
       }
-#else
+      } else {
 #pragma unroll 1
       for (int a0 = 0; a0 < NSLIP; a0 += KD) {
          double pq[KD][8], tau[KD], gd[KD], dg[KD], xr[KD];
@@ -728,7 +757,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
             }
          }
       }
-#endif
+      }
       while (__ballot(pend != 0) != 0ull) {      // one pending window system per lane and pass
          if (pend != 0) {
             const int a = __ffs((int)pend) - 1; pend &= pend - 1;
@@ -736,7 +765,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 #pragma unroll
             for (int c = 0; c < 8; c++) pq[c] = pb.pqt ? pb.pqt[8 * a + c] : PQ_TAB[a][c];      // lane-varying row: LDS copy of the 768-byte table
             double tau1[1] = { pq[0] * k[0] + pq[1] * k[1] + pq[2] * k[2] + pq[3] * k[3] + pq[4] * k[4] }, gd1[1], dg1[1];
-            kmbald_gdot4<WITHJ, 1>(mp, pb.kv, tau1, gd1, dg1);
+            kmbald_gdot4<WITHJ, 1, kin_pq1(KIN)>(mp, pb.kv, tau1, gd1, dg1);
             if (gdot_out) gdot_out[a * pb.gs] = gd1[0];
             dis += tau1[0] * gd1[0]; shr += fabs(gd1[0]);
 #pragma unroll
@@ -759,6 +788,32 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
          }
       }
       ok = isfinite(shr);
+   } else if constexpr (ECM_KM_BATCH && kin_pq1(KIN) && kin_base(KIN) == KIN_KMBALD) {
+      // p == q == 1 instantiation without an athermal threshold (FCC): with the pow() alternatives compiled out the kinetics of a system is
+      // a short straight-line sequence (three exp), so the 12 systems go through it in batches of ECM_KB with static indices like the Voce
+      // form: resolved shear stresses, D^p / W^p and the Jacobian blocks through the factored slip forms (slip_forms_gen.hpp: 104 instead of
+      // 620 multiply-adds per evaluation), ECM_KB independent exp chains in flight per phase.  Same arithmetic per system as the rolled
+      // group loop below; the order of the 12 contributions to the sums changes (round-off).
+      double ks[5];
+#pragma unroll
+      for (int c = 0; c < 5; c++) ks[c] = PSC[c] * k[c];
+      double tau[NSLIP], gd[NSLIP], dg[NSLIP];
+      slip_tau12(ks, tau);
+#pragma unroll
+      for (int a0 = 0; a0 < NSLIP; a0 += ECM_KB) kmbald_gdot4<WITHJ, ECM_KB, true>(mp, pb.kv, tau + a0, gd + a0, dg + a0);
+#pragma unroll
+      for (int a = 0; a < NSLIP; a++) {
+         if (gdot_out) gdot_out[a * pb.gs] = gd[a];
+         dis += tau[a] * gd[a]; shr += fabs(gd[a]);
+      }
+      double dps[5], wps[3];
+      slip_dpwp(gd, dps, wps);
+#pragma unroll
+      for (int c = 0; c < 5; c++) dp[c] = PSC[c] * dps[c];
+#pragma unroll
+      for (int c = 0; c < 3; c++) wp[c] = PB * wps[c];
+      if (WITHJ) slip_jac_blocks(dg, jac.A, jac.B);
+      ok = isfinite(shr);
    } else {
 #pragma unroll 1
       for (int a0 = 0; a0 < NSLIP; a0 += KW) {   // rolled over groups: the table rows of a group come in through scalar loads
@@ -769,7 +824,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
             for (int c = 0; c < 8; c++) pq[a][c] = PQ_TAB[a0 + a][c];
             tau[a] = pq[a][0] * k[0] + pq[a][1] * k[1] + pq[a][2] * k[2] + pq[a][3] * k[3] + pq[a][4] * k[4];
          }
-         kmbald_gdot4<WITHJ>(mp, pb.kv, tau, gd, dg);
+         kmbald_gdot4<WITHJ, ECM_KW, kin_pq1(KIN)>(mp, pb.kv, tau, gd, dg);
 #pragma unroll
          for (int a = 0; a < KW; a++) {
             if (gdot_out) gdot_out[(a0 + a) * pb.gs] = gd[a];
@@ -859,6 +914,7 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
 
 // slip rates at the converged point (Kocks-Mecking family, ECM_KM_GDOT_AT_END): one more pass through the kinetics (no derivatives) instead
 // of 12 global stores per evaluation - on gfx9 every scratch reload of the Newton loop otherwise waits for those stores (vmcnt)
+template <bool PQ1>
 ECM_DI void km_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out) {
    const double k[5] = { mp.kd0 * e_f[0], mp.kd0 * e_f[1], mp.kd2 * e_f[2], mp.kd2 * e_f[3], mp.kd2 * e_f[4] };
 #pragma unroll 1
@@ -866,7 +922,7 @@ ECM_DI void km_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[
       double tau[KW], gd[KW];
 #pragma unroll
       for (int a = 0; a < KW; a++) tau[a] = PQ_TAB[a0 + a][0] * k[0] + PQ_TAB[a0 + a][1] * k[1] + PQ_TAB[a0 + a][2] * k[2] + PQ_TAB[a0 + a][3] * k[3] + PQ_TAB[a0 + a][4] * k[4];
-      kmbald_gdot4<false>(mp, pb.kv, tau, gd, nullptr);
+      kmbald_gdot4<false, ECM_KW, PQ1>(mp, pb.kv, tau, gd, nullptr);
 #pragma unroll
       for (int a = 0; a < KW; a++) stg(&gdot_out[(a0 + a) * pb.gs], gd[a]);
    }
@@ -1284,7 +1340,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       double eNew = ECM_CD(CD_ENEW);
       eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * (ECM_CD(CD_WRKOLD) + wrk_new);
       if constexpr (!kin_is_km(KIN)) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS, dis_rate, shrate);
-      else if (ECM_KM_GDOT_AT_END) km_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS);
+      else if (ECM_KM_GDOT_AT_END) km_slip_rates<kin_pq1(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS);
       stg(&sv1[(H_SHRATE) * QS], shrate);
       stg(&sv1[(H_SHR) * QS], ldg(&sv0[(H_SHR) * QS]) + shrate * dt);
       stg(&sv1[(H_FLOW) * QS], ((deff_keep > TINY_SQRT) ? dis_rate * dt : 0.0) + ldg(&sv0[(H_FLOW) * QS]));   // accumulated plastic work

@@ -8,6 +8,8 @@
 // layout; run-time tail split of long local solves into a dense second launch.
 #include "exa_internal.hpp"
 #include "p2_basis.hpp"
+#include <cstdlib>
+#include <cstring>
 
 using namespace ecmdev;
 
@@ -256,6 +258,13 @@ static void launch_model_rec(exa_ctx* ctx, double dt, double* J, const double* v
    }
 }
 
+// Kocks-Mecking sets with thermal-activation exponents p == q == 1 (the shipped sets) run the instantiation that has the two exponents
+// compiled in (ecmdev::KIN_PQ1: same arithmetic, no pow() code); EXA_KM_PQ1=off keeps the general instantiation for A/B runs
+static bool km_pq1(const exa_ctx* ctx) {
+   static const bool enabled = [] { const char* e = std::getenv("EXA_KM_PQ1"); return !(e && std::strcmp(e, "off") == 0); }();
+   return enabled && ctx->mp.p == 1.0 && ctx->mp.q == 1.0;
+}
+
 int exa_launch_model_setup_rec(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
                                double* stress1, double* state1, hipStream_t s) {
    EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->fail_count_dev, 0, sizeof(int), s));
@@ -267,7 +276,10 @@ int exa_launch_model_setup_rec(exa_ctx* ctx, double dt, double* J, const double*
       case KIN_VOCE: launch_model_rec<KIN_VOCE>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s); break;
       case KIN_VOCE_NL: launch_model_rec<KIN_VOCE_NL>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s); break;
       default:
-         if (ECM_KM_DEFER && ctx->mp.with_g_athermal) launch_model_rec<KIN_KMBALD_GA>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
+         if (km_pq1(ctx)) {
+            if (ECM_KM_DEFER && ctx->mp.with_g_athermal) launch_model_rec<KIN_KMBALD_GA | KIN_PQ1>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
+            else launch_model_rec<KIN_KMBALD | KIN_PQ1>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
+         } else if (ECM_KM_DEFER && ctx->mp.with_g_athermal) launch_model_rec<KIN_KMBALD_GA>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
          else launch_model_rec<KIN_KMBALD>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
          break;
    }
@@ -310,7 +322,10 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
          else launch_model<KIN_VOCE_NL, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
       default:
-         if (ECM_KM_DEFER && ctx->mp.with_g_athermal) {   // athermal-threshold variant (BCC): instantiation with the deferred window systems
+         if (lv && ctx->n == 8 && ctx->qblk && km_pq1(ctx)) {   // p = 1 element-blocked route with the tangent field (Jacobi / element-assembly set-ups)
+            if (ECM_KM_DEFER && ctx->mp.with_g_athermal) launch_model_q<KIN_KMBALD_GA | KIN_PQ1, true, 8, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+            else launch_model_q<KIN_KMBALD | KIN_PQ1, true, 8, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         } else if (ECM_KM_DEFER && ctx->mp.with_g_athermal) {   // athermal-threshold variant (BCC): instantiation with the deferred window systems
             if (lv) launch_model<KIN_KMBALD_GA, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
             else launch_model<KIN_KMBALD_GA, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          } else {
