@@ -133,6 +133,21 @@ ECM_DI double frcp(double x) {
    return y;
 }
 
+// log(x) for x in [0.75, 1.25] (|error| ~ 1 ulp): 2 atanh(s), s = (x - 1) / (x + 1) <= 0.112 with the quotient corrected by one residual step;
+// 25 FP64 instructions instead of the ~60 of the general routine (its table / double-double range reduction is not needed this close to 1)
+ECM_DI double log_near1(double x) {
+   const double w = x - 1.0, d = 2.0 + w;       // w exact for x in [0.5, 2]
+   const double di = frcp(d);
+   double s = w * di;
+   s = fma(fma(-s, d, w), di, s);
+   const double s2 = s * s;
+   double P = 1.0 / 17.0;
+   P = fma(P, s2, 1.0 / 15.0); P = fma(P, s2, 1.0 / 13.0); P = fma(P, s2, 1.0 / 11.0); P = fma(P, s2, 1.0 / 9.0);
+   P = fma(P, s2, 1.0 / 7.0); P = fma(P, s2, 1.0 / 5.0); P = fma(P, s2, 1.0 / 3.0);
+   const double s_2 = s + s;
+   return fma(s_2 * s2, P, s_2);
+}
+
 ECM_DI void vecd_to_sym(const double v[5], double& t00, double& t11, double& t22, double& t01, double& t02, double& t12) {
    const double t1 = SQR2I * v[0], t2 = SQR6I * v[1];
    t00 = t1 - t2; t11 = -t1 - t2; t22 = SQR2B3 * v[1]; t01 = SQR2I * v[2]; t02 = SQR2I * v[3]; t12 = SQR2I * v[4];
@@ -301,6 +316,12 @@ ECM_DI void voce_gdot12(const MatParams& mp, double g_i, const double tau[NSLIP]
 // keeps a uniform branch a branch: without it the compiler speculates the (pure) pow() of the general case and selects afterwards,
 // i.e. every call pays two full pow() expansions (~400 instructions) even when p == q == 1
 #define ECM_NO_SPECULATE() asm volatile("" ::: "memory")
+#ifndef ECM_KM_LOG_NEAR1
+#define ECM_KM_LOG_NEAR1 1   // Kocks-Mecking power-law tail: short-series logarithm when (t_min, t_max] lies in [0.75, 1.25] (A/B switch)
+#endif
+#ifndef ECM_KM_ONE_RCP
+#define ECM_KM_ONE_RCP 1     // Kocks-Mecking: series combination of the thermal and drag branches with one reciprocal instead of three (A/B switch)
+#endif
 #ifndef ECM_EXP_PQ1
 #define ECM_EXP_PQ1 0   // timing experiment: p == q == 1 known at compile time (no pow() code in the kinetics at all)
 #endif
@@ -422,6 +443,11 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
 #pragma unroll
                   for (int a = 0; a < KW; a++) b[a] *= b[a];
                }
+            } else if (ECM_KM_LOG_NEAR1 && mp.t_min >= 0.75 && mp.t_max <= 1.25) {
+               // the tail is only used for t_min < at0 <= t_max, and with 1/m = 2 c_e p q of a few hundred both bounds are close to 1
+               // (1e-60^m, 1e45^m): logarithm by the short series (other lanes compute a finite value that is not used)
+#pragma unroll
+               for (int a = 0; a < KW; a++) pw[a] = exp(mp.xn * log_near1(at0[a]));
             } else {
 #pragma unroll
                for (int a = 0; a < KW; a++) pw[a] = exp(mp.xn * log(fmax(at0[a], 1.0e-300)));
@@ -436,9 +462,16 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
             gw += tail ? temp * at0[a] : 0.0;
             dgw += tail ? temp * mp.xnn * g_i : 0.0;
             const bool valid = inwin[a] && (gw > 0.0);
+#if ECM_KM_ONE_RCP
+            // series combination of the two branches 1 / (1/gw + 1/gr) = gw gr / (gw + gr) with one reciprocal (lanes that are not `valid` may hold junk here)
+            const double R = frcp(gw + gr[a]);
+            const double gd = (gw * gr[a]) * R;
+            if (valid) { gdot[a] = copysign(gd, tau[a]); if (WITHD) dg[a] = (dgw * (gr[a] * gr[a]) + dgr[a] * (gw * gw)) * (R * R); }
+#else
             const double r1 = frcp(gw), r2 = frcp(gr[a]);   // series combination of the two branches; lanes that are not `valid` may hold junk here
             const double gd = frcp(r1 + r2);
             if (valid) { gdot[a] = copysign(gd, tau[a]); if (WITHD) dg[a] = gd * gd * (dgw * r1 * r1 + dgr[a] * r2 * r2); }
+#endif
          }
       }
    }
@@ -495,6 +528,9 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 // every earlier store of the wave (vmcnt), so anything that must survive the Newton loop belongs in LDS, not in global memory.
 #ifndef ECM_KM_GDOT_AT_END
 #define ECM_KM_GDOT_AT_END 1   // Kocks-Mecking: slip rates written once from the converged point (A/B switch)
+#endif
+#ifndef ECM_KEEP_DOGLEG
+#define ECM_KEEP_DOGLEG 1   // Kocks-Mecking: dog-leg data kept across a trial evaluation instead of a re-evaluation after a rejection (A/B switch)
 #endif
 #ifndef ECM_KM_BATCH
 #define ECM_KM_BATCH 1   // p == q == 1 FCC Kocks-Mecking instantiation: batched straight-line slip loop (A/B switch)
@@ -1219,32 +1255,47 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
 #endif
    if (ok && !conv) {
       double delta = 1.0;
+      // Kocks-Mecking without athermal threshold (ECM_KEEP_DOGLEG): the dog-leg ingredients of the accepted point - Newton step, steepest-descent direction and its
+      // three scalars - are computed with every accepted evaluation and kept across the trial, like SNLS does (reject_prev), so a rejected
+      // trial only restores x and shrinks the trust region: no second evaluation at the old point.  With these kinetics nearly every wave
+      // holds a rejecting lane in every iteration, i.e. the re-evaluation of the Voce form below (rare per lane) was paid by all of them.
+      // (not the athermal-threshold variant: its main launch rarely rejects, and the 20 values carried through the evaluation cost 7 % there)
+      constexpr bool KEEP = ECM_KEEP_DOGLEG && kin_base(KIN) == KIN_KMBALD;
+      double nr[8], grad[8], nr2sq = 0.0, norm2_grad = 0.0, Jg_2 = 0.0, s2 = 0.0;
+      bool reject_prev = false;
+      auto dogleg_data = [&]() {   // grad = Js^T r, Jg = Js grad, s2 = |r + Js sd_opt|^2 (all in SNLS's scaled variables)
+         double u[8], rs[8], tt[8];
+         for (int i = 0; i < 8; i++) rs[i] = r[i] * pb.sc;
+         jac_mult_T(mp, pb, J, rs, tt);
+         for (int i = 0; i < 8; i++) { const double cs = (i < 5) ? pb.esc : R_SCALE; grad[i] = pb.sc * cs * tt[i]; u[i] = cs * grad[i]; }
+         jac_mult(mp, pb, J, u, tt);
+         Jg_2 = 0; norm2_grad = 0;
+         for (int i = 0; i < 8; i++) { const double jg = pb.sc * tt[i]; Jg_2 += jg * jg; norm2_grad += grad[i] * grad[i]; }
+         const double fac = (Jg_2 > 0) ? norm2_grad / Jg_2 : 0.0;
+         s2 = 0; for (int i = 0; i < 8; i++) { const double v = rs[i] - fac * pb.sc * tt[i]; s2 += v * v; }
+      };
       for (int it = 0; it < 200; it++) {
          // tail split: a point that needs more than kcap evaluations is handed to the dense tail launch (which starts over, so the
          // result is the one of an uncapped solve); the wave stops waiting for its slowest lanes
          if (nfev >= kcap) return 2;
          // Newton step first; the steepest-descent data (grad = Js^T r, Jg = Js grad) only when the step leaves the trust region
-         double nr[8], t[8];
-         jac_factor(mp, pb, J, F);
-         double nr2sq;
-         if (F.ok) {
-            double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i];
-            jac_solve<false, 2>(mp, pb, J, F, rhs, t);
-            const double esc_i = ECM_ST(st, ST_PB + PB_ESCI);
-            for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? esc_i : (1.0 / R_SCALE));
-            nr2sq = norm8sq(nr);
-         } else { nr2sq = 1e300; for (int i = 0; i < 8; i++) nr[i] = 0; }
+         if (!KEEP || !reject_prev) {
+            double t[8];
+            jac_factor(mp, pb, J, F);
+            if (F.ok) {
+               double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i];
+               jac_solve<false, 2>(mp, pb, J, F, rhs, t);
+               const double esc_i = ECM_ST(st, ST_PB + PB_ESCI);
+               for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? esc_i : (1.0 / R_SCALE));
+               nr2sq = norm8sq(nr);
+            } else { nr2sq = 1e300; for (int i = 0; i < 8; i++) nr[i] = 0; }
+            if (KEEP) dogleg_data();
+         }
          double delx[8], pred_resid; bool use_nr = false;
          if (nr2sq <= delta * delta) { use_nr = true; for (int i = 0; i < 8; i++) delx[i] = nr[i]; pred_resid = 0.0; }
          else {
+            if (!KEEP) dogleg_data();
             const double res_0 = sqrt(res2_0);
-            double grad[8], u[8], rs[8];
-            for (int i = 0; i < 8; i++) rs[i] = r[i] * pb.sc;
-            jac_mult_T(mp, pb, J, rs, t);
-            for (int i = 0; i < 8; i++) { const double cs = (i < 5) ? pb.esc : R_SCALE; grad[i] = pb.sc * cs * t[i]; u[i] = cs * grad[i]; }
-            jac_mult(mp, pb, J, u, t);
-            double Jg_2 = 0, norm2_grad = 0;
-            for (int i = 0; i < 8; i++) { const double jg = pb.sc * t[i]; Jg_2 += jg * jg; norm2_grad += grad[i] * grad[i]; }
             const double norm_grad = sqrt(norm2_grad);
             const double fac = (Jg_2 > 0) ? norm2_grad / Jg_2 : 0.0;
             const double norm_s_sd_opt = (Jg_2 > 0) ? fac * norm_grad : 1e300;
@@ -1254,7 +1305,6 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
                pred_resid = sqrt(fmax(res_0 * res_0 - 2.0 * delta * norm_grad + delta * delta * Jg_2 / norm2_grad, 0.0));
             } else {
                // |r + Js sd|, sd = -fac grad: the Newton point zeroes the linear model, so the dog-leg point predicts (1-beta) of it
-               double s2 = 0; for (int i = 0; i < 8; i++) { const double v = rs[i] - fac * pb.sc * t[i]; s2 += v * v; }
                double qa = 0, qb = 0;
                for (int i = 0; i < 8; i++) { const double sd = -grad[i] * fac, p = nr[i] - sd; qa += p * p; qb += p * sd; }
                const double qc = norm_s_sd_opt * norm_s_sd_opt - delta * delta;
@@ -1291,9 +1341,11 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
             reject = (res2 > res2_0);
             if (!reject) res2_0 = res2;
          }
+         reject_prev = reject;
          if (reject) {
             for (int i = 0; i < 8; i++) x[i] = ECM_ST(st, ST_XS + i);
-            ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);   // restore (r, J) of the accepted point
+            if (!KEEP) ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);   // restore (r, J) of the accepted point
+            else ok = true;   // (the accepted point evaluated fine; r and J hold the rejected trial until the next accepted evaluation)
             if (!ok || delta <= 1e-12) break;
          }
       }
