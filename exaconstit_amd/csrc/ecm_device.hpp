@@ -133,6 +133,37 @@ ECM_DI double frcp(double x) {
    return y;
 }
 
+// exp for N arguments (Kocks-Mecking kinetics: three exponentials per slip system and evaluation).  Same algorithm as the library routine -
+// n = rint(x log2 e), r = x - n ln2 (two-term), polynomial, ldexp - without its overflow / underflow selects: arguments are clamped to
+// [-800, 720], where ldexp itself produces 0 / inf; Taylor degree 13 on |r| <= ln2 / 2 (truncation 4e-18), |error| <= 1.5 ulp.  22 FP64
+// instructions per value instead of 38.  The values are computed one after the other (ECM_KM_EXP == 1: the empty asm keeps the compiler
+// from interleaving them): at 128^3 the interleaved form costs FCC 24.1 ms against 21.2 - the kernel has no registers left for six
+// polynomial chains in flight, and two waves per SIMD hide the FMA latency of a single chain.
+#ifndef ECM_KM_EXP
+#define ECM_KM_EXP 1   // A/B switch: 0 = library exp(), 1 = this routine, 2 = this routine, interleaving left to the compiler
+#endif
+template <int N, bool FAST>   // FAST = false: library routine (the general instantiations, whose register allocation the routine upsets)
+ECM_DI void exp_n(double v[N]) {
+   if constexpr (ECM_KM_EXP != 0 && FAST) {
+   constexpr double tab[14] = { 1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
+      1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0 };
+#pragma unroll
+   for (int a = 0; a < N; a++) {
+      const double x = fmin(fmax(v[a], -800.0), 720.0); const double n = rint(x * tab[0]); double r = fma(n, tab[1], x); r = fma(n, tab[2], r);
+      double p = fma(tab[3], r, tab[4]);
+#pragma unroll
+      for (int k = 5; k < 14; k++) p = fma(p, r, tab[k]);
+      p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0); v[a] = ldexp(p, (int)n);
+#if ECM_KM_EXP == 1
+      asm volatile("" : "+v"(v[a]));
+#endif
+   }
+   } else {
+#pragma unroll
+   for (int a = 0; a < N; a++) v[a] = exp(v[a]);
+   }
+}
+
 // log(x) for x in [0.75, 1.25] (|error| ~ 1 ulp): 2 atanh(s), s = (x - 1) / (x + 1) <= 0.112 with the quotient corrected by one residual step;
 // 25 FP64 instructions instead of the ~60 of the general routine (its table / double-double range reduction is not needed this close to 1)
 ECM_DI double log_near1(double x) {
@@ -380,7 +411,8 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
    if (any_live) {
       double ex[KW], gr[KW], dgr[KW];
 #pragma unroll
-      for (int a = 0; a < KW; a++) ex[a] = exp(-fmax(xr[a], 0.0));
+      for (int a = 0; a < KW; a++) ex[a] = -fmax(xr[a], 0.0);
+      exp_n<KW, PQ1>(ex);
 #pragma unroll
       for (int a = 0; a < KW; a++) {
          const bool small = xr[a] < EPS_SQRT;
@@ -418,10 +450,12 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
             for (int a = 0; a < KW; a++) any_b = any_b || (inwin[a] && eab[a] > -746.0);
          }
 #pragma unroll
-         for (int a = 0; a < KW; a++) ef[a] = exp(eaf[a]);
+         for (int a = 0; a < KW; a++) ef[a] = eaf[a];
+         exp_n<KW, PQ1>(ef);
          if (any_b) {
 #pragma unroll
-            for (int a = 0; a < KW; a++) eb[a] = exp(eab[a]);
+            for (int a = 0; a < KW; a++) eb[a] = eab[a];
+            exp_n<KW, PQ1>(eb);
          } else {
 #pragma unroll
             for (int a = 0; a < KW; a++) eb[a] = 0.0;
@@ -447,10 +481,12 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
                // the tail is only used for t_min < at0 <= t_max, and with 1/m = 2 c_e p q of a few hundred both bounds are close to 1
                // (1e-60^m, 1e45^m): logarithm by the short series (other lanes compute a finite value that is not used)
 #pragma unroll
-               for (int a = 0; a < KW; a++) pw[a] = exp(mp.xn * log_near1(at0[a]));
+               for (int a = 0; a < KW; a++) pw[a] = mp.xn * log_near1(at0[a]);
+               exp_n<KW, PQ1>(pw);
             } else {
 #pragma unroll
-               for (int a = 0; a < KW; a++) pw[a] = exp(mp.xn * log(fmax(at0[a], 1.0e-300)));
+               for (int a = 0; a < KW; a++) pw[a] = mp.xn * log(fmax(at0[a], 1.0e-300));
+               exp_n<KW, PQ1>(pw);
             }
          }
 #pragma unroll
@@ -536,7 +572,7 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #define ECM_KM_BATCH 1   // p == q == 1 FCC Kocks-Mecking instantiation: batched straight-line slip loop (A/B switch)
 #endif
 #ifndef ECM_KB
-#define ECM_KB 6         // systems per batch of that form
+#define ECM_KB 4         // systems per batch of that form (3, 4, 6 within 1.5 % of each other; 12: +70 %)
 #endif
 #ifndef ECM_KM_FORMS_CSE
 #define ECM_KM_FORMS_CSE 2   // athermal-threshold Kocks-Mecking kernel: cheap classes through the factored slip forms: 0 never, 1 always, 2 in the
@@ -719,9 +755,13 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
             if (!(live && over)) xr[a] = -1.0; else any_drag = true;
          }
          if (any_drag) {
+            double exv[NSLIP];
+#pragma unroll
+            for (int a = 0; a < NSLIP; a++) exv[a] = -fmax(xr[a], 0.0);
+            exp_n<NSLIP, kin_pq1(KIN)>(exv);
 #pragma unroll
             for (int a = 0; a < NSLIP; a++) {
-               const double ex = exp(-fmax(xr[a], 0.0));
+               const double ex = exv[a];
                const bool small = xr[a] < EPS_SQRT;
                const double gr = small ? pb.kv.gam_r * xr[a] : pb.kv.gam_r * (1.0 - ex);
                const double dgr = (small ? pb.kv.gam_r : pb.kv.gam_r * ex) * wi;
@@ -761,7 +801,8 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
          if (any_live) {
             double ex[KD];
 #pragma unroll
-            for (int a = 0; a < KD; a++) ex[a] = exp(-fmax(xr[a], 0.0));
+            for (int a = 0; a < KD; a++) ex[a] = -fmax(xr[a], 0.0);
+            exp_n<KD, kin_pq1(KIN)>(ex);
 #pragma unroll
             for (int a = 0; a < KD; a++) {
                const bool small = xr[a] < EPS_SQRT;
