@@ -80,7 +80,7 @@ exa_ctx* exa_create(const exa_config* cfg, int* err) {
 void exa_destroy(exa_ctx* ctx) {
    if (!ctx) return;
    (void)hipFree(ctx->n2e_off); (void)hipFree(ctx->n2e_idx); (void)hipFree(ctx->ev_det);
-   (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->tail_dev); (void)hipFree(ctx->scratch_dev);
+   (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->tail_dev); (void)hipFree(ctx->tail2_dev); (void)hipFree(ctx->resume_dev[0]); (void)hipFree(ctx->resume_dev[1]); (void)hipFree(ctx->scratch_dev);
    (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->T1_dev); (void)hipFree(ctx->pa_c); (void)hipFree(ctx->tbuf);
    delete ctx;
 }
@@ -161,7 +161,12 @@ int exa_model_status(exa_ctx* ctx, exa_stream s) {
 int exa_set_newton_cap(exa_ctx* ctx, int max_evals) {
    if (!ctx || (max_evals != 0 && max_evals < 2)) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_cap: 0 (off) or >= 2");
    if (max_evals && ctx->P >= (int64_t)INT32_MAX) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_cap: the deferred-point list holds 32-bit point ids (P < 2^31)");
-   ctx->newton_cap = max_evals; return EXA_OK;
+   ctx->newton_cap = max_evals; ctx->newton_cap2 = 0; return EXA_OK;
+}
+int exa_set_newton_caps(exa_ctx* ctx, int max_evals, int max_evals_2, int resume) {
+   if (int rc = exa_set_newton_cap(ctx, max_evals)) return rc;
+   if (max_evals_2 != 0 && (max_evals == 0 || max_evals_2 <= max_evals || !resume)) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_caps: the second cap needs a first one below it and resume = 1");
+   ctx->newton_cap2 = max_evals_2; ctx->tail_resume = resume ? 1 : 0; return EXA_OK;
 }
 int exa_model_nfev_hist(exa_ctx* ctx, const double* state, int* hist64_host, exa_stream s) {
    if (!ctx || !state || !hist64_host) return fail(ctx, EXA_ERR_ARG, "exa_model_nfev_hist: null pointer");

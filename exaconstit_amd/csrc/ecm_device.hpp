@@ -51,6 +51,9 @@ __device__ __forceinline__ void stg(double* p, double v) {
 
 // history layout (reference src/mechanics_ecmech.hpp:165-185)
 constexpr int H_SHRATE = 0, H_SHR = 1, H_FLOW = 2, H_NFEV = 3, H_E = 4, H_Q = 9, H_H = 13, H_GDOT = 14;
+constexpr int RS_N = 10;   // doubles of a cut-off point's solver state (point_update, TailIO)
+// tail split (model_kernels.hip, launch_levels): where a cut-off point goes, and the saved state a listed point resumes from (already offset to its slot)
+struct TailIO { int* list_out = nullptr; double* rs_out = nullptr; const double* rs_in = nullptr; int64_t stride = 0; int ipt = 0; };
 constexpr int NUM_HIST = 26, NSTATEV = 28, IND_VOL = 26, IND_EINT = 27;
 
 enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2,
@@ -1207,7 +1210,8 @@ ECM_DI double norm8sq(const double v[8]) { double s = 0; for (int i = 0; i < 8; 
 template <int KIN, int QS, bool REC = false>
 ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const double* __restrict__ sv0, const double* __restrict__ s0,
                         double* __restrict__ sv1, double* __restrict__ s1, double* __restrict__ cmat, double* st, const int kcap,
-                        const double* pq_lds = nullptr, const double tsc = 0.0, const bool trd = false) {
+                        const double* pq_lds = nullptr, const double tsc = 0.0, const bool trd = false, const TailIO tio = TailIO()) {
+   const bool resume = tio.rs_in != nullptr;
    // parking area for the cold values that do not fit the LDS stash: the point's own output slot (written last)
    constexpr int CSTR = REC ? 128 : QS;
    double* cold = REC ? cmat : cmat + ST_NCD * QS;
@@ -1276,7 +1280,11 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    // ---- trust-region dog-leg Newton (SNLS "TrDlDenseG" defaults).  Every evaluation leaves (r, J, slip rates, dissipation) of
    // the point it was asked for; a rejected trial is followed by a re-evaluation at the restored point (rare), so nothing but x
    // and a few scalars has to survive an evaluation and the converged evaluation doubles as the one the tangent needs.
+   // TailIO: a point that is cut off after kcap evaluations appends itself to list_out and leaves its solver state - the accepted iterate x, the
+   // trust radius and the evaluation count - in rs_out at its list slot.  A launch that is handed such a state (rs_in) starts from it: one evaluation at x restores (r, J) (not counted:
+   // it repeats one the cut-off launch has made, bit for bit), then the iteration goes on as if it had never stopped.
    double x[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+   if (resume) { for (int i = 0; i < 8; i++) x[i] = ldg(&tio.rs_in[i * tio.stride]); }
    double r[8], dis_rate, shrate;
    Jac J; Fact F;
    double* gdot_out = (kin_is_km(KIN) && !ECM_KM_GDOT_AT_END) ? sv1 + H_GDOT * QS : nullptr;
@@ -1290,12 +1298,13 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    const double tol2 = mp.tol * mp.tol, sc2 = pb.sc * pb.sc;
    double res2_0 = sc2 * norm8sq(r);
    ok = ok && isfinite(res2_0);
-   if (ok && res2_0 < tol2) conv = true;
+   if (ok && res2_0 < tol2 && !resume) conv = true;
 #ifdef ECM_EXP_SKIP_SOLVE   // timing experiment only (scripts/tune_model.sh): no Newton iterations, the rest of the launch unchanged
    conv = true;
 #endif
    if (ok && !conv) {
       double delta = 1.0;
+      if (resume) { delta = ldg(&tio.rs_in[8 * tio.stride]); nfev = (int)ldg(&tio.rs_in[9 * tio.stride]); }
       // Kocks-Mecking without athermal threshold (ECM_KEEP_DOGLEG): the dog-leg ingredients of the accepted point - Newton step, steepest-descent direction and its
       // three scalars - are computed with every accepted evaluation and kept across the trial, like SNLS does (reject_prev), so a rejected
       // trial only restores x and shrinks the trust region: no second evaluation at the old point.  With these kinetics nearly every wave
@@ -1318,7 +1327,15 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       for (int it = 0; it < 200; it++) {
          // tail split: a point that needs more than kcap evaluations is handed to the dense tail launch (which starts over, so the
          // result is the one of an uncapped solve); the wave stops waiting for its slowest lanes
-         if (nfev >= kcap) return 2;
+         if (nfev >= kcap) {
+            const int slot = atomicAdd(&tio.list_out[0], 1); tio.list_out[1 + slot] = tio.ipt;
+            if (tio.rs_out) {
+               double* o = tio.rs_out + slot;
+               for (int i = 0; i < 8; i++) stg(&o[i * tio.stride], x[i]);
+               stg(&o[8 * tio.stride], delta); stg(&o[9 * tio.stride], (double)nfev);
+            }
+            return 2;
+         }
          // Newton step first; the steepest-descent data (grad = Js^T r, Jg = Js grad) only when the step leaves the trust region
          if (!KEEP || !reject_prev) {
             double t[8];

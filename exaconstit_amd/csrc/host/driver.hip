@@ -301,8 +301,13 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    cap_auto_ = (opt.slip == SlipType::MTSDD);
    if (const char* nc = std::getenv("EXA_NEWTON_CAP")) {
       if (std::string(nc) == "auto") cap_auto_ = true;
-      else { cap_auto_ = false; newton_cap_ = (std::string(nc) == "off") ? 0 : std::atoi(nc); }
+      else {   // "off", "<K>" or "<K>,<K2>" (second level)
+         cap_auto_ = false; newton_cap_ = (std::string(nc) == "off") ? 0 : std::atoi(nc);
+         if (const char* c2 = std::strchr(nc, ',')) newton_cap2_ = std::atoi(c2 + 1);
+      }
    }
+   tail_resume_ = !env_is_off("EXA_TAIL_RESUME");   // A/B switch: the dense launch starts its points over (round 2) instead of resuming them
+   if (!tail_resume_) newton_cap2_ = 0;
    tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.0 : 4.0;   // (Kocks-Mecking: re-measured in round 3 after the slip-rate stores left the Newton loop: 1.5 -> 1.0 picks cap 5 for FCC, 38.7 instead of 40.2 ms; BCC unchanged)
    if (const char* tc = std::getenv("EXA_TAIL_COST")) { const double v = std::atof(tc); if (v > 0.0) tail_cost_ = v; }   // A/B switch of the controller's cost model
    // element assembly: the element matrices are 2x (p = 1) to 5x (p = 2) the bytes of the records they are built from, so the action is
@@ -321,7 +326,7 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    records_setup_ = fast_p1_ && compact_tangent_ && fused_setup_ && !det && !env_is_off("EXA_TANGENT_RECORDS") &&
                     !(std::getenv("EXA_QLAYOUT") && std::string(std::getenv("EXA_QLAYOUT")) == "aos");
    if (det) { abi_check(ctx_, exa_set_deterministic(ctx_, 1), "exa_set_deterministic"); comm_.deterministic = true; }
-   abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");   // A/B switch for measurements; the fused launch is the product path
+   abi_check(ctx_, exa_set_newton_caps(ctx_, newton_cap_, newton_cap2_, tail_resume_ ? 1 : 0), "exa_set_newton_caps");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 and p = 2 paths (EXA_QLAYOUT=aos switches back for A/B runs)
    const char* ql = std::getenv("EXA_QLAYOUT");
    lvec_resid_ = fast_p1_ || (part.p == 2 && !det);      // fused L-vector residual kernels (p = 1 full integration; p = 2 plain and B-bar)
@@ -367,6 +372,44 @@ void NonlinearMechOperator::UpdateEssTDofs(const std::vector<uint8_t>& mask) { e
 // Kocks-Mecking kernel; 0.2 = the second launch's fixed cost.  Measured at 128^3: BCC KM-DD 31.6 -> 16.0 ms, FCC KM-DD 70.9 -> 55.9 ms,
 // Voce stays uncapped (6.9 ms; K = 5 would cost 10.2 ms, which the model reproduces).  Round 3: w = 1.0 for Kocks-Mecking (EXA_TAIL_COST overrides).
 // Returns the K minimising C, or 0 (off) when it does not beat the uncapped launch by 3 %.
+// With resumed tail points (exa_set_newton_caps) a listed point does not repeat its K evaluations: the dense launch pays the point set-up again
+// (~0.7 evaluations), one evaluation that restores (r, J), and the evaluations beyond K.  A second cap K2 splits the dense launch once more:
+//   C(K, K2) = Emax64(min(n,K)) + 0.2 + f1 w (Emax64(min(n,K2) | n > K) - K + 1.7) + [0.2 + f2 w (Emax64(n | n > K2) - K2 + 1.7)]
+// The pair (K, K2) minimising C is returned (K2 = 0: one dense launch), or (0, 0) when it does not beat the uncapped launch by 3 %.
+void choose_newton_caps_resume(const int* hist, double w, int& k1, int& k2) {
+   k1 = k2 = 0;
+   double tot = 0; for (int i = 0; i < 64; i++) tot += hist[i];
+   if (tot <= 0) return;
+   // E[max of 64 draws] of min(n, hi) over the population n > lo
+   auto emax = [&](int lo, int hi) {
+      double n = 0; for (int m = lo + 1; m < 64; m++) n += hist[m];
+      if (n <= 0) return 0.0;
+      double F = 0, prev = 0, e = 0;
+      for (int m = lo + 1; m <= hi; m++) {
+         double pm = hist[m]; if (m == hi) for (int j = hi + 1; j < 64; j++) pm += hist[j];
+         F += pm / n; const double f64 = std::pow(std::min(F, 1.0), 64.0); e += m * (f64 - prev); prev = f64;
+      }
+      return e;
+   };
+   auto above = [&](int k) { double n = 0; for (int m = k + 1; m < 64; m++) n += hist[m]; return n / tot; };
+   const double c_inf = emax(-1, 63);
+   double best = c_inf;
+   for (int K = 3; K < 40; K++) {
+      const double f1 = above(K);
+      if (f1 == 0) break;
+      const double first = emax(-1, K) + 0.2;
+      {  const double c = first + f1 * w * (emax(K, 63) - K + 1.7);
+         if (c < best) { best = c; k1 = K; k2 = 0; } }
+      for (int K2 = K + 2; K2 < 48; K2++) {
+         const double f2 = above(K2);
+         if (f2 == 0) break;
+         const double c = first + f1 * w * (emax(K, K2) - K + 1.7) + 0.2 + f2 * w * (emax(K2, 63) - K2 + 1.7);
+         if (c < best) { best = c; k1 = K; k2 = K2; }
+      }
+   }
+   if (!(best < 0.97 * c_inf)) k1 = k2 = 0;
+}
+
 int choose_newton_cap(const int* hist, double tail_cost_) {
    double tot = 0; for (int i = 0; i < 64; i++) tot += hist[i];
    if (tot <= 0) return 0;
@@ -414,8 +457,10 @@ void NonlinearMechOperator::Setup(const double* k) {
    model_status_pending_ = true;
    if (cap_auto_ && (model_calls <= 4 || model_calls % 4 == 0)) {   // tail split: next cap from the evaluation counts of this launch (the distribution drifts slowly)
       int h[64]; abi_check(ctx_, exa_model_nfev_hist(ctx_, matVars1.p, h, stream_), "exa_model_nfev_hist");
-      newton_cap_ = choose_newton_cap(h, tail_cost_);
-      abi_check(ctx_, exa_set_newton_cap(ctx_, newton_cap_), "exa_set_newton_cap");
+      // (one dense launch: measured at 128^3, a second level loses - FCC 5: 18.0 ms, 5+11: 19.0, 4+6: 21.1; BCC 4: 9.7, 3+5: 13.1 - because
+      //  the dense launches pay for scattered 8-byte accesses into the blocked rows, not for idle lanes; EXA_NEWTON_CAP=K,K2 runs two levels)
+      newton_cap_ = choose_newton_cap(h, tail_cost_); newton_cap2_ = 0;
+      abi_check(ctx_, exa_set_newton_caps(ctx_, newton_cap_, newton_cap2_, tail_resume_ ? 1 : 0), "exa_set_newton_caps");
    }
 }
 template void NonlinearMechOperator::Setup<true>(const double*);

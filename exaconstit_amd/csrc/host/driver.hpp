@@ -88,6 +88,7 @@ class ExaCMechModel {
 
 // tail-split controller (see driver.hip): cap on local-solver evaluations from a 64-bin histogram of their counts; 0 = no cap
 int choose_newton_cap(const int* hist64, double tail_cost);
+void choose_newton_caps_resume(const int* hist64, double tail_cost, int& k1, int& k2);
 
 class NonlinearMechOperator {
  public:
@@ -142,7 +143,7 @@ class NonlinearMechOperator {
    void ensure_mat_grad();
    bool overlap_ = false; int nblk_bdr_ = 0;   // halo exchange overlapped with the interior element blocks (several ranks, atomic p = 1 record action)
    bool fast_p1_ = true, lvec_grad_ = true, fused_setup_ = true; bool lvec_resid_ = false; bool compact_tangent_ = false;
-   bool cap_auto_ = true; int newton_cap_ = 0; double tail_cost_ = 4.0;
+   bool cap_auto_ = true; int newton_cap_ = 0, newton_cap2_ = 0; bool tail_resume_ = true; double tail_cost_ = 4.0;
    DevBuf<double> tmp_l_, tmp_r_, el_y_, el_x2_;
 };
 

@@ -231,6 +231,7 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out, char* err, int e
 }
 
 int exa_choose_newton_cap(const int* hist64, double tail_cost) { return choose_newton_cap(hist64, tail_cost); }
+int exa_choose_newton_caps(const int* hist64, double tail_cost, int* k1, int* k2) { if (!hist64 || !k1 || !k2) return -1; choose_newton_caps_resume(hist64, tail_cost, *k1, *k2); return 0; }
 
 int exa_options_query(const char* toml_path, double* out, char* err, int errlen) {
    try {

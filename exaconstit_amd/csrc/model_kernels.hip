@@ -35,7 +35,11 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
                                                      const double* __restrict__ state0, double* __restrict__ stress1,
                                                      double* __restrict__ state1, double* __restrict__ cmat, int* __restrict__ fail,
                                                      const int kcap, int* __restrict__ tail, const int tail_mode,
-                                                     const double* __restrict__ Wq = nullptr, const int trd = 0) {
+                                                     const double* __restrict__ Wq = nullptr, const int trd = 0,
+                                                     int* __restrict__ tail_out = nullptr, const double* __restrict__ rs_in = nullptr, double* __restrict__ rs_out = nullptr) {
+   // tail: list this launch works on (tail_mode) or appends to; tail_out: list a tail launch appends the points to that it cuts off itself
+   // (second level); rs_in / rs_out: solver states of the listed points, [RS_N][P] by list slot (nullptr: a listed point starts over)
+   if (!tail_out) tail_out = tail;
    static_assert(!REC || (LVEC && QB && NFIX == 8), "record output is built for the fused element-blocked p = 1 launch");
    if (tail_mode && (int64_t)blockIdx.x * blockDim.x >= tail[0]) return;   // tail launch: its grid covers the worst case, blocks beyond the list leave before the table fill
    const int n = NFIX ? NFIX : n_rt;
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
       if (t >= tail[0]) return;
       const int64_t ipt = tail[1 + t];
       q = (int)(ipt % Q); e = ipt / Q;
+      if (rs_in) rs_in += t;   // this point's slot
    } else if (QB) {   // wave = (block of 64 elements, q); lane = element
       const int64_t gw = bidx * (blockDim.x >> 6) + (threadIdx.x >> 6);
       q = (int)(gw % Q); e = (gw / Q) * 64 + (threadIdx.x & 63);
@@ -156,9 +161,9 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    double* st = sG + tab + threadIdx.x;
    // REC: the lane's first 16-byte pair of its compact record ([block][q][13 pairs][64 lanes][2])
    double* tout = REC ? cmat + pac_off<PAC_PAIRS>(e >> 6, Q, q, 0) + 2 * (e & 63) : cmat + vC.base;
-   const int rc = point_update<KIN, QS, REC>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, tout, st, kcap, sG + pqo, tsc, trd != 0);
-   if (rc == 2) { const int slot = atomicAdd(&tail[0], 1); tail[1 + slot] = (int)(e * Q + q); }
-   else if (rc) atomicAdd(fail, 1);
+   const int rc = point_update<KIN, QS, REC>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, tout, st, kcap, sG + pqo, tsc, trd != 0,
+                                             TailIO{ tail_out, rs_out, tail_mode ? rs_in : nullptr, P, (int)(e * Q + q) });
+   if (rc == 1) atomicAdd(fail, 1);
 }
 
 template <bool QB>
@@ -220,6 +225,22 @@ int exa_launch_nfev_hist(exa_ctx* ctx, const double* state, int* hist_dev, hipSt
    return EXA_OK;
 }
 
+// Launch sequence of the tail split (include/exaconstit_hip.h, exa_set_newton_caps): the full launch stops a point after newton_cap evaluations
+// and lists it; a dense launch of the same kernel (thread = listed point; its grid covers the worst case, blocks beyond the list leave at
+// once) takes the list up - from the saved solver state when the context holds the state buffers, from scratch otherwise - and, with a
+// second cap, lists what it cuts off itself for a third launch.
+template <typename Go>
+static void launch_levels(exa_ctx* ctx, int64_t nb, Go&& go) {
+   const int NOCAP = 1 << 30;
+   const bool split = ctx->newton_cap > 0 && ctx->tail_dev != nullptr;
+   if (!split) { go(nb, NOCAP, ctx->tail_dev, 0, (int*)nullptr, (const double*)nullptr, (double*)nullptr); return; }
+   const bool two = ctx->newton_cap2 > ctx->newton_cap && ctx->tail2_dev != nullptr && ctx->resume_dev[0] && ctx->resume_dev[1];
+   const int64_t nbt = (ctx->P + 255) / 256;
+   go(nb, ctx->newton_cap, ctx->tail_dev, 0, ctx->tail_dev, (const double*)nullptr, ctx->resume_dev[0]);
+   go(nbt, two ? ctx->newton_cap2 : NOCAP, ctx->tail_dev, 1, two ? ctx->tail2_dev : ctx->tail_dev, (const double*)ctx->resume_dev[0], two ? ctx->resume_dev[1] : (double*)nullptr);
+   if (two) go(nbt, NOCAP, ctx->tail2_dev, 1, ctx->tail2_dev, (const double*)ctx->resume_dev[1], (double*)nullptr);
+}
+
 template <int KIN, bool LVEC, int NFIX, bool QB>
 static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
                          double* stress1, double* state1, double* cmat, hipStream_t s) {
@@ -230,14 +251,10 @@ static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel
                                         (ecmdev::kin_is_km(KIN) ? (size_t)8 * ecmdev::NSLIP : (size_t)0));
    const double* G = NFIX == 27 ? ctx->T1_dev : ctx->G_dev;
    static_assert(ECM_STASH_STRIDE == 256, "stash stride must equal the block size");
-   const bool split = ctx->newton_cap > 0 && ctx->tail_dev != nullptr;
-   hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
-                      ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, split ? ctx->newton_cap : (1 << 30), ctx->tail_dev, 0);
-   if (split) {   // same kernel, thread = listed point, uncapped.  The grid covers the worst case; blocks beyond the list exit at once.
-      const int64_t nbt = (ctx->P + bs - 1) / bs;
-      hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)nbt), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
-                         ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, 1 << 30, ctx->tail_dev, 1);
-   }
+   launch_levels(ctx, nb, [&](int64_t blocks, int kcap, int* list, int mode, int* list_out, const double* rs_in, double* rs_out) {
+      hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)blocks), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
+                         ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, kcap, list, mode, (const double*)nullptr, 0, list_out, rs_in, rs_out);
+   });
 }
 
 // fused p = 1 launch that writes the compact gradient records (exa_model_setup_lvec_records)
@@ -247,15 +264,11 @@ static void launch_model_rec(exa_ctx* ctx, double dt, double* J, const double* v
    const int bs = 256;
    const int64_t nb = (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64);
    const size_t lds = sizeof(double) * ((size_t)ctx->n * 3 * ctx->Q + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE + (ecmdev::kin_is_km(KIN) ? (size_t)8 * ecmdev::NSLIP : (size_t)0));
-   const bool split = ctx->newton_cap > 0 && ctx->tail_dev != nullptr;
    const int trd = ctx->cfg.assembly == EXA_ASSEMBLY_EA;
-   hipLaunchKernelGGL((k_model_setup<KIN, true, 8, true, true>), dim3((unsigned)nb), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
-                      ctx->nnodes, stress0, state0, stress1, state1, ctx->pa_c, ctx->fail_count_dev, split ? ctx->newton_cap : (1 << 30), ctx->tail_dev, 0, ctx->W_dev, trd);
-   if (split) {
-      const int64_t nbt = (ctx->P + bs - 1) / bs;
-      hipLaunchKernelGGL((k_model_setup<KIN, true, 8, true, true>), dim3((unsigned)nbt), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
-                         ctx->nnodes, stress0, state0, stress1, state1, ctx->pa_c, ctx->fail_count_dev, 1 << 30, ctx->tail_dev, 1, ctx->W_dev, trd);
-   }
+   launch_levels(ctx, nb, [&](int64_t blocks, int kcap, int* list, int mode, int* list_out, const double* rs_in, double* rs_out) {
+      hipLaunchKernelGGL((k_model_setup<KIN, true, 8, true, true>), dim3((unsigned)blocks), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+                         ctx->nnodes, stress0, state0, stress1, state1, ctx->pa_c, ctx->fail_count_dev, kcap, list, mode, ctx->W_dev, trd, list_out, rs_in, rs_out);
+   });
 }
 
 // Kocks-Mecking sets with thermal-activation exponents p == q == 1 (the shipped sets) run the instantiation that has the two exponents
@@ -265,12 +278,28 @@ static bool km_pq1(const exa_ctx* ctx) {
    return enabled && ctx->mp.p == 1.0 && ctx->mp.q == 1.0;
 }
 
+// lists and solver-state buffers of the tail split, allocated on first use; the list counters are cleared for the coming launch sequence
+static int exa_prepare_tail_lists(exa_ctx* ctx, hipStream_t s) {
+   if (!ctx->tail_dev) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tail_dev, sizeof(int) * ((size_t)ctx->P + 1)));
+   EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->tail_dev, 0, sizeof(int), s));
+   if (ctx->tail_resume) {
+      if (!ctx->resume_dev[0]) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->resume_dev[0], sizeof(double) * ecmdev::RS_N * (size_t)ctx->P));
+      if (ctx->newton_cap2 > ctx->newton_cap) {
+         if (!ctx->tail2_dev) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tail2_dev, sizeof(int) * ((size_t)ctx->P + 1)));
+         if (!ctx->resume_dev[1]) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->resume_dev[1], sizeof(double) * ecmdev::RS_N * (size_t)ctx->P));
+         EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->tail2_dev, 0, sizeof(int), s));
+      }
+   } else if (ctx->resume_dev[0]) {   // switched off after use: the launches test the pointers
+      (void)hipFree(ctx->resume_dev[0]); (void)hipFree(ctx->resume_dev[1]); ctx->resume_dev[0] = ctx->resume_dev[1] = nullptr;
+   }
+   return EXA_OK;
+}
+
 int exa_launch_model_setup_rec(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
                                double* stress1, double* state1, hipStream_t s) {
    EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->fail_count_dev, 0, sizeof(int), s));
    if (ctx->newton_cap > 0) {
-      if (!ctx->tail_dev) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tail_dev, sizeof(int) * ((size_t)ctx->P + 1)));
-      EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->tail_dev, 0, sizeof(int), s));
+      if (int rc = exa_prepare_tail_lists(ctx, s)) return rc;
    }
    switch (ctx->mp.kin) {
       case KIN_VOCE: launch_model_rec<KIN_VOCE>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s); break;
@@ -307,8 +336,7 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
                            double* stress1, double* state1, double* cmat, hipStream_t s) {
    EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->fail_count_dev, 0, sizeof(int), s));
    if (ctx->newton_cap > 0) {
-      if (!ctx->tail_dev) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tail_dev, sizeof(int) * ((size_t)ctx->P + 1)));
-      EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->tail_dev, 0, sizeof(int), s));
+      if (int rc = exa_prepare_tail_lists(ctx, s)) return rc;
    }
    const bool lv = xl != nullptr;
    if (lv && ctx->n == 27 && ctx->qblk) { if (int rc = exa_ensure_p2_tables(ctx)) return rc; }

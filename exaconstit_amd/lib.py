@@ -59,6 +59,7 @@ exa_model_setup = _sig("exa_model_setup", C.c_int, C.c_void_p, C.c_double, dptr,
 exa_model_setup_lvec_records = _sig("exa_model_setup_lvec_records", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_setup_lvec = _sig("exa_model_setup_lvec", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_set_newton_cap = _sig("exa_set_newton_cap", C.c_int, C.c_void_p, C.c_int)
+exa_set_newton_caps = _sig("exa_set_newton_caps", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
 exa_model_tail_count = _sig("exa_model_tail_count", C.c_int, C.c_void_p, C.c_void_p)
 exa_model_nfev_hist = _sig("exa_model_nfev_hist", C.c_int, C.c_void_p, dptr, C.POINTER(C.c_int), C.c_void_p)
 exa_model_status = _sig("exa_model_status", C.c_int, C.c_void_p, C.c_void_p)
@@ -165,6 +166,7 @@ exa_driver_bench_prepare = _sig("exa_driver_bench_prepare", C.c_int, C.c_void_p,
 exa_driver_bench_model = _sig("exa_driver_bench_model", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_driver_bench_pcg = _sig("exa_driver_bench_pcg", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_choose_newton_cap = _sig("exa_choose_newton_cap", C.c_int, C.POINTER(C.c_int), C.c_double)
+exa_choose_newton_caps = _sig("exa_choose_newton_caps", C.c_int, C.POINTER(C.c_int), C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int))
 exa_options_query = _sig("exa_options_query", C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_mesh_partition_query = _sig("exa_mesh_partition_query", C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int)
 exa_partition_query_boundary_first = _sig("exa_partition_query_boundary_first", C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p)

@@ -78,6 +78,8 @@ int exa_options_query(const char* toml_path, double* out20, char* err, int errle
 /* the driver's tail-split controller as a pure function (host logic; tests): cap on local-solver evaluations chosen from a 64-bin
  * histogram of evaluation counts, 0 = leave the launch uncapped.  tail_cost = relative cost of a point in the second launch. */
 int exa_choose_newton_cap(const int* hist64, double tail_cost);
+/* the same for resumed tail points (exa_set_newton_caps): first cap and second cap (0 = one dense launch) */
+int exa_choose_newton_caps(const int* hist64, double tail_cost, int* k1, int* k2);
 
 /* block decomposition of an N0 x N1 x N2 element grid (reference: ParMesh/METIS, src/mechanics_driver.cpp:312): sizes first
  * (info[0..7] = {E, NN, nneighbors, pg0, pg1, pg2, total shared dofs, n}; info[7] is in/out: H1 order p on input (0 or 1 -> 1, 2 -> 2),

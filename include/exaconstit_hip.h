@@ -104,6 +104,13 @@ int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* coords_l
  * scratch without a cap, so every output - the evaluation count in state slot 3 included - is the one of the uncapped solve.
  * exa_model_tail_count (synchronises) returns how many points the last launch handed over. */
 int exa_set_newton_cap(exa_ctx* ctx, int max_evals);
+/* The same with the dense launch resuming instead of starting over (resume = 1, the default of a context): a point that is cut off leaves
+ * its solver state - accepted iterate, trust radius, evaluation count; 80 bytes, stored by list slot - and the dense launch restores (r, J)
+ * with one evaluation at that iterate and carries on, bit for bit the uncapped iteration.  max_evals_2 > max_evals (0 = off) adds a second
+ * level: the dense launch stops at max_evals_2 evaluations and a third launch finishes what is left (the evaluation counts of a
+ * Kocks-Mecking RVE have a second mode near 10 and a thin tail up to 20: two dense launches waste fewer idle lanes than one).
+ * exa_set_newton_cap(ctx, K) is exa_set_newton_caps(ctx, K, 0, <current resume setting>). */
+int exa_set_newton_caps(exa_ctx* ctx, int max_evals, int max_evals_2, int resume);
 int exa_model_tail_count(exa_ctx* ctx, exa_stream s);
 /* histogram (64 bins, last bin = 63 and more) of the evaluation counts stored in slot 3 of a state array; synchronises.  The driver
  * picks max_evals from it (host/driver.hip, choose_newton_cap). */

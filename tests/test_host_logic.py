@@ -134,6 +134,23 @@ def test_tail_split_controller():
     assert cap({3: 36464, 4: 29018, 5: 16278, 6: 8254, 7: 2499, 8: 1509, 9: 2919, 10: 4377, 11: 4438, 12: 2875, 13: 1529}, 1.5) == 6
     assert cap({}, 1.5) == 0 and cap({4: 1000}, 1.5) == 0
 
+    # resumed tail points (exa_set_newton_caps): first and second cap; 128^3 histograms of profiles/r03_bench_n128_{fcc,bcc}_kmdd.json
+    def caps(counts, w):
+        h = (C.c_int * 64)(*([0] * 64))
+        for n, c in counts.items():
+            h[n] = c
+        k1, k2 = C.c_int(-1), C.c_int(-1)
+        assert L.exa_choose_newton_caps(h, w, C.byref(k1), C.byref(k2)) == 0
+        return k1.value, k2.value
+    assert caps({5: 15417772, 6: 1353423, 7: 6021}, 4.0) == (0, 0)
+    fcc = {3: 5727094, 4: 5375245, 5: 1931232, 6: 1105587, 7: 320681, 8: 209811, 9: 440309, 10: 584807, 11: 542477, 12: 332173, 13: 168195, 14: 36806, 15: 2359, 16: 383, 17: 57}
+    bcc = {3: 13666837, 4: 2823624, 5: 48561, 6: 32733, 7: 29108, 8: 5166, 9: 328, 10: 1903, 11: 24858, 12: 28558, 13: 33761, 14: 33583, 15: 28132, 16: 12739, 17: 4533, 18: 2587, 19: 200, 20: 4, 21: 1}
+    k1, k2 = caps(fcc, 1.0)
+    assert 3 <= k1 <= 6 and k1 + 2 <= k2 <= 13, (k1, k2)      # broad main mode, second mode near 10: two dense launches
+    k1, k2 = caps(bcc, 1.0)
+    assert k1 in (3, 4) and (k2 == 0 or k2 >= k1 + 2), (k1, k2)
+    assert caps({}, 1.0) == (0, 0) and caps({4: 1000}, 1.0) == (0, 0)
+
 
 @pytest.mark.parametrize("mesh,nranks", [("cube5_shuffled.mesh", 2), ("cube5_shuffled.mesh", 3), ("cube5_nodes.mesh", 8)])
 def test_file_mesh_partition_invariants(mesh, nranks):
