@@ -8,6 +8,7 @@ STEPS=${STEPS:-100} bash scripts/profile_round.sh r03
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d gpurun_out/r03km_pmc_$c -- python bench.py --model bcc_kmdd --steps 3 --warmup 1 --pcg-iters 10 --no-cpu-baseline > gpurun_out/r03km_pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/r03kf_pmc_$c -- python bench.py --model fcc_kmdd --steps 3 --warmup 1 --pcg-iters 10 --no-cpu-baseline > gpurun_out/r03kf_pmc_$c.log 2>&1
 done
 python - <<'PY'
 import collections, csv, glob, json, statistics
@@ -31,7 +32,9 @@ def traffic(tag, key):
     return (2 * med[("FETCH_SIZE", k)] + med.get(("WRITE_SIZE", k), 0.0)) * 1024 / grid[k], k
 out = {"k_model_setup": {}}
 t = traffic("r03", "k_model_setup<0");   out["k_model_setup"]["fcc_voce"] = t[0] if t else None
-t = traffic("r03km", "k_model_setup<3"); out["k_model_setup"]["bcc_kmdd"] = t[0] if t else None
+# Kocks-Mecking sets with p = q = 1 run the KIN_PQ1 instantiations (ecm_device.hpp): 7 = athermal-threshold (BCC), 6 = FCC
+t = traffic("r03km", "k_model_setup<7"); out["k_model_setup"]["bcc_kmdd"] = t[0] if t else None
+t = traffic("r03kf", "k_model_setup<6"); out["k_model_setup"]["fcc_kmdd"] = t[0] if t else None
 t = traffic("r03", "k_grad_apply_p1")
 if t: out["k_grad_apply_p1"] = t[0] / 8.0      # one thread per element, 8 points
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (scripts/profile_round3.sh), bench.py at 128^3, per kernel instantiation",
@@ -41,6 +44,7 @@ print(out)
 PY
 MODEL=fcc_voce bash scripts/pmc_model.sh r03_sq_fcc_voce > gpurun_out/r03_sq_fcc_voce.txt 2>&1
 MODEL=bcc_kmdd bash scripts/pmc_model.sh r03_sq_bcc_kmdd > gpurun_out/r03_sq_bcc_kmdd.txt 2>&1
+MODEL=fcc_kmdd bash scripts/pmc_model.sh r03_sq_fcc_kmdd > gpurun_out/r03_sq_fcc_kmdd.txt 2>&1
 bash scripts/pmc_flops.sh r03 > gpurun_out/r03_pmc_flops.out 2>&1
-rm -rf gpurun_out/r03_pmc_FETCH_SIZE gpurun_out/r03_pmc_WRITE_SIZE gpurun_out/r03km_pmc_FETCH_SIZE gpurun_out/r03km_pmc_WRITE_SIZE gpurun_out/r03_sq_fcc_voce gpurun_out/r03_sq_bcc_kmdd gpurun_out/r03_pmc_flops
-cat gpurun_out/r03_sq_fcc_voce.txt gpurun_out/r03_sq_bcc_kmdd.txt; tail -1 gpurun_out/r03_pmc_flops.out
+rm -rf gpurun_out/r03_pmc_FETCH_SIZE gpurun_out/r03_pmc_WRITE_SIZE gpurun_out/r03km_pmc_FETCH_SIZE gpurun_out/r03km_pmc_WRITE_SIZE gpurun_out/r03kf_pmc_FETCH_SIZE gpurun_out/r03kf_pmc_WRITE_SIZE gpurun_out/r03_sq_fcc_kmdd gpurun_out/r03_sq_fcc_voce gpurun_out/r03_sq_bcc_kmdd gpurun_out/r03_pmc_flops
+cat gpurun_out/r03_sq_fcc_voce.txt gpurun_out/r03_sq_bcc_kmdd.txt gpurun_out/r03_sq_fcc_kmdd.txt; tail -1 gpurun_out/r03_pmc_flops.out
