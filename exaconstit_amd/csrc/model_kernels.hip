@@ -274,8 +274,8 @@ static void launch_model_rec(exa_ctx* ctx, double dt, double* J, const double* v
 // Kocks-Mecking sets with thermal-activation exponents p == q == 1 (the shipped sets) run the instantiation that has the two exponents
 // compiled in (ecmdev::KIN_PQ1: same arithmetic, no pow() code); EXA_KM_PQ1=off keeps the general instantiation for A/B runs
 static bool km_pq1(const exa_ctx* ctx) {
-   static const bool enabled = [] { const char* e = std::getenv("EXA_KM_PQ1"); return !(e && std::strcmp(e, "off") == 0); }();
-   return enabled && ctx->mp.p == 1.0 && ctx->mp.q == 1.0;
+   const char* e = std::getenv("EXA_KM_PQ1");   // read per launch: the tests flip it inside one process
+   return !(e && std::strcmp(e, "off") == 0) && ctx->mp.p == 1.0 && ctx->mp.q == 1.0;
 }
 
 // lists and solver-state buffers of the tail split, allocated on first use; the list counters are cleared for the coming launch sequence

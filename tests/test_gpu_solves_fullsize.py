@@ -107,3 +107,27 @@ def test_config5_64_p2_bbar_ea_eight_ranks(oracle):
     r1 = _run(L, N, props, quats, **kw)
     r8 = _run(L, N, props, quats, nranks=8, **kw)
     _same_run(r1, r8, 1e-6)
+
+
+@pytest.mark.parametrize("bcc", [True, False])
+def test_config3_64_kocks_mecking_switches(oracle, monkeypatch, bcc):
+    """BASELINE config 3 material (Kocks-Mecking dislocation density, p = q = 1) at 64^3 through three real steps: the shipped route - p = q = 1
+    kernel instantiation, tail points resumed from their saved solver state, cap from the histogram controller - against the general
+    instantiation (EXA_KM_PQ1=off), the tail points started over (EXA_TAIL_RESUME=off) and no tail split at all (EXA_NEWTON_CAP=off):
+    the same Newton history and volume averages.  The tail split is bit-neutral per launch (test_gpu_parity.py); the instantiations differ
+    in round-off only (summation order of the slip forms, exp / log routines of the kinetics)."""
+    import exaconstit_amd.lib as L
+    N = 64
+    props = np.loadtxt(os.path.join(oracle.REFDATA, "props_cp_mts.txt")).ravel()
+    quats = hipref.random_quats(N ** 3).ravel()
+    kw = dict(bcc=bcc, slip=2)
+    ref = _run(L, N, props, quats, **kw)
+    assert ref["diag"][0]["model_failed_points"] == 0
+    for var, val, tol in (("EXA_TAIL_RESUME", "off", 1e-12), ("EXA_NEWTON_CAP", "off", 1e-12), ("EXA_KM_PQ1", "off", 1e-7)):
+        monkeypatch.setenv(var, val)
+        alt = _run(L, N, props, quats, **kw)
+        _same_run(ref, alt, tol)
+        if var == "EXA_KM_PQ1":   # the other instantiation really ran: same answers, not the same bits
+            assert np.max(np.abs(alt["avgs"][0] - ref["avgs"][0])) > 0.0
+        monkeypatch.delenv(var)
+    print("config 3 (64^3 Kocks-Mecking, %s): newton %s krylov %s" % ("BCC" if bcc else "FCC", list(ref["stats"][0][0]), list(ref["stats"][0][1])))
