@@ -8,6 +8,7 @@ int exa_launch_model_setup(exa_ctx*, double, double*, const double*, const doubl
 int exa_launch_model_setup_rec(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
 int exa_launch_init_state(exa_ctx*, double*, const double*, const double*, hipStream_t);
 int exa_launch_nfev_hist(exa_ctx*, const double*, int*, hipStream_t);
+int exa_launch_selftest_km_math(const double*, double*, int, hipStream_t);
 int exa_launch_calc_dp(exa_ctx*, const double*, double*, hipStream_t);
 int exa_launch_jacobians(exa_ctx*, const double*, double*, hipStream_t);
 int exa_launch_jacobians_from_geom(exa_ctx*, const double*, double*, hipStream_t);
@@ -176,6 +177,10 @@ int exa_model_nfev_hist(exa_ctx* ctx, const double* state, int* hist64_host, exa
    EXA_HIP_CHECK(ctx, hipMemcpyAsync(hist64_host, hd, sizeof(int) * 64, hipMemcpyDeviceToHost, S(s)));
    EXA_HIP_CHECK(ctx, hipStreamSynchronize(S(s)));
    return EXA_OK;
+}
+int exa_selftest_km_math(const double* x_dev, double* out_dev, int n, exa_stream s) {
+   if (!x_dev || !out_dev || n <= 0) return EXA_ERR_ARG;
+   return exa_launch_selftest_km_math(x_dev, out_dev, n, S(s));
 }
 int exa_model_tail_count(exa_ctx* ctx, exa_stream s) {
    if (!ctx) return EXA_ERR_ARG;

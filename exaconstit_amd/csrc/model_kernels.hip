@@ -217,6 +217,19 @@ __global__ void k_nfev_hist(const int Q, const int64_t P, const double* __restri
    if (threadIdx.x < 64 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
 
+// self-test hook of the kinetics' own elementary functions (ecm_device.hpp: exp_n, log_near1): out[i] = exp_n(x[i]), out[n + i] = log_near1(x[i])
+__global__ void k_selftest_km_math(const double* __restrict__ x, double* __restrict__ out, const int n) {
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   double v[1] = { x[i] };
+   ecmdev::exp_n<1, true>(v);
+   out[i] = v[0]; out[n + i] = ecmdev::log_near1(x[i]);
+}
+int exa_launch_selftest_km_math(const double* x, double* out, int n, hipStream_t s) {
+   hipLaunchKernelGGL(k_selftest_km_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n);
+   return hipGetLastError() == hipSuccess ? EXA_OK : EXA_ERR_HIP;
+}
+
 int exa_launch_nfev_hist(exa_ctx* ctx, const double* state, int* hist_dev, hipStream_t s) {
    EXA_HIP_CHECK(ctx, hipMemsetAsync(hist_dev, 0, sizeof(int) * 64, s));
    if (ctx->qblk) hipLaunchKernelGGL(k_nfev_hist<true>, dim3(1024), dim3(256), 0, s, ctx->Q, ctx->P, state, hist_dev);

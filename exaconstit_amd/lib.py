@@ -59,6 +59,7 @@ exa_model_setup = _sig("exa_model_setup", C.c_int, C.c_void_p, C.c_double, dptr,
 exa_model_setup_lvec_records = _sig("exa_model_setup_lvec_records", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_setup_lvec = _sig("exa_model_setup_lvec", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_set_newton_cap = _sig("exa_set_newton_cap", C.c_int, C.c_void_p, C.c_int)
+exa_selftest_km_math = _sig("exa_selftest_km_math", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 exa_set_newton_caps = _sig("exa_set_newton_caps", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
 exa_model_tail_count = _sig("exa_model_tail_count", C.c_int, C.c_void_p, C.c_void_p)
 exa_model_nfev_hist = _sig("exa_model_nfev_hist", C.c_int, C.c_void_p, dptr, C.POINTER(C.c_int), C.c_void_p)

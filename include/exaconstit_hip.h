@@ -174,6 +174,9 @@ int exa_grad_tangent_defect(exa_ctx* ctx, const double* ddsdde_dev, double* defe
  * 24 x 24) or 52 KB (p = 2, 81 x 81) per element.  Built for p = 1 full integration and for p = 2 (plain and B-bar); other
  * contexts keep the assembled path.  The matrices themselves are assembled on the first call that needs them (exa_grad_apply on
  * E-vectors, exa_grad_diagonal, exa_grad_get_ea).  Default: off. */
+/* self-test hook (tests/test_gpu_point_fixtures.py): the Kocks-Mecking kinetics' own exp and near-1 log evaluated on the device,
+ * out[0..n) = exp(x), out[n..2n) = log(x) (the latter meaningful for x in [0.75, 1.25]); no context needed */
+int exa_selftest_km_math(const double* x_dev, double* out_dev, int n, exa_stream s);
 int exa_set_ea_matrix_free(exa_ctx* ctx, int on);
 /* Bit-reproducible E->L sums (reference: mfem::ElementRestriction::MultTranspose; the fused kernels here scatter with FP64 atomics, whose
  * order - and therefore the last bits of the L-vector, and from there every CG iterate - changes from run to run).  With `on` != 0

@@ -79,3 +79,35 @@ def test_gpu_tangent_is_the_derivative_of_the_gpu_stress_update(name):
         errs = np.concatenate(errs)
         assert np.quantile(errs, 0.9) < 1.0e-4, (name, np.quantile(errs, [0.5, 0.9, 0.99]))
     ctx.close()
+
+
+def test_kinetics_elementary_functions():
+    """The Kocks-Mecking kinetics' own exp (no overflow selects, clamped arguments, Taylor 13) and near-1 log (atanh series) against mpmath-free
+    references: numpy's correctly rounded-to-<1-ulp routines, error counted in ulps of the result.  exp over the whole range the kinetics
+    use (-745 ... 105; beyond: 0 / inf like the library), log over its domain [0.75, 1.25]."""
+    import torch
+    import exaconstit_amd.lib as L
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-745.0, 105.0, 200000), rng.uniform(-2.0, 2.0, 100000), -np.logspace(-300, 2, 5000), [0.0, -0.0, -800.0, -1e300, 709.0, 720.0, 1e300]])
+    d_x = torch.from_numpy(x).cuda(); d_o = torch.zeros(2 * len(x), dtype=torch.float64, device="cuda")
+    assert L.exa_selftest_km_math(ptr(d_x), ptr(d_o), len(x), None) == 0
+    torch.cuda.synchronize()
+    got = d_o.cpu().numpy()[:len(x)]
+    with np.errstate(over="ignore", under="ignore"):
+        ref = np.exp(np.clip(x, -800.0, 720.0))
+    fin = np.isfinite(ref) & (ref > 1e-300)              # normal range: ulp-level agreement
+    ulp = np.abs(got[fin] - ref[fin]) / np.spacing(ref[fin])
+    assert ulp.max() <= 2.0, ulp.max()
+    assert np.all(got[ref == 0.0] == 0.0) and np.all(np.isinf(got[np.isinf(ref)]))
+    sub = ~fin & np.isfinite(ref) & (ref > 0)            # denormal results: absolute agreement
+    assert np.all(np.abs(got[sub] - ref[sub]) <= 4e-308 * 1e-8 + np.spacing(ref[sub]) * 4)
+    y = np.concatenate([rng.uniform(0.75, 1.25, 200000), 1.0 + np.concatenate([np.logspace(-16, -1, 2000), -np.logspace(-16, -1, 2000)]), [1.0, 0.75, 1.25]])
+    d_y = torch.from_numpy(y).cuda(); d_o = torch.zeros(2 * len(y), dtype=torch.float64, device="cuda")
+    assert L.exa_selftest_km_math(ptr(d_y), ptr(d_o), len(y), None) == 0
+    torch.cuda.synchronize()
+    gl = d_o.cpu().numpy()[len(y):]
+    rl = np.log(y)
+    nz = rl != 0.0
+    assert np.all(gl[~nz] == 0.0)
+    ulp = np.abs(gl[nz] - rl[nz]) / np.spacing(np.abs(rl[nz]))
+    assert ulp.max() <= 3.0, ulp.max()
