@@ -53,7 +53,8 @@ __device__ __forceinline__ void stg(double* p, double v) {
 constexpr int H_SHRATE = 0, H_SHR = 1, H_FLOW = 2, H_NFEV = 3, H_E = 4, H_Q = 9, H_H = 13, H_GDOT = 14;
 constexpr int RS_N = 10;   // doubles of a cut-off point's solver state (point_update, TailIO)
 // tail split (model_kernels.hip, launch_levels): where a cut-off point goes, and the saved state a listed point resumes from (already offset to its slot)
-struct TailIO { int* list_out = nullptr; double* rs_out = nullptr; const double* rs_in = nullptr; int64_t stride = 0; int ipt = 0; };
+// defer_reject (capped full launch with state buffers): a point whose trial is rejected leaves for the dense launch right away (point_update)
+struct TailIO { int* list_out = nullptr; double* rs_out = nullptr; const double* rs_in = nullptr; int64_t stride = 0; int ipt = 0; bool defer_reject = false; };
 constexpr int NUM_HIST = 26, NSTATEV = 28, IND_VOL = 26, IND_EINT = 27;
 
 enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2,
@@ -568,8 +569,14 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #ifndef ECM_KM_GDOT_AT_END
 #define ECM_KM_GDOT_AT_END 1   // Kocks-Mecking: slip rates written once from the converged point (A/B switch)
 #endif
+#ifndef ECM_DEFER_REJECT
+#define ECM_DEFER_REJECT 1   // capped launch with resumed tail points: a rejected trial hands the point over instead of re-evaluating (A/B switch;
+                             // 2 = also in instantiations that keep the dog-leg data: FCC 20.1 ms against 17.2 / 18.0)
+#endif
 #ifndef ECM_KEEP_DOGLEG
-#define ECM_KEEP_DOGLEG 1   // Kocks-Mecking: dog-leg data kept across a trial evaluation instead of a re-evaluation after a rejection (A/B switch)
+#define ECM_KEEP_DOGLEG 0   // Kocks-Mecking without athermal threshold: dog-leg data kept across a trial evaluation instead of a re-evaluation after a
+                            // rejection.  Worth 14 % (FCC 29.7 -> 25.6 ms) until ECM_DEFER_REJECT made the capped launch free of re-evaluations
+                            // without the 20 carried values (18.0 -> 17.2 ms); still the better choice for a launch WITHOUT tail split (A/B switch)
 #endif
 #ifndef ECM_KM_BATCH
 #define ECM_KM_BATCH 1   // p == q == 1 FCC Kocks-Mecking instantiation: batched straight-line slip loop (A/B switch)
@@ -1309,10 +1316,16 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       // three scalars - are computed with every accepted evaluation and kept across the trial, like SNLS does (reject_prev), so a rejected
       // trial only restores x and shrinks the trust region: no second evaluation at the old point.  With these kinetics nearly every wave
       // holds a rejecting lane in every iteration, i.e. the re-evaluation of the Voce form below (rare per lane) was paid by all of them.
-      // (not the athermal-threshold variant: its main launch rarely rejects, and the 20 values carried through the evaluation cost 7 % there)
+      // (not the athermal-threshold variant: the 20 values carried through the evaluation cost 7 % there).  Off by default since the capped
+      // launch hands rejecting points over to the dense launch (ECM_DEFER_REJECT below), which removes the re-evaluations at no cost.
       constexpr bool KEEP = ECM_KEEP_DOGLEG && kin_base(KIN) == KIN_KMBALD;
       double nr[8], grad[8], nr2sq = 0.0, norm2_grad = 0.0, Jg_2 = 0.0, s2 = 0.0;
       bool reject_prev = false;
+      // A rejected trial needs (r, J) of the accepted point again: one more evaluation, rare per lane but paid by the whole wave.  In a capped
+      // launch whose listed points resume from their saved state (ECM_DEFER_REJECT) such a point is handed over instead - x restored, trust
+      // radius shrunk: exactly the state a resumed point starts from, and the evaluation that restores (r, J) there is the one saved here.
+      // The points that reject are the ones with long iteration histories, i.e. the ones the cap would list a few evaluations later anyway.
+      bool hand_over = false;
       auto dogleg_data = [&]() {   // grad = Js^T r, Jg = Js grad, s2 = |r + Js sd_opt|^2 (all in SNLS's scaled variables)
          double u[8], rs[8], tt[8];
          for (int i = 0; i < 8; i++) rs[i] = r[i] * pb.sc;
@@ -1327,7 +1340,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       for (int it = 0; it < 200; it++) {
          // tail split: a point that needs more than kcap evaluations is handed to the dense tail launch (which starts over, so the
          // result is the one of an uncapped solve); the wave stops waiting for its slowest lanes
-         if (nfev >= kcap) {
+         if (nfev >= kcap || hand_over) {
             const int slot = atomicAdd(&tio.list_out[0], 1); tio.list_out[1 + slot] = tio.ipt;
             if (tio.rs_out) {
                double* o = tio.rs_out + slot;
@@ -1402,6 +1415,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          reject_prev = reject;
          if (reject) {
             for (int i = 0; i < 8; i++) x[i] = ECM_ST(st, ST_XS + i);
+            if (ECM_DEFER_REJECT && (!KEEP || ECM_DEFER_REJECT == 2) && tio.defer_reject && delta > 1e-12) { hand_over = true; continue; }
             if (!KEEP) ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);   // restore (r, J) of the accepted point
             else ok = true;   // (the accepted point evaluated fine; r and J hold the rejected trial until the next accepted evaluation)
             if (!ok || delta <= 1e-12) break;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    // REC: the lane's first 16-byte pair of its compact record ([block][q][13 pairs][64 lanes][2])
    double* tout = REC ? cmat + pac_off<PAC_PAIRS>(e >> 6, Q, q, 0) + 2 * (e & 63) : cmat + vC.base;
    const int rc = point_update<KIN, QS, REC>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, tout, st, kcap, sG + pqo, tsc, trd != 0,
-                                             TailIO{ tail_out, rs_out, tail_mode ? rs_in : nullptr, P, (int)(e * Q + q) });
+                                             TailIO{ tail_out, rs_out, tail_mode ? rs_in : nullptr, P, (int)(e * Q + q), !tail_mode && rs_out != nullptr });
    if (rc == 1) atomicAdd(fail, 1);
 }
 
