@@ -308,7 +308,7 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    }
    tail_resume_ = !env_is_off("EXA_TAIL_RESUME");   // A/B switch: the dense launch starts its points over (round 2) instead of resuming them
    if (!tail_resume_) newton_cap2_ = 0;
-   tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.0 : 4.0;   // (Kocks-Mecking: re-measured in round 3 after the slip-rate stores left the Newton loop: 1.5 -> 1.0 picks cap 5 for FCC, 38.7 instead of 40.2 ms; BCC unchanged)
+   tail_cost_ = (opt.slip == SlipType::MTSDD) ? 1.5 : 4.0;   // (Kocks-Mecking: re-measured on the final round-3 kernels - resumed tail points, rejecting points handed over: w = 1.2 ... 2 picks cap 6 for FCC, 16.6 instead of 16.9 ms at cap 5 (w <= 1); BCC 4 either way)
    if (const char* tc = std::getenv("EXA_TAIL_COST")) { const double v = std::atof(tc); if (v > 0.0) tail_cost_ = v; }   // A/B switch of the controller's cost model
    // element assembly: the element matrices are 2x (p = 1) to 5x (p = 2) the bytes of the records they are built from, so the action is
    // computed from the records and the matrices only exist if somebody asks for them (diagonal, export); EXA_EA_ASSEMBLED=1 streams them instead
@@ -370,7 +370,7 @@ void NonlinearMechOperator::UpdateEssTDofs(const std::vector<uint8_t>& mask) { e
 // w = measured cost of a point in the second launch relative to the first (its lanes are scattered points: 8-byte accesses into the
 // blocked rows): 4 for the Voce kernels, whose first launch is close to the memory system's limits, 1.5 for the compute-heavy
 // Kocks-Mecking kernel; 0.2 = the second launch's fixed cost.  Measured at 128^3: BCC KM-DD 31.6 -> 16.0 ms, FCC KM-DD 70.9 -> 55.9 ms,
-// Voce stays uncapped (6.9 ms; K = 5 would cost 10.2 ms, which the model reproduces).  Round 3: w = 1.0 for Kocks-Mecking (EXA_TAIL_COST overrides).
+// Voce stays uncapped (6.9 ms; K = 5 would cost 10.2 ms, which the model reproduces).  Round 3: w = 1.0 at mid-round, 1.5 again on the final kernels (EXA_TAIL_COST overrides).
 // Returns the K minimising C, or 0 (off) when it does not beat the uncapped launch by 3 %.
 // With resumed tail points (exa_set_newton_caps) a listed point does not repeat its K evaluations: the dense launch pays the point set-up again
 // (~0.7 evaluations), one evaluation that restores (r, J), and the evaluations beyond K.  A second cap K2 splits the dense launch once more:
