@@ -165,8 +165,8 @@ int exa_set_newton_cap(exa_ctx* ctx, int max_evals) {
    ctx->newton_cap = max_evals; ctx->newton_cap2 = 0; return EXA_OK;
 }
 int exa_set_newton_caps(exa_ctx* ctx, int max_evals, int max_evals_2, int resume) {
+   if (ctx && max_evals_2 != 0 && (max_evals == 0 || max_evals_2 <= max_evals || !resume)) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_caps: the second cap needs a first one below it and resume = 1");
    if (int rc = exa_set_newton_cap(ctx, max_evals)) return rc;
-   if (max_evals_2 != 0 && (max_evals == 0 || max_evals_2 <= max_evals || !resume)) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_caps: the second cap needs a first one below it and resume = 1");
    ctx->newton_cap2 = max_evals_2; ctx->tail_resume = resume ? 1 : 0; return EXA_OK;
 }
 int exa_model_nfev_hist(exa_ctx* ctx, const double* state, int* hist64_host, exa_stream s) {

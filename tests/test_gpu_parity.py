@@ -573,6 +573,9 @@ def test_abi_error_behaviour(oracle):
     assert L.exa_residual_apply(ctx.h, ptr(z), None) == -3
     assert L.exa_residual_lvec(ctx.h, ptr(z), ptr(z), ptr(z), None) == -3          # connectivity not set
     assert L.exa_set_newton_cap(ctx.h, 1) == -1 and L.exa_set_quadrature_layout(ctx.h, 5) == -1
+    # second cap: needs a first one below it and resumed tail points
+    assert L.exa_set_newton_caps(ctx.h, 4, 3, 1) == -1 and L.exa_set_newton_caps(ctx.h, 0, 5, 1) == -1 and L.exa_set_newton_caps(ctx.h, 4, 6, 0) == -1
+    assert L.exa_set_newton_caps(ctx.h, 4, 6, 1) == 0 and L.exa_set_newton_caps(ctx.h, 4, 0, 0) == 0 and L.exa_set_newton_caps(ctx.h, 0, 0, 1) == 0
     # the one-element problem runs end to end and matches the oracle
     quats = hipref.random_quats(1)
     sv0 = dev.zeros(28 * 8); d_q = dev.up(quats.ravel()); ctx.check(L.exa_init_state(ctx.h, ptr(sv0), ptr(d_q), None))
