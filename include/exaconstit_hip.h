@@ -109,6 +109,9 @@ int exa_set_newton_cap(exa_ctx* ctx, int max_evals);
  * with one evaluation at that iterate and carries on, bit for bit the uncapped iteration.  max_evals_2 > max_evals (0 = off) adds a second
  * level: the dense launch stops at max_evals_2 evaluations and a third launch finishes what is left (the evaluation counts of a
  * Kocks-Mecking RVE have a second mode near 10 and a thin tail up to 20: two dense launches waste fewer idle lanes than one).
+ * With resume on, the capped launch of a Kocks-Mecking model also lists a point at the moment one of its trial steps is rejected (such a
+ * point sits at its accepted iterate with a smaller trust radius - a resumable state - and would be listed a few evaluations later anyway),
+ * so that no wave of the full launch pays the re-evaluation of the accepted point; same bits again.
  * exa_set_newton_cap(ctx, K) is exa_set_newton_caps(ctx, K, 0, <current resume setting>). */
 int exa_set_newton_caps(exa_ctx* ctx, int max_evals, int max_evals_2, int resume);
 int exa_model_tail_count(exa_ctx* ctx, exa_stream s);
