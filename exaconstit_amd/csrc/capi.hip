@@ -105,6 +105,7 @@ int exa_set_quadrature_layout(exa_ctx* ctx, int layout) {
    ctx->qblk = (layout == EXA_QLAYOUT_EB64); ctx->have_resid = false; ctx->have_grad = false;
    return EXA_OK;
 }
+int exa_get_quadrature_layout(const exa_ctx* ctx) { return (ctx && ctx->qblk) ? EXA_QLAYOUT_EB64 : EXA_QLAYOUT_AOS; }
 int64_t exa_qf_size(const exa_ctx* ctx, int vdim) { return (ctx && vdim > 0) ? (int64_t)exa_qf_doubles(ctx, vdim) : -1; }
 
 int exa_init_state(exa_ctx* ctx, double* state0, const double* quats, exa_stream s) {

@@ -59,10 +59,14 @@ constexpr int NUM_HIST = 26, NSTATEV = 28, IND_VOL = 26, IND_EINT = 27;
 
 enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2,
        KIN_KMBALD_GA = 3,     // compile-time variant of KIN_KMBALD for with_g_athermal (BCC): same arithmetic, window systems deferred (eval_rj)
-       KIN_PQ1 = 4 };         // flag on the two Kocks-Mecking kinds: thermal-activation exponents p == q == 1 known at compile time (no pow()
+       KIN_PQ1 = 4,           // flag on the two Kocks-Mecking kinds: thermal-activation exponents p == q == 1 known at compile time (no pow()
                               // code in the kinetics: 7-11 % fewer cycles at 128^3 through lower register pressure; same arithmetic)
+       KIN_XN49 = 8 };        // flag on the two Voce kinds: power-law exponent 1/m - 1 == 49 (m = 0.02, the shipped sets) known at compile time.  The
+                              // run-time choice among the x^9 / x^19 / x^49 / x^99 / rolled / exp-log forms sits in every evaluation: each form leaves
+                              // its 12 powers in other registers, and the merge costs ~100 v_mov / v_and per evaluation (9 % of the launch's VALU work)
 constexpr int kin_base(int k) { return k & 3; }
 constexpr bool kin_pq1(int k) { return (k & KIN_PQ1) != 0; }
+constexpr int kin_xn_ct(int k) { return (k & KIN_XN49) ? 49 : 0; }   // compile-time power-law exponent (0: run-time choice)
 constexpr bool kin_is_km(int k) { return kin_base(k) == KIN_KMBALD || kin_base(k) == KIN_KMBALD_GA; }
 
 // Schmid tensors of the 12 FCC {111}<110> systems: P = vecd(sym(s x m)), Q = axial(skew(s x m)).
@@ -299,12 +303,13 @@ ECM_DI void pow12_ct(const double tf[NSLIP], double pw[NSLIP]) {
 }
 
 // Voce power law for all 12 systems at once (independent chains -> the FP64 pipeline stays full).  WITHD: also d gdot / d tau.
-template <bool WITHD, bool CUT>
+template <bool WITHD, bool CUT, int XNCT = 0>
 ECM_DI void voce_gdot12(const MatParams& mp, double g_i, const double tau[NSLIP], double gd[NSLIP], double dg[NSLIP]) {
    double tf[NSLIP], pw[NSLIP];
 #pragma unroll
    for (int a = 0; a < NSLIP; a++) tf[a] = tau[a] * g_i;
-   if (mp.xn_int == 49) pow12_ct<49>(tf, pw);
+   if constexpr (XNCT > 0) pow12_ct<XNCT>(tf, pw);
+   else if (mp.xn_int == 49) pow12_ct<49>(tf, pw);
    else if (mp.xn_int == 99) pow12_ct<99>(tf, pw);
    else if (mp.xn_int == 19) pow12_ct<19>(tf, pw);
    else if (mp.xn_int == 9) pow12_ct<9>(tf, pw);
@@ -522,7 +527,7 @@ ECM_DI void kin_sdot(const MatParams& mp, double h, double shrate, double ev1, d
    if (kin_is_km(KIN)) {
       const double t1 = exp(-0.5 * h);
       sdot = (mp.k1 * t1 - ev1) * shrate; dsdot = (-0.5 * mp.k1 * t1) * shrate;
-   } else if (KIN == KIN_VOCE_NL) {
+   } else if (kin_base(KIN) == KIN_VOCE_NL) {
       const double r = (ev1 - h) / (ev1 - mp.tausi);
       const double t1 = (mp.xmprime == 1.0) ? 1.0 : pow(fmax(r, 0.0), mp.xmprime - 1.0);
       sdot = mp.h0 * t1 * r * shrate; dsdot = -mp.h0 * mp.xmprime * t1 / (ev1 - mp.tausi) * shrate;
@@ -671,7 +676,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
          tau[a] = t;
       }
       }
-      voce_gdot12<WITHJ, false>(mp, g_i, tau, gd, dg);
+      voce_gdot12<WITHJ, false, kin_xn_ct(KIN)>(mp, g_i, tau, gd, dg);
       // the dissipation rate is an output of the converged point only: voce_slip_rates computes it there (12 FMAs fewer per evaluation)
       if (!ECM_DEFER_DIS) {
 #pragma unroll
@@ -979,6 +984,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 }
 
 // slip rates at the converged point (Voce family): written once, instead of one global store per system and evaluation
+template <int XNCT>
 ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out, double& dis_rate, double& shrate) {
    const double ks[5] = { mp.pk0 * e_f[0], mp.pk1 * e_f[1], mp.pk2 * e_f[2], mp.pk2 * e_f[3], mp.pk2 * e_f[4] };
    double tau[NSLIP], gd[NSLIP];
@@ -992,7 +998,7 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
       tau[a] = t;
    }
    }
-   voce_gdot12<false, true>(mp, pb.g_i, tau, gd, nullptr);
+   voce_gdot12<false, true, XNCT>(mp, pb.g_i, tau, gd, nullptr);
    double dis = 0.0, shr = 0.0;
 #pragma unroll
    for (int a = 0; a < NSLIP; a++) { stg(&gdot_out[a * pb.gs], gd[a]); dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
@@ -1466,7 +1472,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       const double vNew = ECM_CD(CD_VNEW);
       double eNew = ECM_CD(CD_ENEW);
       eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * (ECM_CD(CD_WRKOLD) + wrk_new);
-      if constexpr (!kin_is_km(KIN)) voce_slip_rates(mp, pb, e_f, sv1 + H_GDOT * QS, dis_rate, shrate);
+      if constexpr (!kin_is_km(KIN)) voce_slip_rates<kin_xn_ct(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS, dis_rate, shrate);
       else if (ECM_KM_GDOT_AT_END) km_slip_rates<kin_pq1(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS);
       stg(&sv1[(H_SHRATE) * QS], shrate);
       stg(&sv1[(H_SHR) * QS], ldg(&sv0[(H_SHR) * QS]) + shrate * dt);

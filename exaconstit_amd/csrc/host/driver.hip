@@ -99,10 +99,10 @@ void Comm::loopback_destroy(const void* id128) {
 
 void Comm::get_unique_id(void* out128) { ncclUniqueId id; nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId"); std::memcpy(out128, &id, sizeof(id)); }
 
-void Comm::init(int rank_, int nranks_, const void* uid) {
+void Comm::init(int rank_, int nranks_, const void* uid, bool force_rccl) {
    rank = rank_; nranks = nranks_;
    // EXA_FORCE_RCCL=1 routes the one-rank case through RCCL too (plumbing check on a single-GPU box)
-   force_ = (nranks == 1 && std::getenv("EXA_FORCE_RCCL") != nullptr);
+   force_ = (nranks == 1 && (force_rccl || std::getenv("EXA_FORCE_RCCL") != nullptr));
    if (uid && std::memcmp(uid, kLoopMagic, 8) == 0) {
       LoopbackGroup* g; std::memcpy(&g, (const char*)uid + 8, sizeof(g));
       if (g->n != nranks) throw std::runtime_error("Comm::init: loopback group size mismatch");
@@ -1019,12 +1019,13 @@ int SystemDriver::RunAll() {
 
 // per-rank wall time of every step's solve, one value per line with 8 digits: ./time/time_solve.<rank>.txt of the reference
 // (src/mechanics_driver.cpp:982-998; every rank writes its own file, appended like the reference's)
-void SystemDriver::WriteStepTimes() const {
+void SystemDriver::WriteStepTimes() {
    if (!write_files || step_wall_s.empty()) return;
    const std::string dir = out_dir + "/time";
    (void)::mkdir(dir.c_str(), 0755);
    std::ofstream f(dir + "/time_solve." + std::to_string(comm.rank) + ".txt", std::ios::out | std::ios::app);
    for (double v : step_wall_s) f << std::setprecision(8) << v << "\n";
+   step_wall_s.clear();   // written once: a second RunAll / WriteStepTimes appends only its own steps
 }
 
 }  // namespace exa_host

@@ -24,7 +24,8 @@ class Comm {
  public:
    int rank = 0, nranks = 1;
    ~Comm();
-   void init(int rank_, int nranks_, const void* nccl_unique_id /*128 bytes, identical on all ranks*/);
+   // force_rccl: run the RCCL calls on a one-rank communicator too (what EXA_FORCE_RCCL=1 selects from the environment)
+   void init(int rank_, int nranks_, const void* nccl_unique_id /*128 bytes, identical on all ranks*/, bool force_rccl = false);
    static void get_unique_id(void* out128);
    // in-process loopback transport for tests: several ranks (one host thread each) on ONE device, host-synchronous exchanges
    static void loopback_create(int nranks, void* out128);
@@ -176,7 +177,7 @@ class SystemDriver {
    double time = 0.0, dt_class = 0.0; int steps_done = 0;
    bool write_files = true; std::string out_dir = ".";
    std::vector<double> step_wall_s;            // wall time of each step (solve part), written to time/time_solve.<rank>.txt by RunAll
-   void WriteStepTimes() const;
+   void WriteStepTimes();
    Precond precond = Precond::IDENTITY;
    int cg_check_every = 16;
    int64_t cg_graph_max_dofs = 3 * 33 * 33 * 33;   // PCG iterations replayed from a hipGraph up to this many local dofs (32^3 elements at p = 1: +9 % at 16^3, +3 % at 32^3, a loss from 48^3 on); EXA_PCG_GRAPH=0 | all

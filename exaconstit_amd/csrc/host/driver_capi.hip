@@ -43,8 +43,7 @@ int exa_bootstrap(int* rank, int* nranks, void* uid128, char* err, int errlen) {
 // us per grouped send/recv of n doubles to the own rank }; input of the scaling prediction in DESIGN.md section 7
 int exa_rccl_microbench(int iters, int n, double* out2, char* err, int errlen) {
    try {
-      setenv("EXA_FORCE_RCCL", "1", 1);
-      Comm c; c.init(0, 1, nullptr);
+      Comm c; c.init(0, 1, nullptr, /*force_rccl=*/true);   // (no environment change: later drivers of the process keep their own setting)
       c.microbench(iters, n, out2, out2 + 1);
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
@@ -130,7 +129,7 @@ void exa_driver_get_timers(exa_driver* d, double* out) {
    const Timers& t = d->sd->oper().timers;
    out[0] = t.t_model_ms; out[1] = t.t_krylov_ms; out[2] = t.t_solve_ms; out[3] = (double)t.qpt_updates; out[4] = (double)t.krylov_iters;
 }
-void exa_driver_reset_timers(exa_driver* d) { d->sd->oper().timers = Timers(); }
+void exa_driver_reset_timers(exa_driver* d) { d->sd->oper().FlushModelTimers(); d->sd->oper().timers = Timers(); }   // pending event pairs belong to the old totals
 // out[0] quadrature points whose local solve failed (sum over all constitutive launches, this rank), out[1] linear solves that
 // did not converge, out[2] PCG iterations that saw (Ad, d) < 0, out[3] flag of the last PCG solve (1 converged, 2 max_iter, -1 den == 0)
 void exa_driver_get_diagnostics(exa_driver* d, int64_t* out) {
@@ -145,6 +144,24 @@ int exa_driver_nfev_hist(exa_driver* d, int* hist64, char* err, int errlen) {
    try {
       NonlinearMechOperator& op = d->sd->oper();
       if (exa_model_nfev_hist(op.GetModel()->ctx(), op.matVars1.p, hist64, op.stream()) != EXA_OK) throw std::runtime_error(exa_last_error(op.GetModel()->ctx()));
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
+int exa_driver_get_qf_component(exa_driver* d, int which, int comp, double* out, char* err, int errlen) {
+   try {
+      NonlinearMechOperator& op = d->sd->oper();
+      const DevBuf<double>* b = which == 0 ? &op.matVars0 : (which == 1 ? &op.matVars1 : (which == 2 ? &op.stress0 : &op.stress1));
+      const int W = which < 2 ? 28 : 6;
+      if (comp < 0 || comp >= W) throw std::runtime_error("exa_driver_get_qf_component: component out of range");
+      EXA_HC(hipStreamSynchronize(op.stream()));
+      const std::vector<double> h = b->to_host();
+      const exa_ctx* ctx = op.GetModel()->ctx();
+      const int Q = exa_qpts_per_elem(ctx); const int64_t E = d->sd->part.E;
+      const bool blk = exa_get_quadrature_layout(ctx) == EXA_QLAYOUT_EB64;
+      for (int64_t e = 0; e < E; e++)
+         for (int q = 0; q < Q; q++)
+            out[e * Q + q] = blk ? h[((((e >> 6) * Q + q) * (int64_t)W + comp) << 6) + (e & 63)] : h[(int64_t)W * (q + (int64_t)Q * e) + comp];
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }

@@ -291,6 +291,14 @@ static bool km_pq1(const exa_ctx* ctx) {
    return !(e && std::strcmp(e, "off") == 0) && ctx->mp.p == 1.0 && ctx->mp.q == 1.0;
 }
 
+// Voce sets whose power-law exponent 1/m - 1 is 49 (m = 0.02: the shipped sets) run the instantiation with the exponent compiled in
+// (ecmdev::KIN_XN49: same multiplication chain, no run-time choice among the power forms inside every evaluation); EXA_VOCE_XN_CT=off keeps the
+// general instantiation for A/B runs.  Element-blocked fused launches only (the driver's routes).
+static bool voce_xn49(const exa_ctx* ctx) {
+   const char* e = std::getenv("EXA_VOCE_XN_CT");
+   return !(e && std::strcmp(e, "off") == 0) && ctx->mp.xn_int == 49;
+}
+
 // lists and solver-state buffers of the tail split, allocated on first use; the list counters are cleared for the coming launch sequence
 static int exa_prepare_tail_lists(exa_ctx* ctx, hipStream_t s) {
    if (!ctx->tail_dev) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->tail_dev, sizeof(int) * ((size_t)ctx->P + 1)));
@@ -315,8 +323,14 @@ int exa_launch_model_setup_rec(exa_ctx* ctx, double dt, double* J, const double*
       if (int rc = exa_prepare_tail_lists(ctx, s)) return rc;
    }
    switch (ctx->mp.kin) {
-      case KIN_VOCE: launch_model_rec<KIN_VOCE>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s); break;
-      case KIN_VOCE_NL: launch_model_rec<KIN_VOCE_NL>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s); break;
+      case KIN_VOCE:
+         if (voce_xn49(ctx)) launch_model_rec<KIN_VOCE | KIN_XN49>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
+         else launch_model_rec<KIN_VOCE>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
+         break;
+      case KIN_VOCE_NL:
+         if (voce_xn49(ctx)) launch_model_rec<KIN_VOCE_NL | KIN_XN49>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
+         else launch_model_rec<KIN_VOCE_NL>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
+         break;
       default:
          if (km_pq1(ctx)) {
             if (ECM_KM_DEFER && ctx->mp.with_g_athermal) launch_model_rec<KIN_KMBALD_GA | KIN_PQ1>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
@@ -355,11 +369,17 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
    if (lv && ctx->n == 27 && ctx->qblk) { if (int rc = exa_ensure_p2_tables(ctx)) return rc; }
    switch (ctx->mp.kin) {
       case KIN_VOCE:
-         if (lv) launch_model<KIN_VOCE, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         if (lv && ctx->qblk && (ctx->n == 8 || ctx->n == 27) && voce_xn49(ctx)) {   // element-blocked fused launches with the exponent compiled in
+            if (ctx->n == 8) launch_model_q<KIN_VOCE | KIN_XN49, true, 8, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+            else launch_model_q<KIN_VOCE | KIN_XN49, true, 27, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         } else if (lv) launch_model<KIN_VOCE, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          else launch_model<KIN_VOCE, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
       case KIN_VOCE_NL:
-         if (lv) launch_model<KIN_VOCE_NL, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         if (lv && ctx->qblk && (ctx->n == 8 || ctx->n == 27) && voce_xn49(ctx)) {
+            if (ctx->n == 8) launch_model_q<KIN_VOCE_NL | KIN_XN49, true, 8, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+            else launch_model_q<KIN_VOCE_NL | KIN_XN49, true, 27, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
+         } else if (lv) launch_model<KIN_VOCE_NL, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          else launch_model<KIN_VOCE_NL, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
       default:

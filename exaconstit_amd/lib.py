@@ -52,6 +52,7 @@ exa_nodes_per_elem = _sig("exa_nodes_per_elem", C.c_int, C.c_void_p)
 exa_qpts_per_elem = _sig("exa_qpts_per_elem", C.c_int, C.c_void_p)
 exa_shape_table = _sig("exa_shape_table", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 exa_set_quadrature_layout = _sig("exa_set_quadrature_layout", C.c_int, C.c_void_p, C.c_int)
+exa_get_quadrature_layout = _sig("exa_get_quadrature_layout", C.c_int, C.c_void_p)
 exa_qf_size = _sig("exa_qf_size", C.c_int64, C.c_void_p, C.c_int)
 EXA_QLAYOUT_AOS, EXA_QLAYOUT_EB64 = 0, 1
 exa_init_state = _sig("exa_init_state", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
@@ -157,6 +158,7 @@ exa_driver_get_stats = _sig("exa_driver_get_stats", C.c_int, C.c_void_p, C.POINT
 exa_driver_get_timers = _sig("exa_driver_get_timers", None, C.c_void_p, C.POINTER(C.c_double))
 exa_driver_reset_timers = _sig("exa_driver_reset_timers", None, C.c_void_p)
 exa_driver_nfev_hist = _sig("exa_driver_nfev_hist", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_int)
+exa_driver_get_qf_component = _sig("exa_driver_get_qf_component", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int)
 exa_driver_get_diagnostics = _sig("exa_driver_get_diagnostics", None, C.c_void_p, C.POINTER(C.c_int64))
 exa_rccl_microbench = _sig("exa_rccl_microbench", C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_bootstrap_env = _sig("exa_bootstrap_env", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
@@ -260,6 +262,13 @@ class Driver:
         h = np.zeros(64, dtype=np.int32)
         self._chk(exa_driver_nfev_hist(self.h, h.ctypes.data_as(C.POINTER(C.c_int)), self._err, 512))
         return h
+
+    def qf_component(self, which, comp):
+        """One component of a quadrature function ([element][point]); which: 0/1 begin/end state, 2/3 begin/end stress."""
+        import numpy as np
+        out = np.zeros(exa_driver_local_qpts(self.h))
+        self._chk(exa_driver_get_qf_component(self.h, which, comp, out.ctypes.data_as(C.c_void_p), self._err, 512))
+        return out
 
     def bench_model(self, steps):
         import numpy as np

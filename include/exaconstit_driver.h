@@ -66,6 +66,9 @@ void exa_driver_get_diagnostics(exa_driver* d, int64_t* out4);
 void exa_driver_get_pcg_reduction(exa_driver* d, double* out2);
 /* 64-bin histogram of the local-solver evaluation counts (ExaCMech's nFEval state variable) of the last constitutive launch */
 int exa_driver_nfev_hist(exa_driver* d, int* hist64, char* err, int errlen);
+/* one component of a quadrature function of the operator, de-blocked on the host: which = 0 begin-of-step state, 1 end-of-step state (28),
+ * 2 begin stress, 3 end stress (6); out receives E * Q doubles ordered [element][point] (diagnostics: nFEval maps, parity tools) */
+int exa_driver_get_qf_component(exa_driver* d, int which, int comp, double* out, char* err, int errlen);
 int exa_driver_bench_prepare(exa_driver* d, int nsteps, const double* dts, double perturb, char* err, int errlen);
 int exa_driver_bench_model(exa_driver* d, int steps, double* out3, char* err, int errlen);
 int exa_driver_bench_pcg(exa_driver* d, int iters, double* out3, char* err, int errlen);

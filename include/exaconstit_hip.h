@@ -68,6 +68,7 @@ int exa_shape_table(const exa_ctx* ctx, double* G_host /*(n,3,Q)*/, double* W_ho
  *                    the L-vector entry points only (exa_residual_setup / exa_residual_apply stay AOS).  An MFEM adapter keeps AOS. */
 enum { EXA_QLAYOUT_AOS = 0, EXA_QLAYOUT_EB64 = 1 };
 int exa_set_quadrature_layout(exa_ctx* ctx, int layout);
+int exa_get_quadrature_layout(const exa_ctx* ctx);               /* EXA_QLAYOUT_* currently selected */
 int64_t exa_qf_size(const exa_ctx* ctx, int vdim);
 
 /* ExaModel seam ------------------------------------------------------------------------------------------------ */

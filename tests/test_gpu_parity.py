@@ -508,6 +508,48 @@ def test_element_blocked_layout_p2(oracle, integ, assembly, cap):
         assert rel_l2(b[k], a[k]) < tol, k
 
 
+@pytest.mark.parametrize("model,pkey", [(0, "voce"), (2, "voce"), (1, "vocenl")])
+def test_voce_compile_time_exponent_instantiation(oracle, model, pkey, monkeypatch):
+    """Voce sets with 1/m - 1 = 49 run the kernel instantiation that has the exponent compiled in (ecmdev::KIN_XN49; model_kernels.hip,
+    voce_xn49); EXA_VOCE_XN_CT=off keeps the run-time choice among the power forms.  Same multiplication chain: stress, state (evaluation
+    counts included) and tangent agree to round-off of the surrounding arithmetic (the two instantiations are scheduled differently)."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 6, distort=0.15)
+    E, Q, NN = rve["E"], rve["Q"], rve["NN"]
+    props = _props(orc, pkey)
+    assert 1.0 / props[7] - 1.0 == 49.0      # m = 0.02 in the shipped sets
+    quats = hipref.random_quats(E)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    v_nodes = hipref.velocity_field(rve, scale=2.0)
+    outs = []
+    for sw in (None, "off"):
+        if sw is None:
+            monkeypatch.delenv("EXA_VOCE_XN_CT", raising=False)
+        else:
+            monkeypatch.setenv("EXA_VOCE_XN_CT", sw)
+        ctx = L.Context(model, props, 298.0, 1, E)
+        ctx.check(L.exa_set_quadrature_layout(ctx.h, L.EXA_QLAYOUT_EB64)); ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+        sz = lambda w: int(L.exa_qf_size(ctx.h, w))
+        sv = [dev.zeros(sz(28)), dev.zeros(sz(28))]; sg = [dev.zeros(sz(6)), dev.zeros(sz(6))]; cm = dev.zeros(sz(36)); J = dev.zeros(sz(9))
+        d_quats_keep = dev.up(quats.ravel())
+        ctx.check(L.exa_init_state(ctx.h, ptr(sv[0]), ptr(d_quats_keep), None))
+        d_x = dev.up(rve["X"]); d_v = dev.up(v_nodes)
+        for dt in (0.1, 0.3, 0.5, 0.5):
+            d_x += dt * d_v
+            ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(sg[0]), ptr(sv[0]), ptr(sg[1]), ptr(sv[1]), ptr(cm), ptr(J), None))
+            assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+            sv.reverse(); sg.reverse()
+        outs.append((_eb64_to_aos(sv[0], E, Q, 28).cpu().numpy(), _eb64_to_aos(sg[0], E, Q, 6).cpu().numpy(), _eb64_to_aos(cm, E, Q, 36).cpu().numpy()))
+        ctx.close()
+    a, b = outs
+    assert a[0][:, 3].max() > 4                                  # plastic: the local solve iterated
+    assert np.array_equal(a[0][:, 3], b[0][:, 3])                # same evaluation counts
+    assert rel_l2(a[0], b[0]) < 1e-13 and rel_l2(a[1], b[1]) < 1e-13 and rel_l2(a[2], b[2]) < 1e-12
+
+
 @pytest.mark.parametrize("model,pkey,cap", [(0, "voce", 4), (5, "mts", 3), (4, "mts", 5)])
 def test_tail_split_is_bitwise_neutral(oracle, model, pkey, cap):
     """exa_set_newton_cap(s): points cut off after K evaluations are finished by the dense tail launch - from scratch, resumed from the saved
