@@ -54,7 +54,7 @@ constexpr int H_SHRATE = 0, H_SHR = 1, H_FLOW = 2, H_NFEV = 3, H_E = 4, H_Q = 9,
 constexpr int RS_N = 10;   // doubles of a cut-off point's solver state (point_update, TailIO)
 // tail split (model_kernels.hip, launch_levels): where a cut-off point goes, and the saved state a listed point resumes from (already offset to its slot)
 // defer_reject (capped full launch with state buffers): a point whose trial is rejected leaves for the dense launch right away (point_update)
-struct TailIO { int* list_out = nullptr; double* rs_out = nullptr; const double* rs_in = nullptr; int64_t stride = 0; int ipt = 0; bool defer_reject = false; };
+struct TailIO { int* list_out = nullptr; double* rs_out = nullptr; const double* rs_in = nullptr; int64_t stride = 0; bool defer_reject = false; };
 constexpr int NUM_HIST = 26, NSTATEV = 28, IND_VOL = 26, IND_EINT = 27;
 
 enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2,
@@ -604,10 +604,21 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #define ECM_SWEEP_UNROLL 0   // block Gauss-Seidel sweeps of the Newton step rolled (1: unrolled; A/B on MI355X)
 #endif
 #ifndef ECM_STASH_STRIDE
-#define ECM_STASH_STRIDE 256
+#define ECM_STASH_STRIDE 128   // = threads per block of the constitutive launch.  128 (4 blocks of 2 waves per CU) instead of 256: every stash slot is then within
+                               // the 64 KB reach of a ds_read / ds_write immediate offset from ONE address register (with 256 the slots from 32 up
+                               // needed their own address registers, which the allocator spilled), and a block waits for 2 waves instead of 4
+#endif
+#ifndef ECM_EPI_NO_LOADS
+#define ECM_EPI_NO_LOADS 1   // no global or scratch load behind the first output store: on gfx9 loads and stores share the in-order vmcnt counter, so a load
+                             // issued after the record / state stores waits until every one of them has reached memory (a store-queue drain of a few
+                             // microseconds, twice per wave in the round-3 kernel).  The two begin-of-step values the outputs need are read with the other
+                             // inputs and parked in the stash, and the output addresses are re-derived from the thread index after the local solve
+                             // (PointIO::refresh) instead of being carried - and spilled - through it (A/B switch)
 #endif
 constexpr int ST_EN = 0, ST_DN = 5, ST_WN = 10, ST_XS = 13, ST_CD = 21, ST_PB = 33, ST_SLOTS = 38;   // ST_XS: restore copy of the unknowns; ST_CD: parking slots; ST_PB: rarely used scalars of the point problem
 constexpr int PB_SCI = 0, PB_ESCI = 1, PB_DETVRI = 2;   // 1/sc, 1/esc, 1/detV: read once per Newton step / in the epilogue only
+constexpr int PB_SHR0 = 3, PB_FLOW0 = 4;               // begin-of-step accumulated shear / plastic work: only the outputs need them (see ECM_EPI_NO_LOADS)
+static_assert(ST_PB + PB_FLOW0 < ST_SLOTS, "stash slots");
 constexpr int ST_NCD = ST_PB - ST_CD;
 // (the deviatoric stress work of the step needs D' and the old stress only through  sum (s_old + s_new) . D' = s_old . D' + s_lat . d_lat:
 //  the first scalar is parked, the second uses the lattice-frame D' of the converged evaluation - 10 slots fewer than parking both vectors)
@@ -616,8 +627,8 @@ static_assert(CD_WRKOLD < ST_NCD, "every parked value lives in the LDS stash");
 #define ECM_ST(p, slot) (p)[(slot) * ECM_STASH_STRIDE]
 // compiler-only barrier: what was parked must be re-loaded later instead of being kept alive in registers
 #define ECM_PARK_BARRIER() asm volatile("" ::: "memory")
-// parking slot c (compile-time): the first ST_NCD live in the LDS stash, the rest in the point's tangent slot in global memory
-#define ECM_CD(c) (*(((c) < ST_NCD) ? &ECM_ST(st, ST_CD + (((c) < ST_NCD) ? (c) : 0)) : &cold[(((c) < ST_NCD) ? 0 : (c) - ST_NCD) * CSTR]))
+// parking slot c (compile-time) of the LDS stash (every parked value lives there: static_assert above)
+#define ECM_CD(c) ECM_ST(st, ST_CD + (c))
 
 // ------------------------------------------------------------------------------------------------------------
 // the point problem: unknowns x = (delta e / E_SCALE, xi / R_SCALE).  e is the library's strain STATE = a_V * E with a_V = detV^(1/3)
@@ -1171,20 +1182,39 @@ ECM_DI void jac_mult_T(const MatParams& mp, const Prob& pb, const Jac& J, const 
 }
 
 // solve J dx = rhs by block Gauss-Seidel on the exact diagonal-block inverses (rhs_r may be identically zero: ZERO_R)
+// ECM_GS_START0: the sweeps start from x_r = 0 instead of x_r = Jrr^-1 rhs_r.  The first sweep then has no coupling term in its strain
+// half (x_e = Jee^-1 rhs_e) and the start-up product disappears: 39 FP64 operations fewer per Newton step.  Both starts leave an error
+// of (contraction)^2 ~ 1e-8 of an O(1) quantity after two sweeps (x_r* itself here, Jrr^-1 Jre x_e* there).
+#ifndef ECM_GS_START0
+#define ECM_GS_START0 0   // measured at 128^3 (profiles/r04_kernel_experiments.txt): 4.85 ms either way, so the round-3 form stays
+#endif
+#ifndef ECM_EXP_NSWEEP
+#define ECM_EXP_NSWEEP 0   // timing experiment: number of sweeps of the Newton step (0 = the product's two)
+#endif
 template <bool ZERO_R, int NSWEEP>
 ECM_DI void jac_solve(const MatParams& mp, const Prob& pb, const Jac& J, const Fact& F, const double rhs[8], double dx[8]) {
    double xr[3] = { 0, 0, 0 };
-   if (!ZERO_R) {
+   double xe[5];
+   if (ECM_GS_START0) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) xe[i] = rhs[i];
+      jee_solve(mp, J, xe);
+      double c[3]; jre_mult(mp, J, xe, c);
+      double br[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) br[i] = (ZERO_R ? 0.0 : rhs[5 + i]) - c[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) xr[i] = F.Ri[3 * i] * br[0] + F.Ri[3 * i + 1] * br[1] + F.Ri[3 * i + 2] * br[2];
+   } else if (!ZERO_R) {
 #pragma unroll
       for (int i = 0; i < 3; i++) xr[i] = F.Ri[3 * i] * rhs[5] + F.Ri[3 * i + 1] * rhs[6] + F.Ri[3 * i + 2] * rhs[7];
    }
-   double xe[5];
 #if ECM_SWEEP_UNROLL
 #pragma unroll
 #else
 #pragma unroll 1
 #endif
-   for (int sweep = 0; sweep < NSWEEP; sweep++) {
+   for (int sweep = (ECM_GS_START0 ? 1 : 0); sweep < NSWEEP; sweep++) {
       double t[5]; jer_mult(J, xr, t);
 #pragma unroll
       for (int i = 0; i < 5; i++) xe[i] = rhs[i] - t[i];
@@ -1220,14 +1250,14 @@ ECM_DI double norm8sq(const double v[8]) { double s = 0; for (int i = 0; i < 8; 
 // tangent is built from, D = D55 / dt, and the bulk term K, both times tsc = dt W_q / detJ - what AssembleGradPA + the projection of
 // k_grad_setup_pa<.., CMP> would produce from the 36 entries (reference src/mechanics_integrators.cpp:331-414), without the round trip.
 // cmat then points at the lane's first 16-byte pair of the record ([13 pairs][64 lanes][2]); trd stores D^T (element-assembly contexts).
-template <int KIN, int QS, bool REC = false>
-ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const double* __restrict__ sv0, const double* __restrict__ s0,
-                        double* __restrict__ sv1, double* __restrict__ s1, double* __restrict__ cmat, double* st, const int kcap,
+// IO: where the point's data lives (model_kernels.hip, PointIO): sv0() / s0() begin-of-step state / stress, sv1() / s1() / cm() outputs, stash()
+// the lane's LDS stash, ipt() the point id, refresh() re-derives all of them from the thread index (see ECM_EPI_NO_LOADS)
+template <int KIN, int QS, bool REC = false, class IO>
+ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io, const int kcap,
                         const double* pq_lds = nullptr, const double tsc = 0.0, const bool trd = false, const TailIO tio = TailIO()) {
    const bool resume = tio.rs_in != nullptr;
-   // parking area for the cold values that do not fit the LDS stash: the point's own output slot (written last)
-   constexpr int CSTR = REC ? 128 : QS;
-   double* cold = REC ? cmat : cmat + ST_NCD * QS;
+   const double* __restrict__ sv0 = io.sv0(); const double* __restrict__ s0 = io.s0();
+   double* st = io.stash();
    Prob pb; pb.st = st; pb.gs = QS; pb.pqt = pq_lds;
    pb.dt_ri = 1.0 / dt;
    {
@@ -1265,6 +1295,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       for (int i = 0; i < 4; i++) ECM_CD(CD_QN + i) = qn[i];
       ECM_CD(CD_VOLD) = vOld; ECM_CD(CD_VNEW) = vNew; ECM_CD(CD_ENEW) = eNew; ECM_CD(CD_DEFF) = dEff; ECM_CD(CD_BULK) = bulkNew; ECM_CD(CD_HU) = h_u;
       if (REC) ECM_CD(CD_TSC) = tsc;
+      if (ECM_EPI_NO_LOADS) { ECM_ST(st, ST_PB + PB_SHR0) = ldg(&sv0[(H_SHR) * QS]); ECM_ST(st, ST_PB + PB_FLOW0) = ldg(&sv0[(H_FLOW) * QS]); }
       double adots_ref;
       if (kin_is_km(KIN)) {
          const double sq = sqrt(h_u);
@@ -1282,6 +1313,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
 
 #ifdef ECM_EXP_IO_ONLY   // timing experiment only: the launch's memory traffic without the constitutive arithmetic
    {
+      double* sv1 = io.sv1(); double* s1 = io.s1(); double* cmat = io.cm();
       double acc = 0.0;
       for (int i = 0; i < NSTATEV; i++) { const double v = ldg(&sv0[i * QS]); acc += v; stg(&sv1[i * QS], v + L[i % 9]); }
       for (int i = 0; i < 6; i++) stg(&s1[i * QS], ldg(&s0[i * QS]) + acc);
@@ -1300,7 +1332,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
    if (resume) { for (int i = 0; i < 8; i++) x[i] = ldg(&tio.rs_in[i * tio.stride]); }
    double r[8], dis_rate, shrate;
    Jac J; Fact F;
-   double* gdot_out = (kin_is_km(KIN) && !ECM_KM_GDOT_AT_END) ? sv1 + H_GDOT * QS : nullptr;
+   double* gdot_out = (kin_is_km(KIN) && !ECM_KM_GDOT_AT_END) ? io.sv1() + H_GDOT * QS : nullptr;
    int nfev = 1; bool conv = false;
    bool ok = eval_rj<KIN, true>(mp, pb, x, r, J, gdot_out, dis_rate, shrate);
    // Norms are carried SQUARED: the common iteration (full Newton step inside the trust region) only compares them - |r| < tol, |dx| <= delta,
@@ -1350,7 +1382,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          // tail split: a point that needs more than kcap evaluations is handed to the dense tail launch (which starts over, so the
          // result is the one of an uncapped solve); the wave stops waiting for its slowest lanes
          if (nfev >= kcap || (DEFER && hand_over)) {
-            const int slot = atomicAdd(&tio.list_out[0], 1); tio.list_out[1 + slot] = tio.ipt;
+            const int slot = atomicAdd(&tio.list_out[0], 1); tio.list_out[1 + slot] = io.ipt();
             if (tio.rs_out) {
                double* o = tio.rs_out + slot;
                for (int i = 0; i < 8; i++) stg(&o[i * tio.stride], x[i]);
@@ -1364,7 +1396,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
             jac_factor(mp, pb, J, F);
             if (F.ok) {
                double rhs[8]; for (int i = 0; i < 8; i++) rhs[i] = -r[i];
-               jac_solve<false, 2>(mp, pb, J, F, rhs, t);
+               jac_solve<false, (ECM_EXP_NSWEEP ? ECM_EXP_NSWEEP : 2)>(mp, pb, J, F, rhs, t);
                const double esc_i = ECM_ST(st, ST_PB + PB_ESCI);
                for (int i = 0; i < 8; i++) nr[i] = t[i] * ((i < 5) ? esc_i : (1.0 / R_SCALE));
                nr2sq = norm8sq(nr);
@@ -1432,6 +1464,8 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       }
    }
    // ---- converged state: stress, energy, history (getResponseSngl tail + reference kernel_postprocessing src/mechanics_ecmech.cpp:116-152)
+   if (ECM_EPI_NO_LOADS) { io.refresh(); st = io.stash(); pb.st = st; }
+   double* __restrict__ sv1 = io.sv1(); double* __restrict__ s1 = io.s1(); double* __restrict__ cmat = io.cm();
    double e_f[5], xi[3];
    for (int i = 0; i < 5; i++) e_f[i] = ECM_ST(st, ST_EN + i) + x[i] * pb.esc;
    for (int i = 0; i < 3; i++) xi[i] = x[5 + i] * R_SCALE;
@@ -1475,8 +1509,8 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       if constexpr (!kin_is_km(KIN)) voce_slip_rates<kin_xn_ct(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS, dis_rate, shrate);
       else if (ECM_KM_GDOT_AT_END) km_slip_rates<kin_pq1(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS);
       stg(&sv1[(H_SHRATE) * QS], shrate);
-      stg(&sv1[(H_SHR) * QS], ldg(&sv0[(H_SHR) * QS]) + shrate * dt);
-      stg(&sv1[(H_FLOW) * QS], ((deff_keep > TINY_SQRT) ? dis_rate * dt : 0.0) + ldg(&sv0[(H_FLOW) * QS]));   // accumulated plastic work
+      stg(&sv1[(H_SHR) * QS], (ECM_EPI_NO_LOADS ? ECM_ST(st, ST_PB + PB_SHR0) : ldg(&sv0[(H_SHR) * QS])) + shrate * dt);
+      stg(&sv1[(H_FLOW) * QS], ((deff_keep > TINY_SQRT) ? dis_rate * dt : 0.0) + (ECM_EPI_NO_LOADS ? ECM_ST(st, ST_PB + PB_FLOW0) : ldg(&sv0[(H_FLOW) * QS])));   // accumulated plastic work
       stg(&sv1[(H_NFEV) * QS], (double)nfev);
       { const double a_V = E_SCALE * ECM_ST(st, ST_PB + PB_ESCI); for (int i = 0; i < 5; i++) stg(&sv1[(H_E + i) * QS], e_f[i] * a_V); }   // state e = a_V E
       stg(&sv1[(H_H) * QS], hu_keep);
@@ -1487,6 +1521,10 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
       stg(&s1[(3) * QS], SQR2I * s_sm[4]); stg(&s1[(4) * QS], SQR2I * s_sm[3]); stg(&s1[(5) * QS], SQR2I * s_sm[2]);
    };
    if (!ECM_TANGENT_FIRST) write_state();
+#ifdef ECM_EXP_TAN_FAKE   // timing experiment: the 13 record stores without the tangent arithmetic
+   if constexpr (REC) { double2* rc = reinterpret_cast<double2*>(cmat); for (int pr = 0; pr < 13; pr++) rc[pr * 64] = make_double2(J.A[pr] * detV_ri, bulkNew + J.B[pr % 3][pr % 5]); }
+#define ECM_NO_TANGENT 1
+#endif
 #ifndef ECM_NO_TANGENT
    // ---- tangent (last: it overwrites the parking area): lattice-frame d sigma'/d D' by implicit differentiation on the converged
    // factorisation, rotated to the sample frame, then to Voigt (engineering shear) + bulk term, column-major
@@ -1595,8 +1633,12 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], const
          }
          Dm[25] = bulkNew * rsc;
          double2* rc = reinterpret_cast<double2*>(cmat);
+#ifdef ECM_EXP_TAN_NOSTORE   // timing experiment: the tangent arithmetic without its 13 record stores (one store of a checksum keeps it alive)
+         { double a = 0.0, b = 0.0; for (int pr = 0; pr < 13; pr++) { a += Dm[2 * pr]; b += Dm[2 * pr + 1]; } rc[0] = make_double2(a, b); }
+#else
 #pragma unroll
          for (int pr = 0; pr < 13; pr++) rc[pr * 64] = make_double2(Dm[2 * pr], Dm[2 * pr + 1]);
+#endif
       } else {
       const double dti = pb.dt_ri * (okT ? 1.0 : 0.0);
 #pragma unroll

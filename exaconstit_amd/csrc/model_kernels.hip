@@ -16,6 +16,39 @@ using namespace ecmdev;
 #ifndef EXA_MODEL_OCC
 #define EXA_MODEL_OCC 2   // waves per SIMD the register allocator is asked to fit (tuned on MI355X)
 #endif
+#ifndef EXA_MODEL_BS
+#define EXA_MODEL_BS ECM_STASH_STRIDE   // threads per block of the constitutive launch = stride of the per-lane LDS stash
+#endif
+static_assert(EXA_MODEL_BS == ECM_STASH_STRIDE && EXA_MODEL_BS % 64 == 0, "stash stride must equal the block size");
+
+// Where one thread's quadrature point lives.  Everything is a function of (block index, thread index) and kernel-uniform data, so nothing
+// per-lane has to survive the local Newton solve: locate() derives the point from the thread index, refresh() does it again behind a compiler
+// barrier after the solve, and the accessors form the addresses where they are used.  Before, five 64-bit row pointers and two LDS addresses
+// were live across the solve; the register allocator spilled some of them and re-loaded them from scratch BEHIND the first output stores,
+// where a load waits for the whole store queue of the wave (ecm_device.hpp, ECM_EPI_NO_LOADS).
+template <bool QB, bool REC>
+struct PointIO {
+   const double* state0; const double* stress0; double* state1; double* stress1; double* cmat;   // kernel-uniform array bases
+   double* stash0;                  // LDS stash of thread 0 of the block
+   const int* tail; int tail_mode;  // dense tail launch: thread t owns point tail[1 + t]
+   int Q; int64_t bidx; int wpb;    // points per element, (remapped) block index, waves per block
+   int q; int64_t e; int tid;       // this thread's point and its index in the block
+   __device__ __forceinline__ void locate(const int tid_) {
+      tid = tid_;
+      if (tail_mode) { const int64_t ipt = tail[1 + bidx * (int64_t)(wpb * 64) + tid]; q = (int)(ipt % Q); e = ipt / Q; }
+      else if (QB) { const int64_t gw = bidx * wpb + (tid >> 6); q = (int)(gw % Q); e = (gw / Q) * 64 + (tid & 63); }   // wave = (block of 64 elements, q); lane = element
+      else { const int64_t ip = bidx * (int64_t)(wpb * 64) + tid; q = (int)(ip % Q); e = ip / Q; }
+   }
+   __device__ __forceinline__ void refresh() { int t = threadIdx.x; asm volatile("" : "+v"(t)); locate(t); }
+   __device__ __forceinline__ const double* sv0() const { return state0 + qview<QB>(ecmdev::NSTATEV, Q, e, q).base; }
+   __device__ __forceinline__ const double* s0() const { return stress0 + qview<QB>(6, Q, e, q).base; }
+   __device__ __forceinline__ double* sv1() const { return state1 + qview<QB>(ecmdev::NSTATEV, Q, e, q).base; }
+   __device__ __forceinline__ double* s1() const { return stress1 + qview<QB>(6, Q, e, q).base; }
+   // REC: the lane's first 16-byte pair of its compact record ([block][q][13 pairs][64 lanes][2]); else the tangent slot
+   __device__ __forceinline__ double* cm() const { return REC ? cmat + pac_off<PAC_PAIRS>(e >> 6, Q, q, 0) + 2 * (e & 63) : cmat + qview<QB>(36, Q, e, q).base; }
+   __device__ __forceinline__ double* stash() const { return stash0 + tid; }
+   __device__ __forceinline__ int ipt() const { return (int)(e * Q + q); }
+};
 
 // LVEC = false: J (3,3,Q,E) and the velocity E-vector (n,3,E) are inputs (the reference's ModelSetup signature).
 // LVEC = true : the kernel gathers nodal coordinates and velocities from the L-vectors through the connectivity, computes J itself
@@ -28,7 +61,7 @@ using namespace ecmdev;
 // REC (fused p = 1 launch of the stand-alone driver): cmat is the buffer of compact gradient records and the launch writes, instead of the
 // 36 tangent entries, the record the gradient action streams (ecm_device.hpp, point_update<.., REC>): AssembleGradPA rides in the launch.
 template <int KIN, bool LVEC, int NFIX, bool QB, bool REC = false>
-__global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatParams mp, const int Q, const int n_rt, const int64_t P, const double dt,
+__global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(const MatParams mp, const int Q, const int n_rt, const int64_t P, const double dt,
                                                      double* __restrict__ Jio, const double* __restrict__ G,
                                                      const double* __restrict__ vel, const double* __restrict__ xl, const int32_t* __restrict__ conn, const int nnodes,
                                                      const double* __restrict__ stress0,
@@ -44,14 +77,6 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
    if (tail_mode && (int64_t)blockIdx.x * blockDim.x >= tail[0]) return;   // tail launch: its grid covers the worst case, blocks beyond the list leave before the table fill
    const int n = NFIX ? NFIX : n_rt;
    constexpr bool P2F = (NFIX == 27);   // triquadratic fused path: G holds the 3 x 6 one-dimensional tables, read through scalar loads
-   extern __shared__ double sG[];   // (n,3,Q) shape table (not for P2F), then the per-thread stash
-   const int tab = P2F ? 0 : n * 3 * Q;
-   // Kocks-Mecking: the slip table (12 rows of 8) behind the stash, for the rows that are read by lane-varying index (ecm_device.hpp, eval_rj)
-   const int pqo = tab + ecmdev::ST_SLOTS * ECM_STASH_STRIDE;
-   if (!P2F) for (int i = threadIdx.x; i < tab; i += blockDim.x) sG[i] = G[i];
-   if (ecmdev::kin_is_km(KIN) && threadIdx.x < 8 * ecmdev::NSLIP) sG[pqo + threadIdx.x] = (&ecmdev::PQ_TAB[0][0])[threadIdx.x];
-   if (!P2F || ecmdev::kin_is_km(KIN)) __syncthreads();
-   int q; int64_t e;
 #ifndef EXA_MODEL_XCD_REMAP
 #define EXA_MODEL_XCD_REMAP 0
 #endif
@@ -62,24 +87,34 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
       const unsigned nb = gridDim.x, qq = nb >> 3, r = nb & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
       bidx = x < r ? (int64_t)x * (qq + 1) + i : (int64_t)r * (qq + 1) + (int64_t)(x - r) * qq + i;
    }
+   // LDS: shape-derivative rows (not for P2F), the per-thread stash, the slip table (Kocks-Mecking).  A wave of the element-blocked launch works
+   // on ONE point index q, so only the rows of the block's waves are staged (row w = the (n,3) table of wave w's q: 192 B per wave instead of
+   // the 1.5 KB table - what lets four 128-thread blocks of the Kocks-Mecking kernels fit the 160 KB of a CU); the dense tail launch and the
+   // reference layout have lane-varying q and stage the whole (n,3,Q) table (model_lds_bytes gives the launch the matching size)
+   extern __shared__ double sG[];
+   const bool rows_by_wave = QB && !tail_mode;
+   const int wpb = (int)(blockDim.x >> 6);
+   const int tab = P2F ? 0 : n * 3 * (rows_by_wave ? wpb : Q);
+   // Kocks-Mecking: the slip table (12 rows of 8) behind the stash, for the rows that are read by lane-varying index (ecm_device.hpp, eval_rj)
+   const int pqo = tab + ecmdev::ST_SLOTS * ECM_STASH_STRIDE;
+   if (!P2F) for (int i = threadIdx.x; i < tab; i += blockDim.x) {
+      const int row = i / (3 * n), k = i - row * (3 * n);
+      sG[i] = G[3 * n * (rows_by_wave ? (int)((bidx * wpb + row) % Q) : row) + k];
+   }
+   if (ecmdev::kin_is_km(KIN)) for (int i = threadIdx.x; i < 8 * ecmdev::NSLIP; i += blockDim.x) sG[pqo + i] = (&ecmdev::PQ_TAB[0][0])[i];
+   if (!P2F || ecmdev::kin_is_km(KIN)) __syncthreads();
    if (tail_mode) {   // dense pass over the points the capped launch handed over: thread t owns point tail[1 + t]
       const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
       if (t >= tail[0]) return;
-      const int64_t ipt = tail[1 + t];
-      q = (int)(ipt % Q); e = ipt / Q;
       if (rs_in) rs_in += t;   // this point's slot
-   } else if (QB) {   // wave = (block of 64 elements, q); lane = element
-      const int64_t gw = bidx * (blockDim.x >> 6) + (threadIdx.x >> 6);
-      q = (int)(gw % Q); e = (gw / Q) * 64 + (threadIdx.x & 63);
-      if (e * Q >= P) return;
-   } else {
-      const int64_t ip = bidx * blockDim.x + threadIdx.x;
-      if (ip >= P) return;
-      q = (int)(ip % Q); e = ip / Q;
    }
+   PointIO<QB, REC> io{ state0, stress0, state1, stress1, cmat, sG + tab, tail, tail_mode, Q, bidx, wpb, 0, 0, 0 };
+   io.locate(threadIdx.x);
+   const int q = io.q; const int64_t e = io.e;
+   if (!tail_mode && e * Q >= P) return;
    constexpr int QS = QB ? 64 : 1;
-   const QView vJ = qview<QB>(9, Q, e, q), vS = qview<QB>(6, Q, e, q), vV = qview<QB>(NSTATEV, Q, e, q), vC = qview<QB>(36, Q, e, q);
-   const double* Gq = sG + 3 * n * q;
+   const QView vJ = qview<QB>(9, Q, e, q);
+   const double* Gq = sG + 3 * n * (rows_by_wave ? (int)(threadIdx.x >> 6) : q);
    double J11, J21, J31, J12, J22, J32, J13, J23, J33;
    double tsc = 0.0;   // REC: dt W_q / detJ
    double L[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -157,12 +192,9 @@ __global__ __launch_bounds__(256, EXA_MODEL_OCC) void k_model_setup(const MatPar
 #pragma unroll
       for (int tt = 0; tt < 3; tt++) L[c + 3 * tt] = Lx[c] * Ji[0][tt] + Lx[c + 3] * Ji[1][tt] + Lx[c + 6] * Ji[2][tt];
    }
-   // per-thread stash behind the shape table in LDS: slot s of this thread at stash[s * 256 + threadIdx.x]
-   double* st = sG + tab + threadIdx.x;
-   // REC: the lane's first 16-byte pair of its compact record ([block][q][13 pairs][64 lanes][2])
-   double* tout = REC ? cmat + pac_off<PAC_PAIRS>(e >> 6, Q, q, 0) + 2 * (e & 63) : cmat + vC.base;
-   const int rc = point_update<KIN, QS, REC>(mp, dt, L, state0 + vV.base, stress0 + vS.base, state1 + vV.base, stress1 + vS.base, tout, st, kcap, sG + pqo, tsc, trd != 0,
-                                             TailIO{ tail_out, rs_out, tail_mode ? rs_in : nullptr, P, (int)(e * Q + q), !tail_mode && rs_out != nullptr });
+   // per-thread stash behind the shape table in LDS: slot s of this thread at stash[s * ECM_STASH_STRIDE + threadIdx.x] (PointIO::stash)
+   const int rc = point_update<KIN, QS, REC>(mp, dt, L, io, kcap, sG + pqo, tsc, trd != 0,
+                                             TailIO{ tail_out, rs_out, tail_mode ? rs_in : nullptr, P, !tail_mode && rs_out != nullptr });
    if (rc == 1) atomicAdd(fail, 1);
 }
 
@@ -242,13 +274,19 @@ int exa_launch_nfev_hist(exa_ctx* ctx, const double* state, int* hist_dev, hipSt
 // and lists it; a dense launch of the same kernel (thread = listed point; its grid covers the worst case, blocks beyond the list leave at
 // once) takes the list up - from the saved solver state when the context holds the state buffers, from scratch otherwise - and, with a
 // second cap, lists what it cuts off itself for a third launch.
+// dynamic LDS of a launch of k_model_setup: shape rows (per wave for the element-blocked full launch, the whole table otherwise) + stash + slip table
+static size_t model_lds_bytes(const exa_ctx* ctx, bool km, bool p2f, bool qb, int tail_mode) {
+   const size_t rows = p2f ? 0 : (size_t)ctx->n * 3 * ((qb && !tail_mode) ? (size_t)(EXA_MODEL_BS / 64) : (size_t)ctx->Q);
+   return sizeof(double) * (rows + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE + (km ? (size_t)8 * ecmdev::NSLIP : (size_t)0));
+}
+
 template <typename Go>
 static void launch_levels(exa_ctx* ctx, int64_t nb, Go&& go) {
    const int NOCAP = 1 << 30;
    const bool split = ctx->newton_cap > 0 && ctx->tail_dev != nullptr;
    if (!split) { go(nb, NOCAP, ctx->tail_dev, 0, (int*)nullptr, (const double*)nullptr, (double*)nullptr); return; }
    const bool two = ctx->newton_cap2 > ctx->newton_cap && ctx->tail2_dev != nullptr && ctx->resume_dev[0] && ctx->resume_dev[1];
-   const int64_t nbt = (ctx->P + 255) / 256;
+   const int64_t nbt = (ctx->P + EXA_MODEL_BS - 1) / EXA_MODEL_BS;
    go(nb, ctx->newton_cap, ctx->tail_dev, 0, ctx->tail_dev, (const double*)nullptr, ctx->resume_dev[0]);
    go(nbt, two ? ctx->newton_cap2 : NOCAP, ctx->tail_dev, 1, two ? ctx->tail2_dev : ctx->tail_dev, (const double*)ctx->resume_dev[0], two ? ctx->resume_dev[1] : (double*)nullptr);
    if (two) go(nbt, NOCAP, ctx->tail2_dev, 1, ctx->tail2_dev, (const double*)ctx->resume_dev[1], (double*)nullptr);
@@ -257,15 +295,12 @@ static void launch_levels(exa_ctx* ctx, int64_t nb, Go&& go) {
 template <int KIN, bool LVEC, int NFIX, bool QB>
 static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
                          double* stress1, double* state1, double* cmat, hipStream_t s) {
-   const int bs = 256;
+   const int bs = EXA_MODEL_BS;
    // QB: one wave per (64-element block, q)
    const int64_t nb = QB ? (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64) : (ctx->P + bs - 1) / bs;
-   const size_t lds = sizeof(double) * ((NFIX == 27 ? (size_t)0 : (size_t)ctx->n * 3 * ctx->Q) + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE +
-                                        (ecmdev::kin_is_km(KIN) ? (size_t)8 * ecmdev::NSLIP : (size_t)0));
    const double* G = NFIX == 27 ? ctx->T1_dev : ctx->G_dev;
-   static_assert(ECM_STASH_STRIDE == 256, "stash stride must equal the block size");
    launch_levels(ctx, nb, [&](int64_t blocks, int kcap, int* list, int mode, int* list_out, const double* rs_in, double* rs_out) {
-      hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)blocks), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
+      hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)blocks), dim3(bs), model_lds_bytes(ctx, ecmdev::kin_is_km(KIN), NFIX == 27, QB, mode), s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
                          ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, kcap, list, mode, (const double*)nullptr, 0, list_out, rs_in, rs_out);
    });
 }
@@ -274,12 +309,11 @@ static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel
 template <int KIN>
 static void launch_model_rec(exa_ctx* ctx, double dt, double* J, const double* vel, const double* xl, const double* stress0, const double* state0,
                              double* stress1, double* state1, hipStream_t s) {
-   const int bs = 256;
+   const int bs = EXA_MODEL_BS;
    const int64_t nb = (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64);
-   const size_t lds = sizeof(double) * ((size_t)ctx->n * 3 * ctx->Q + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE + (ecmdev::kin_is_km(KIN) ? (size_t)8 * ecmdev::NSLIP : (size_t)0));
    const int trd = ctx->cfg.assembly == EXA_ASSEMBLY_EA;
    launch_levels(ctx, nb, [&](int64_t blocks, int kcap, int* list, int mode, int* list_out, const double* rs_in, double* rs_out) {
-      hipLaunchKernelGGL((k_model_setup<KIN, true, 8, true, true>), dim3((unsigned)blocks), dim3(bs), lds, s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+      hipLaunchKernelGGL((k_model_setup<KIN, true, 8, true, true>), dim3((unsigned)blocks), dim3(bs), model_lds_bytes(ctx, ecmdev::kin_is_km(KIN), false, true, mode), s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
                          ctx->nnodes, stress0, state0, stress1, state1, ctx->pa_c, ctx->fail_count_dev, kcap, list, mode, ctx->W_dev, trd, list_out, rs_in, rs_out);
    });
 }
@@ -331,6 +365,9 @@ int exa_launch_model_setup_rec(exa_ctx* ctx, double dt, double* J, const double*
          if (voce_xn49(ctx)) launch_model_rec<KIN_VOCE_NL | KIN_XN49>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
          else launch_model_rec<KIN_VOCE_NL>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
          break;
+#ifdef EXA_VARIANT_VOCE_ONLY   // timing builds (make variant): the Kocks-Mecking instantiations are left out
+      default: ctx->err = "variant build without Kocks-Mecking kernels"; return EXA_ERR_UNSUPPORTED;
+#else
       default:
          if (km_pq1(ctx)) {
             if (ECM_KM_DEFER && ctx->mp.with_g_athermal) launch_model_rec<KIN_KMBALD_GA | KIN_PQ1>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
@@ -338,6 +375,7 @@ int exa_launch_model_setup_rec(exa_ctx* ctx, double dt, double* J, const double*
          } else if (ECM_KM_DEFER && ctx->mp.with_g_athermal) launch_model_rec<KIN_KMBALD_GA>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
          else launch_model_rec<KIN_KMBALD>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, s);
          break;
+#endif
    }
    EXA_HIP_CHECK(ctx, hipGetLastError());
    return EXA_OK;
@@ -382,6 +420,9 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
          } else if (lv) launch_model<KIN_VOCE_NL, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          else launch_model<KIN_VOCE_NL, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          break;
+#ifdef EXA_VARIANT_VOCE_ONLY
+      default: ctx->err = "variant build without Kocks-Mecking kernels"; return EXA_ERR_UNSUPPORTED;
+#else
       default:
          if (lv && ctx->n == 8 && ctx->qblk && km_pq1(ctx)) {   // p = 1 element-blocked route with the tangent field (Jacobi / element-assembly set-ups)
             if (ECM_KM_DEFER && ctx->mp.with_g_athermal) launch_model_q<KIN_KMBALD_GA | KIN_PQ1, true, 8, true>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
@@ -394,6 +435,7 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
             else launch_model<KIN_KMBALD, false>(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, s);
          }
          break;
+#endif
    }
    EXA_HIP_CHECK(ctx, hipGetLastError());
    return EXA_OK;

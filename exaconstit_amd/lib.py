@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libexaconstit_hip.so")
+LIB_PATH = os.environ.get("EXA_LIB") or os.path.join(_HERE, "libexaconstit_hip.so")   # EXA_LIB: a timing variant built by `make variant` (experiments only)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
