@@ -4,8 +4,11 @@
 Metric (BASELINE.json): "quadrature-point constitutive updates/s + Newton-PCG iter/s, 128^3 hex RVE".
   * `value`            = quadrature-point constitutive updates/s.  One STEP is one full constitutive pass of the residual evaluation
                          (L->E restriction, geometric factors, fused velocity-gradient + ExaCMech update + tangent kernel) over ALL
-                         quadrature points of the 128^3 FCC-Voce RVE in the plastic regime, restarting from the same begin-of-step
-                         state exactly as every residual evaluation of a Newton solve does.
+                         quadrature points of the 128^3 FCC-Voce RVE, restarting from the same begin-of-step state exactly as every
+                         residual evaluation of a Newton solve does.  The state is the one a REAL Newton/PCG solve of the
+                         reference schedule reaches in step --solve-steps (default 14: plastic regime); the passes repeat
+                         that step's converged (last) residual evaluation.  --solve-steps 0 times the kinematically driven state of the
+                         earlier rounds instead (reported beside it as `kinematic_state` in the default run).
   * `pcg_iters_per_s`  = partial-assembly PCG iterations/s on the same RVE (second timed region of the same run).
 Inputs are synthetic (seeded orientations, reference test properties) and resident in HBM before the timed regions.
 Multi-GPU: one process per GPU (torchrun), block domain decomposition of the SAME 128^3 problem (strong scaling, BASELINE config 4),
@@ -37,7 +40,8 @@ APPLY_MOVED_BYTES_COMPACT = 248.0 # ... with the tangent in its deviatoric-block
 PCG_VEC_BYTES_PER_DOF = 128.0
 MODEL_NAMES = {"fcc_voce": "FCC Voce power-law", "bcc_voce": "BCC Voce power-law", "fcc_voce_nl": "FCC non-linear Voce",
                "fcc_kmdd": "FCC Kocks-Mecking dislocation density", "bcc_kmdd": "BCC Kocks-Mecking dislocation density"}
-SETTLE_PASSES = 60                # untimed constitutive passes before the timed region (>= --warmup), see main()
+SETTLE_PASSES = 60                # untimed constitutive passes before the timed region (>= --warmup): reported as `warmup`, see main()
+SOLVE_STEPS_DEFAULT = 14          # real Newton/PCG steps of the reference schedule before the timed passes (plastic regime: steps >= 10)
 PREP_DTS = [0.005, 0.195, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1]   # first 10 steps of the reference schedule: 0.1 % strain, plastic
 
 
@@ -107,6 +111,7 @@ def cpu_baseline(props, seconds_target=12.0):
     nc, elc = timed(0.4 * seconds_target)
     orc.lib().orc_set_threads(1)
     return {"value": P * nc / elc, "unit": "qpt-updates/s", "cores": cores, "cpu": cpu_model(), "kind": "port", "single_thread_value": P * n1 / el1,
+            "what": "oracle/ = this repo's own C++ restatement of the ExaCMech update (g++ -O2 -fopenmp), NOT the ExaCMech library (absent from the image)",
             "sample": f"{N}^3-element FCC-Voce RVE ({P} qpts), same kinematic drive to the plastic regime; constitutive passes of the oracle "
                       f"(element/qpt loops of the reference's CPU path): {n1} serial passes in {el1:.1f} s (rtmodel=CPU analogue) and {nc} passes "
                       f"in {elc:.1f} s with an OpenMP loop over all {cores} host threads (rtmodel=OPENMP analogue; `value`)"}
@@ -124,7 +129,8 @@ def main():
                     help="crystal model of the RVE; the headline metric is quoted on fcc_voce (BASELINE config 4 also names bcc_kmdd)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--jacobi", action="store_true", help="true Jacobi preconditioner (refreshed every Newton iteration) instead of the reference's effective identity (SURVEY fact 9)")
-    ap.add_argument("--solve-steps", type=int, default=0, help="additionally run this many real Newton/PCG time steps and report their rates")
+    ap.add_argument("--solve-steps", type=int, default=int(os.environ.get("EXA_BENCH_SOLVE_STEPS", str(SOLVE_STEPS_DEFAULT))),
+                    help="real Newton/PCG time steps of the reference schedule that bring the RVE to the benchmark state (0: kinematically driven state only)")
     args = ap.parse_args()
 
     import torch
@@ -167,36 +173,88 @@ def main():
     props = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", pfile)).ravel()
     rng = np.random.default_rng(20240928)
     quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
-    drv = L.Driver.synthetic(N, props, quats.ravel(), np.array(PREP_DTS), assembly=0 if args.assembly.upper() == "PA" else 1,
+    asm = 0 if args.assembly.upper() == "PA" else 1
+    drv = L.Driver.synthetic(N, props, quats.ravel(), np.array(PREP_DTS), assembly=asm,
                              krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=uid, jacobi=args.jacobi, **mk)
     del quats
+    P_global = 8 * N ** 3
+    settle = max(args.warmup, SETTLE_PASSES)
+
+    def hist_dict(h):
+        return {"mean": float((h * np.arange(64)).sum() / max(h.sum(), 1)), "max": int(np.nonzero(h)[0].max()) if h.any() else 0,
+                "hist": {str(i): int(c) for i, c in enumerate(h) if c}}
+
+    def timed_passes(d, steps):
+        """untimed settle passes, then `steps` timed passes bracketed by barrier + synchronize; wall s (max over ranks), kernel ms per pass, failed points, histogram"""
+        if settle > 0:
+            d.bench_model(settle)
+        barrier(); t0 = time.perf_counter()
+        mm = d.bench_model(steps)
+        barrier(); tw = max_over_ranks(time.perf_counter() - t0)
+        return tw, max_over_ranks(mm["kernel_ms"]) / steps, mm["failed"], d.nfev_hist()
+
     # elastic regime (first step of the schedule from the virgin state), reported beside the headline plastic-regime value (SURVEY 8(d))
     drv.bench_prepare(PREP_DTS[:1], advance=False)
     drv.bench_model(1)
     barrier(); t0 = time.perf_counter()
     me = drv.bench_model(max(1, args.steps // 2))
     barrier(); t_el = max_over_ranks(time.perf_counter() - t0)
-    elastic = {"value": 8 * N ** 3 * max(1, args.steps // 2) / t_el, "unit": "qpt-updates/s", "avg_kernel_ms": max_over_ranks(me["kernel_ms"]) / max(1, args.steps // 2),
+    elastic = {"value": P_global * max(1, args.steps // 2) / t_el, "unit": "qpt-updates/s", "avg_kernel_ms": max_over_ranks(me["kernel_ms"]) / max(1, args.steps // 2),
                "regime": "elastic (step 1 of the schedule, dt = 0.005, virgin state)"}
+    # kinematically driven plastic state (the benchmark state of rounds 1-3): 10 prescribed-velocity passes, no equilibrium solve
     t0 = time.perf_counter(); drv.bench_prepare(PREP_DTS); barrier(); prep_s = time.perf_counter() - t0
     P_local = L.exa_driver_local_qpts(drv.h)
-    P_global = 8 * N ** 3
-    # ---- timed region 1: constitutive passes -------------------------------------------------------------------------
+    kin_steps = args.steps if args.solve_steps <= 0 else max(5, args.steps // 2)
+    t_kin, kin_kern_ms, kin_failed, kin_hist = timed_passes(drv, kin_steps)
+    kinematic = {"value": P_global * kin_steps / t_kin, "unit": "qpt-updates/s", "avg_kernel_ms": kin_kern_ms, "passes": kin_steps, "nonconverged_points": kin_failed,
+                 "local_solver_evals": hist_dict(kin_hist), "prepare_wall_s": prep_s,
+                 "state": "10 prescribed-velocity passes (v = L0 x + seeded perturbation) through the elastic-plastic transition, no equilibrium solve"}
+    solve = None
+    if args.solve_steps > 0:
+        # ---- real time stepping (Newton + PCG with the reference's settings) on a fresh driver: the benchmark state ------------------------------
+        drv.close()
+        rng = np.random.default_rng(20240928)
+        quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
+        sched = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "custom_dt.txt")).ravel()[:args.solve_steps]
+        drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=asm, rank=rank, nranks=world, uid=uid, jacobi=args.jacobi, **mk)
+        del quats
+        barrier(); t0 = time.perf_counter()
+        rows = []; hist_pl = np.zeros(64, dtype=np.int64); ms_pl = 0.0; calls_pl = 0; kms_tot = 0.0; kit_tot = 0; model_ms_tot = 0.0; calls_tot = 0
+        for ti in range(1, args.solve_steps + 1):
+            drv.reset_timers()
+            last = ti == args.solve_steps     # the last step is solved but not committed: the timed passes repeat its converged launch
+            assert drv.step(ti, commit=not last), f"Newton failed at step {ti}"
+            tm = drv.timers(); nw, kr, mc = drv.stats()
+            mms = max_over_ranks(tm["model_ms"]); calls = int(mc[-1])
+            rows.append({"step": ti, "dt": float(sched[ti - 1]), "newton_iters": int(nw[-1]), "krylov_iters": int(kr[-1]), "model_calls": calls,
+                         "kernel_ms_per_call": mms / max(calls, 1), "qpt_updates_per_s_in_kernel": P_global * calls / (mms * 1e-3)})
+            kms_tot += max_over_ranks(tm["krylov_ms"]); kit_tot += tm["krylov_iters"]; model_ms_tot += mms; calls_tot += calls
+            if ti >= 10:     # steady plastic regime (SURVEY 8(d): "steps >= 5 of the schedule"; the transition has passed by step 10)
+                ms_pl += mms; calls_pl += calls; hist_pl += drv.nfev_hist(which=1 if last else 0)
+        barrier(); wall = max_over_ranks(time.perf_counter() - t0)
+        dg = drv.diagnostics()
+        solve = {"steps": args.solve_steps, "wall_s": wall, "per_step": rows,
+                 "qpt_updates_per_s_in_kernel": P_global * calls_tot / (model_ms_tot * 1e-3),
+                 "pcg_iters_per_s": kit_tot / (kms_tot * 1e-3),
+                 "steady_plastic": ({"steps": f"10..{args.solve_steps}", "qpt_updates_per_s_in_kernel": P_global * calls_pl / (ms_pl * 1e-3),
+                                     "kernel_ms_per_call": ms_pl / calls_pl,
+                                     "local_solver_evals": dict(hist_dict(hist_pl), note="converged launch of every step >= 10 (rank 0)")} if calls_pl else None),
+                 "avg_stress_zz": [float(x) for x in drv.avgs(0, 6)[:, 2]],      # committed steps
+                 "model_failed_points": dg["model_failed_points"], "pcg_solves_at_iteration_cap": dg["pcg_not_converged"],
+                 "pcg_worst_residual_reduction_at_cap": dg["pcg_worst_capped_reduction"], "pcg_rel_tol": 1e-7,
+                 "note": "reference schedule (test/data/custom_dt.txt) and solver settings (NR rel 5e-5 / abs 5e-10, PCG rel 1e-7 / 1000 iterations, identity 'Jacobi'); at this "
+                         "size the linear solves stop at the iteration cap: pcg_worst_residual_reduction_at_cap = |r|/|r0| they reached (Newton converges regardless)"}
+        P_local = L.exa_driver_local_qpts(drv.h)
+    # ---- timed region 1: constitutive passes at the benchmark state --------------------------------------------------------------------
     # untimed passes before the timed region: the --warmup passes of the contract, and at least SETTLE_PASSES in total so that a short
-    # timed region (the driver runs --steps 20) starts at the clock a long one runs at (the first dozens of launches after the prepare
-    # phase read ~4 % slow: 6.95 ms in a 20-pass run against 6.70 ms in a 300-pass one on the round-2 build)
-    settle = max(args.warmup, SETTLE_PASSES)
-    if settle > 0:
-        drv.bench_model(settle)
-    barrier()
-    t0 = time.perf_counter()
-    m = drv.bench_model(args.steps)
-    barrier()
-    t_model = max_over_ranks(time.perf_counter() - t0)
-    kern_ms = max_over_ranks(m["kernel_ms"]) / args.steps
-    nfev = drv.nfev_hist()
+    # timed region (the driver runs --steps 20) starts at the clock a long one runs at; the line's `warmup` is the number that ran
+    if args.solve_steps > 0:
+        t_model, kern_ms, failed, nfev = timed_passes(drv, args.steps)
+    else:
+        t_model, kern_ms, failed, nfev = t_kin, kin_kern_ms, kin_failed, kin_hist
+    m = {"failed": failed}
     value = P_global * args.steps / t_model
-    # ---- timed region 2: PCG iterations -----------------------------------------------------------------------------------
+    # ---- timed region 2: PCG iterations (same state) ----------------------------------------------------------------------------------
     drv.bench_pcg(max(2, args.pcg_iters // 10))   # warm-up
     barrier()
     t0 = time.perf_counter()
@@ -205,36 +263,28 @@ def main():
     t_pcg_wall = max_over_ranks(time.perf_counter() - t0)
     pcg_ms = max_over_ranks(pc["pcg_ms"]); apply_ms = max_over_ranks(pc["apply_ms"]) / args.pcg_iters
     pcg_it_s = pc["iters"] / (pcg_ms * 1e-3)
-    solve = None
-    if args.solve_steps > 0:
-        # real time stepping (Newton + PCG with the reference's tolerances) on a fresh driver: rates of the actual solve
-        drv.close()
-        rng = np.random.default_rng(20240928)
-        quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
-        sched = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "custom_dt.txt")).ravel()[:args.solve_steps]
-        drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=0 if args.assembly.upper() == "PA" else 1, rank=rank, nranks=world, uid=uid, jacobi=args.jacobi, **mk)
-        barrier(); t0 = time.perf_counter()
-        for ti in range(1, args.solve_steps + 1):
-            assert drv.step(ti), f"Newton failed at step {ti}"
-        barrier(); wall = max_over_ranks(time.perf_counter() - t0)
-        tm = drv.timers(); nw, kr, mc = drv.stats()
-        solve = {"steps": args.solve_steps, "wall_s": wall, "newton_iters": [int(x) for x in nw], "krylov_iters": [int(x) for x in kr],
-                 "model_calls": [int(x) for x in mc], "qpt_updates_per_s_in_kernel": 8 * N ** 3 * int(sum(mc)) / (max_over_ranks(tm["model_ms"]) * 1e-3),
-                 "pcg_iters_per_s": tm["krylov_iters"] / (max_over_ranks(tm["krylov_ms"]) * 1e-3),
-                 "avg_stress_zz": [float(x) for x in drv.avgs(0, 6)[:, 2]]}
-        dg = drv.diagnostics()
-        solve.update({"model_failed_points": dg["model_failed_points"], "pcg_solves_at_iteration_cap": dg["pcg_not_converged"],
-                      "pcg_worst_residual_reduction_at_cap": dg["pcg_worst_capped_reduction"], "pcg_rel_tol": 1e-7,
-                      "note": "the reference's settings (1000 PCG iterations, identity 'Jacobi') do not converge the linear solves of this size to rel_tol; "
-                              "pcg_worst_residual_reduction_at_cap = |r|/|r0| the capped solves reached (Newton converges regardless: newton_iters)"})
     if rank == 0:
         ndof_local = L.exa_driver_local_dofs(drv.h)
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench): bytes/qpt x local qpts
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench): bytes/qpt x local qpts.  The counter
+        # files carry the kernel build id of the library they were measured on (scripts/profile_round4.sh); a file of another build is refused
+        kid = L.exa_kernel_build_id().decode()
         traffic = {}
+
+        def profile_json(suffix):
+            """newest profiles/*<suffix> whose kernel_build_id is this library's; (None, reason) otherwise"""
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix))
+            for f in reversed(cands):
+                try:
+                    d = json.load(open(os.path.join(ROOT, "profiles", f)))
+                except Exception:
+                    continue
+                if d.get("kernel_build_id") == kid:
+                    return d, "profiles/" + f
+            return None, (f"no profiles/*{suffix} of kernel build {kid} (newest: {cands[-1]})" if cands else f"no profiles/*{suffix}")
         try:
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-            if cands:
-                raw = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["bytes_per_qpt"]
+            tj, tsrc = profile_json("_pmc_traffic.json")
+            if tj is not None:
+                raw = tj["bytes_per_qpt"]
                 # per kernel either one number (measured on the fcc_voce instantiation) or {model: bytes}: never quote one model's counters for another
                 for k, v in raw.items():
                     if isinstance(v, dict):
@@ -242,14 +292,14 @@ def main():
                             traffic[k] = v[args.model]
                     elif args.model == "fcc_voce" or k != "k_model_setup":
                         traffic[k] = v
-                traffic["_file"] = "profiles/" + cands[-1]
-        except Exception:
-            traffic = {}
+            traffic["_file"] = tsrc
+        except Exception as e:
+            traffic = {"_file": f"unreadable: {e}"}
         flops = None; valu_per_wave = None
         try:
-            cf = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_flops.json"))
-            if cf:
-                pl = json.load(open(os.path.join(ROOT, "profiles", cf[-1])))["k_model_setup"]["plastic"]
+            fj, _ = profile_json("_pmc_flops.json")
+            if fj is not None:
+                pl = fj["k_model_setup"]["plastic"]
                 flops = pl["flop_per_qpt"]; valu_per_wave = pl["valu_insts_per_wave"]
         except Exception:
             flops = None
@@ -263,21 +313,22 @@ def main():
         iter_bytes = APPLY_BYTES_PER_QPT * P_local + PCG_VEC_BYTES_PER_DOF * ndof_local
         out = {
             "metric": "quadrature-point constitutive updates/s + Newton-PCG iter/s, 128^3 hex RVE",
-            "value": value, "unit": "qpt-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "qpt-updates/s", "n_gpus": world, "steps": args.steps, "warmup": settle, "warmup_requested": args.warmup,
             "ms_per_step": t_model / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{N}^3 hex RVE p=1, {MODEL_NAMES[args.model]} (ExaCMech evptn), plastic regime; "
                                    f"{'partial' if args.assembly.upper() == 'PA' else 'element'}-assembly PCG", "elements": N ** 3,
+                       "state": (f"real Newton/PCG solve of the reference schedule, {args.solve_steps} steps; timed passes = the converged (last) residual evaluation of step {args.solve_steps}"
+                                 if args.solve_steps > 0 else "kinematically driven (10 prescribed-velocity passes)"),
                        "qpts": P_global, "decomposition": f"{world} block(s)"},
             "pcg_iters_per_s": pcg_it_s, "pcg_iters": pc["iters"], "pcg_ms_per_iter": pcg_ms / max(pc["iters"], 1),
             "pcg_wall_s": t_pcg_wall, "nonconverged_points": m["failed"],
-            "local_solver_evals": {"mean": float((nfev * np.arange(64)).sum() / max(nfev.sum(), 1)), "max": int(np.nonzero(nfev)[0].max()) if nfev.any() else 0,
-                                   "hist": {str(i): int(c) for i, c in enumerate(nfev) if c}, "note": "residual/Jacobian evaluations of the 8-unknown point solve per quadrature point (rank 0), last timed pass"},
+            "local_solver_evals": dict(hist_dict(nfev), note="residual/Jacobian evaluations of the 8-unknown point solve per quadrature point (rank 0), last timed pass"),
             "elastic_regime": elastic,
-            "prepare_passes": {"passes": len(PREP_DTS), "wall_s": prep_s, "note": "the 10 kinematic passes through the elastic-plastic transition that bring the RVE to the benchmark state"},
+            "kinematic_state": kinematic,
             "roofline": {"kernel": f"k_model_setup<{'KM-DD' if 'kmdd' in args.model else 'Voce'}> (fused node gather + grad_calc + ExaCMech update + tangent)", "bound": "hbm",
                          "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic["k_model_setup"] * P_local if "k_model_setup" in traffic else None, "traffic_source": traffic.get("_file"),
+                         "traffic": traffic["k_model_setup"] * P_local if "k_model_setup" in traffic else None, "traffic_source": traffic.get("_file"), "kernel_build_id": kid,
                          "bytes_per_qpt": MODEL_BYTES_PER_QPT, "avg_kernel_ms": kern_ms,
                          "bytes_written_per_qpt_note": ("this launch writes the 26-number gradient record instead of the 36 tangent entries (848 B/qpt moved; "
                                                         "AssembleGradPA fused in); frac stays priced at SURVEY 8(d)'s 928 B/qpt") if records else None,

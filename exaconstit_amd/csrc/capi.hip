@@ -132,7 +132,7 @@ int exa_model_setup_lvec(exa_ctx* ctx, double dt, const double* x_lvec, const do
 
 int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* x_lvec, const double* v_lvec, const double* stress0, const double* state0,
                                  double* stress1, double* state1, double* J_out, exa_stream s) {
-   if (!ctx || !x_lvec || !v_lvec || !stress0 || !state0 || !stress1 || !state1 || !J_out) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: null pointer");
+   if (!ctx || !x_lvec || !v_lvec || !stress0 || !state0 || !stress1 || !state1) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: null pointer");   // J_out may be null
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec_records: call exa_set_connectivity first");
    if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: dt must be positive");
    if (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL || !ctx->qblk || ctx->tangent_form != EXA_TANGENT_DEV5_BULK ||
@@ -426,8 +426,10 @@ int exa_grad_apply_lvec(exa_ctx* ctx, const double* x, double* y, const uint8_t*
 }
 
 int exa_residual_lvec(exa_ctx* ctx, const double* J, const double* stress1, double* y, exa_stream s) {
-   if (!ctx || !J || !stress1 || !y) return fail(ctx, EXA_ERR_ARG, "exa_residual_lvec: null pointer");
+   if (!ctx || !stress1 || !y) return fail(ctx, EXA_ERR_ARG, "exa_residual_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_residual_lvec: connectivity not set");
+   if (!J && !(ctx->p == 1 && ctx->cfg.integ == EXA_INTEG_FULL && ctx->coords_lvec))
+      return fail(ctx, EXA_ERR_ARG, "exa_residual_lvec: a null Jacobian field needs p = 1 full integration and nodal coordinates (exa_grad_set_coords)");
    if (ctx->det && ctx->p == 2) return fail(ctx, EXA_ERR_UNSUPPORTED, "deterministic mode: the fused p = 2 residual scatters with atomics; use exa_residual_setup/apply + exa_restrict_transpose_add");
    if (ctx->p == 2) {
       if (ctx->cfg.integ == EXA_INTEG_BBAR && !ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * PA_BLK * (size_t)((ctx->E + PA_BLK - 1) / PA_BLK)));

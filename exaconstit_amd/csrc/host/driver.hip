@@ -325,6 +325,7 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    // true Jacobi needs the 46-double records for the diagonal and takes that route as well (SetPrecond).
    records_setup_ = fast_p1_ && compact_tangent_ && fused_setup_ && !det && !env_is_off("EXA_TANGENT_RECORDS") &&
                     !(std::getenv("EXA_QLAYOUT") && std::string(std::getenv("EXA_QLAYOUT")) == "aos");
+   geo_resid_ = !(std::getenv("EXA_JAC_FIELD") && std::string(std::getenv("EXA_JAC_FIELD")) == "on");   // A/B switch: the record route writes and reads the Jacobian field as before
    if (det) { abi_check(ctx_, exa_set_deterministic(ctx_, 1), "exa_set_deterministic"); comm_.deterministic = true; }
    abi_check(ctx_, exa_set_newton_caps(ctx_, newton_cap_, newton_cap2_, tail_resume_ ? 1 : 0), "exa_set_newton_caps");   // A/B switch for measurements; the fused launch is the product path
    // internal quadrature-function layout: element-blocked on the fused p = 1 and p = 2 paths (EXA_QLAYOUT=aos switches back for A/B runs)
@@ -443,14 +444,17 @@ void NonlinearMechOperator::Setup(const double* k) {
    // per rank the launch is 0.6 ms: an event wait plus a status read-back per evaluation (round 2) was ~10 % of it.
    EvPair& ev = NextModelTimer();
    EXA_HC(hipEventRecord(ev.a, stream_));
-   if (use_records()) model_->ModelSetupLVecRecords(x_cur.p, k, el_jac.p, stream_);   // ... and AssembleGradPA: the launch writes the action's point records
-   else if (fused_setup_) { ensure_mat_grad(); model_->ModelSetupLVec(x_cur.p, k, el_jac.p, stream_); }   // L->E of x and v + SetupJacobianTerms inside the constitutive launch
+   // ... and AssembleGradPA: the launch writes the action's point records.  With the L-vector residual both integrator actions take the geometry
+   // from x_cur, so no Jacobian field is written (72 of 848 B per point); UpdateModel refreshes it once per step for the volume averages
+   if (use_records()) { model_->ModelSetupLVecRecords(x_cur.p, k, geo_resid() ? nullptr : el_jac.p, stream_); jac_stale_ = geo_resid(); }
+   else if (fused_setup_) { ensure_mat_grad(); model_->ModelSetupLVec(x_cur.p, k, el_jac.p, stream_); jac_stale_ = false; }   // L->E of x and v + SetupJacobianTerms inside the constitutive launch
    else {
       ensure_mat_grad();
       abi_check(ctx_, exa_restrict(ctx_, x_cur.p, el_x.p, stream_), "exa_restrict");
       abi_check(ctx_, exa_jacobians(ctx_, el_x.p, el_jac.p, stream_), "exa_jacobians");   // SetupJacobianTerms
       abi_check(ctx_, exa_restrict(ctx_, k, el_v.p, stream_), "exa_restrict");
       model_->ModelSetup(el_jac.p, el_v.p, stream_);
+      jac_stale_ = false;
    }
    EXA_HC(hipEventRecord(ev.b, stream_)); ev.pending = true;
    timers.qpt_updates += (int64_t)E_ * npe_; model_calls++;
@@ -486,7 +490,10 @@ void NonlinearMechOperator::ReadModelStatus() {
 
 void NonlinearMechOperator::ResidualAction(double* y) {
    EXA_HC(hipMemsetAsync(y, 0, sizeof(double) * nd_, stream_));
-   if (lvec_resid_) abi_check(ctx_, exa_residual_lvec(ctx_, el_jac.p, stress1.p, y, stream_), "exa_residual_lvec");
+   if (lvec_resid_ && jac_stale_) {   // geometry from the nodes of the configuration the stress belongs to
+      abi_check(ctx_, exa_grad_set_coords(ctx_, x_cur.p), "exa_grad_set_coords");
+      abi_check(ctx_, exa_residual_lvec(ctx_, nullptr, stress1.p, y, stream_), "exa_residual_lvec");
+   } else if (lvec_resid_) abi_check(ctx_, exa_residual_lvec(ctx_, el_jac.p, stress1.p, y, stream_), "exa_residual_lvec");
    else {   // Hform->Setup() = AssemblePA, Hform->Mult = L->E, AddMultPA, E->L
       abi_check(ctx_, exa_residual_setup(ctx_, el_jac.p, stress1.p, stream_), "exa_residual_setup");
       el_y_.zero(stream_);
@@ -498,6 +505,14 @@ void NonlinearMechOperator::ResidualAction(double* y) {
 }
 
 void NonlinearMechOperator::Mult(const double* k, double* y) { Setup<true>(k); ResidualAction(y); }
+
+// Jacobians of the current configuration when the constitutive launch did not write them (record route): L->E of x_cur + SetupJacobianTerms
+void NonlinearMechOperator::RefreshJacobians() {
+   if (!jac_stale_) return;
+   abi_check(ctx_, exa_restrict(ctx_, x_cur.p, el_x.p, stream_), "exa_restrict");
+   abi_check(ctx_, exa_jacobians(ctx_, el_x.p, el_jac.p, stream_), "exa_jacobians");
+   jac_stale_ = false;
+}
 
 void NonlinearMechOperator::GetGradient() {
    if (use_records()) {   // the constitutive launch of the last residual evaluation wrote the records of this state; the action recomputes the geometry from x_cur
@@ -939,6 +954,7 @@ void SystemDriver::UpdateModel() {
    NonlinearMechOperator& op = *oper_;
    hipStream_t s = op.stream();
    exa_ctx* ctx = op.GetModel()->ctx();
+   op.RefreshJacobians();   // the averages weight with det J of the converged configuration (reference: the determinants cached by the last Setup)
    op.UpdateModel();
    auto vol_avg = [&](const double* qf, int vdim, bool normalise, double* out) {
       std::vector<double> h(vdim + 1);
@@ -974,7 +990,7 @@ void SystemDriver::UpdateModel() {
 }
 
 // one pass of the reference's time-step loop body (src/mechanics_driver.cpp:837-907)
-bool SystemDriver::Step(int ti) {
+bool SystemDriver::Step(int ti, bool commit) {
    NonlinearMechOperator& op = *oper_;
    hipStream_t s = op.stream(); const int64_t nd = op.Height();
    double dt_real;
@@ -999,6 +1015,7 @@ bool SystemDriver::Step(int ti) {
    op.timers.t_solve_ms += ms;
    step_wall_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count());
    if (!ok) return false;
+   if (!commit) return true;   // the converged state stays the END-of-step state: the next constitutive pass repeats this step's last residual evaluation
    UpdateModel();
    op.SwapCoords();
    steps_done++;

@@ -109,6 +109,7 @@ class NonlinearMechOperator {
    // reference src/mechanics_operator.cpp:446-483
    void GetUpdateBCsAction(const double* k, const double* x, double* y);
    void ResidualAction(double* y);
+   void RefreshJacobians();                // el_jac of x_cur when the record route left it unwritten (volume averages)
    void UpdateModel();                     // swap begin/end state, x_beg <- x_cur
    void SwapCoords();
    ExaCMechModel* GetModel() { return model_.get(); }
@@ -141,6 +142,8 @@ class NonlinearMechOperator {
    int nn_, nd_, E_, npe_ = 8; double dt_ = 1.0;
    bool records_setup_ = false;   // gradient records written by the constitutive launch (p = 1 fast path, identity preconditioner)
    bool use_records() const { return records_setup_ && precond == Precond::IDENTITY; }
+   bool geo_resid_ = true, jac_stale_ = false;   // record route + L-vector residual: no Jacobian field is written, both actions recompute the geometry (EXA_JAC_FIELD=on keeps it)
+   bool geo_resid() const { return geo_resid_ && lvec_resid_; }
    void ensure_mat_grad();
    bool overlap_ = false; int nblk_bdr_ = 0;   // halo exchange overlapped with the interior element blocks (several ranks, atomic p = 1 record action)
    bool fast_p1_ = true, lvec_grad_ = true, fused_setup_ = true; bool lvec_resid_ = false; bool compact_tangent_ = false;
@@ -160,7 +163,8 @@ class SystemDriver {
    bool Solve(double* x);
    void UpdateModel();
    // one time step of the reference's loop (src/mechanics_driver.cpp:837-907); returns false if Newton failed
-   bool Step(int ti);
+   // commit = false (bench): solve the step but leave begin-of-step state, coordinates and outputs untouched
+   bool Step(int ti, bool commit = true);
    int RunAll();
    bool NewtonSolve(double* x, SolverStats& st);
    int CGSolve(const double* b, double* x);   // device PCG, returns iterations

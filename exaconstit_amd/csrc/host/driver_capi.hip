@@ -104,6 +104,11 @@ int exa_driver_step(exa_driver* d, int ti, char* err, int errlen) {
    try { return d->sd->Step(ti) ? 1 : 0; } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }
 
+// the step's Newton/PCG solve without the end-of-step update (bench: the timed constitutive passes that follow repeat the step's converged launch)
+int exa_driver_step_nocommit(exa_driver* d, int ti, char* err, int errlen) {
+   try { return d->sd->Step(ti, false) ? 1 : 0; } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
 int exa_driver_run(exa_driver* d, char* err, int errlen) {
    try { return d->sd->RunAll(); } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1000000; }
 }
@@ -140,13 +145,16 @@ void exa_driver_get_diagnostics(exa_driver* d, int64_t* out) {
 // out[0] = sqrt((r, M^-1 r) / (r0, M^-1 r0)) reached by the last PCG solve, out[1] = the worst value among the solves that stopped at max_iter
 void exa_driver_get_pcg_reduction(exa_driver* d, double* out2) { out2[0] = d->sd->last_cg_reduction; out2[1] = d->sd->worst_capped_cg_reduction; }
 
-int exa_driver_nfev_hist(exa_driver* d, int* hist64, char* err, int errlen) {
+// which: 1 = end-of-step state of the last constitutive launch, 0 = begin-of-step state (after a completed step: that step's converged launch)
+int exa_driver_nfev_hist_of(exa_driver* d, int which, int* hist64, char* err, int errlen) {
    try {
       NonlinearMechOperator& op = d->sd->oper();
-      if (exa_model_nfev_hist(op.GetModel()->ctx(), op.matVars1.p, hist64, op.stream()) != EXA_OK) throw std::runtime_error(exa_last_error(op.GetModel()->ctx()));
+      const double* st = which == 0 ? op.matVars0.p : op.matVars1.p;
+      if (exa_model_nfev_hist(op.GetModel()->ctx(), st, hist64, op.stream()) != EXA_OK) throw std::runtime_error(exa_last_error(op.GetModel()->ctx()));
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }
+int exa_driver_nfev_hist(exa_driver* d, int* hist64, char* err, int errlen) { return exa_driver_nfev_hist_of(d, 1, hist64, err, errlen); }
 
 int exa_driver_get_qf_component(exa_driver* d, int which, int comp, double* out, char* err, int errlen) {
    try {

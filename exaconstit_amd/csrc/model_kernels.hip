@@ -157,9 +157,11 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
          J12 += x0 * g1; J22 += x1 * g1; J32 += x2 * g1;
          J13 += x0 * g2; J23 += x1 * g2; J33 += x2 * g2;
       }
-      double* Jo = Jio + vJ.base;
-      ecmdev::stg(Jo, J11); ecmdev::stg(Jo + QS, J21); ecmdev::stg(Jo + 2 * QS, J31); ecmdev::stg(Jo + 3 * QS, J12); ecmdev::stg(Jo + 4 * QS, J22); ecmdev::stg(Jo + 5 * QS, J32);
-      ecmdev::stg(Jo + 6 * QS, J13); ecmdev::stg(Jo + 7 * QS, J23); ecmdev::stg(Jo + 8 * QS, J33);
+      if (Jio) {   // optional (uniform): the driver's p = 1 record route needs no Jacobian field - its integrator kernels take the geometry from the nodes
+         double* Jo = Jio + vJ.base;
+         ecmdev::stg(Jo, J11); ecmdev::stg(Jo + QS, J21); ecmdev::stg(Jo + 2 * QS, J31); ecmdev::stg(Jo + 3 * QS, J12); ecmdev::stg(Jo + 4 * QS, J22); ecmdev::stg(Jo + 5 * QS, J32);
+         ecmdev::stg(Jo + 6 * QS, J13); ecmdev::stg(Jo + 7 * QS, J23); ecmdev::stg(Jo + 8 * QS, J33);
+      }
    } else {
       const double* Jq = Jio + vJ.base;
       J11 = Jq[0]; J21 = Jq[QS]; J31 = Jq[2 * QS]; J12 = Jq[3 * QS]; J22 = Jq[4 * QS]; J32 = Jq[5 * QS]; J13 = Jq[6 * QS]; J23 = Jq[7 * QS]; J33 = Jq[8 * QS];

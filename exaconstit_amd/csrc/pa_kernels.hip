@@ -352,11 +352,24 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_diag_p1(const int E, const doub
 }
 
 // fused AssemblePA + AddMultPA + scatter-add for p = 1
-template <bool LVEC, bool QB>
+// GEO: no Jacobian field - J(i,j) = sum_a x_a,i dN_a/dxi_j at the 8 points from the element's nodal coordinates (gathered once through the
+// connectivity the scatter needs anyway): 72 B per point less to read, and the constitutive launch need not write them (exa_residual_lvec)
+template <bool LVEC, bool QB, bool GEO = false>
 __global__ __launch_bounds__(PA_BLK) void k_residual_p1(const int E, const double* __restrict__ W, const double* __restrict__ J, const double* __restrict__ S,
-                                                        double* __restrict__ y, const int32_t* __restrict__ conn, const int nnodes, double* __restrict__ ev = nullptr) {
+                                                        double* __restrict__ y, const int32_t* __restrict__ conn, const int nnodes, double* __restrict__ ev = nullptr,
+                                                        const double* __restrict__ coords = nullptr) {
    const int64_t e = (int64_t)blockIdx.x * PA_BLK + threadIdx.x;
    if (e >= E) return;
+   static_assert(!GEO || LVEC, "geometry from the nodes needs the connectivity");
+   double XC[GEO ? 3 : 1][8];
+   if (GEO) {
+#pragma unroll
+      for (int a = 0; a < 8; a++) {
+         const int g = conn[a + 8 * e];
+#pragma unroll
+         for (int c = 0; c < 3; c++) XC[c][a] = coords[g + (int64_t)nnodes * c];
+      }
+   }
    double Y[3][8];
 #pragma unroll
    for (int c = 0; c < 3; c++)
@@ -365,7 +378,15 @@ __global__ __launch_bounds__(PA_BLK) void k_residual_p1(const int E, const doubl
 #pragma unroll
    for (int q = 0; q < 8; q++) {
       const QView vj = qview<QB>(9, 8, e, q), vs = qview<QB>(6, 8, e, q);
-      double adj[9], detJ; adj_det(J + vj.base, adj, detJ, vj.stride);
+      double adj[9], detJ;
+      if (GEO) {
+         double Jl[9];
+#pragma unroll
+         for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) { double t = 0; for (int a = 0; a < 8; a++) t += G1(a, j, q) * XC[i][a]; Jl[i + 3 * j] = t; }
+         adj_det(Jl, adj, detJ);
+      } else adj_det(J + vj.base, adj, detJ, vj.stride);
       const double* sp = S + vs.base;
       const double s[6] = { sp[0], sp[vs.stride], sp[2 * vs.stride], sp[3 * vs.stride], sp[4 * vs.stride], sp[5 * vs.stride] };
       const double w = W[q];
@@ -598,7 +619,10 @@ int exa_launch_residual_p1(exa_ctx* ctx, const double* J, const double* S, doubl
    const unsigned nb = nblk(ctx->E, PA_BLK);
    double* ev = nullptr;
    if (lvec && ctx->det) { if (int rc = exa_det_prepare(ctx)) return rc; ev = ctx->ev_det; }
-   if (lvec && ctx->qblk) hipLaunchKernelGGL((k_residual_p1<true, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes, ev);
+   if (lvec && J == nullptr) {   // geometry from the nodal coordinates registered with exa_grad_set_coords
+      if (ctx->qblk) hipLaunchKernelGGL((k_residual_p1<true, true, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes, ev, ctx->coords_lvec);
+      else hipLaunchKernelGGL((k_residual_p1<true, false, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes, ev, ctx->coords_lvec);
+   } else if (lvec && ctx->qblk) hipLaunchKernelGGL((k_residual_p1<true, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes, ev);
    else if (lvec) hipLaunchKernelGGL((k_residual_p1<true, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes, ev);
    else if (ctx->qblk) hipLaunchKernelGGL((k_residual_p1<false, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);
    else hipLaunchKernelGGL((k_residual_p1<false, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->W_dev, J, S, y, ctx->conn, ctx->nnodes);

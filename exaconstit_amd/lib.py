@@ -47,6 +47,8 @@ def _sig(name, restype, *argtypes):
 exa_create = _sig("exa_create", C.c_void_p, C.POINTER(ExaConfig), C.POINTER(C.c_int))
 exa_destroy = _sig("exa_destroy", None, C.c_void_p)
 exa_last_error = _sig("exa_last_error", C.c_char_p, C.c_void_p)
+exa_build_id = _sig("exa_build_id", C.c_char_p)
+exa_kernel_build_id = _sig("exa_kernel_build_id", C.c_char_p)
 exa_num_state_vars = _sig("exa_num_state_vars", C.c_int, C.c_void_p)
 exa_nodes_per_elem = _sig("exa_nodes_per_elem", C.c_int, C.c_void_p)
 exa_qpts_per_elem = _sig("exa_qpts_per_elem", C.c_int, C.c_void_p)
@@ -152,6 +154,7 @@ exa_driver_num_steps = _sig("exa_driver_num_steps", C.c_int, C.c_void_p)
 exa_driver_local_qpts = _sig("exa_driver_local_qpts", C.c_int64, C.c_void_p)
 exa_driver_local_dofs = _sig("exa_driver_local_dofs", C.c_int64, C.c_void_p)
 exa_driver_step = _sig("exa_driver_step", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_int)
+exa_driver_step_nocommit = _sig("exa_driver_step_nocommit", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_int)
 exa_driver_run = _sig("exa_driver_run", C.c_int, C.c_void_p, C.c_char_p, C.c_int)
 exa_driver_get_avgs = _sig("exa_driver_get_avgs", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int)
 exa_driver_get_stats = _sig("exa_driver_get_stats", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
@@ -159,6 +162,7 @@ exa_driver_get_timers = _sig("exa_driver_get_timers", None, C.c_void_p, C.POINTE
 exa_driver_reset_timers = _sig("exa_driver_reset_timers", None, C.c_void_p)
 exa_driver_nfev_hist = _sig("exa_driver_nfev_hist", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_int)
 exa_driver_get_qf_component = _sig("exa_driver_get_qf_component", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int)
+exa_driver_nfev_hist_of = _sig("exa_driver_nfev_hist_of", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_int)
 exa_driver_get_diagnostics = _sig("exa_driver_get_diagnostics", None, C.c_void_p, C.POINTER(C.c_int64))
 exa_rccl_microbench = _sig("exa_rccl_microbench", C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_bootstrap_env = _sig("exa_bootstrap_env", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
@@ -210,8 +214,8 @@ class Driver:
             raise RuntimeError(self._err.value.decode())
         return rc
 
-    def step(self, ti):
-        rc = exa_driver_step(self.h, ti, self._err, 512)
+    def step(self, ti, commit=True):
+        rc = (exa_driver_step if commit else exa_driver_step_nocommit)(self.h, ti, self._err, 512)
         if rc < 0:
             raise RuntimeError(self._err.value.decode())
         return rc == 1
@@ -256,12 +260,16 @@ class Driver:
         dts = np.ascontiguousarray(dts, dtype=np.float64)
         self._chk(exa_driver_bench_prepare(self.h, len(dts) if advance else 0, dts.ctypes.data_as(C.POINTER(C.c_double)), perturb, self._err, 512))
 
-    def nfev_hist(self):
-        """Histogram (64 bins) of the local-solver evaluation counts of the last constitutive launch."""
+    def nfev_hist(self, which=1):
+        """Histogram (64 bins) of the local-solver evaluation counts of the last constitutive launch (which = 1: end-of-step state) or,
+        after a completed step, of the launch that step converged with (which = 0: begin-of-step state)."""
         import numpy as np
         h = np.zeros(64, dtype=np.int32)
-        self._chk(exa_driver_nfev_hist(self.h, h.ctypes.data_as(C.POINTER(C.c_int)), self._err, 512))
+        self._chk(exa_driver_nfev_hist_of(self.h, which, h.ctypes.data_as(C.POINTER(C.c_int)), self._err, 512))
         return h
+
+    def reset_timers(self):
+        exa_driver_reset_timers(self.h)
 
     def qf_component(self, which, comp):
         """One component of a quadrature function ([element][point]); which: 0/1 begin/end state, 2/3 begin/end stress."""

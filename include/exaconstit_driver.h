@@ -52,6 +52,8 @@ int exa_driver_num_steps(exa_driver* d);
 int64_t exa_driver_local_qpts(exa_driver* d);
 int64_t exa_driver_local_dofs(exa_driver* d);
 int exa_driver_step(exa_driver* d, int ti, char* err, int errlen);
+/* solve step ti but do not commit it (no begin/end swap, no coordinate update, no output row): the state bench.py times its passes on */
+int exa_driver_step_nocommit(exa_driver* d, int ti, char* err, int errlen);
 int exa_driver_run(exa_driver* d, char* err, int errlen);
 int exa_driver_get_avgs(exa_driver* d, int which, double* out, int maxrows);
 int exa_driver_get_stats(exa_driver* d, int* newton, int* krylov, int* model_calls, int maxrows);
@@ -66,6 +68,8 @@ void exa_driver_get_diagnostics(exa_driver* d, int64_t* out4);
 void exa_driver_get_pcg_reduction(exa_driver* d, double* out2);
 /* 64-bin histogram of the local-solver evaluation counts (ExaCMech's nFEval state variable) of the last constitutive launch */
 int exa_driver_nfev_hist(exa_driver* d, int* hist64, char* err, int errlen);
+/* the same of the begin-of-step state (which = 0: after a completed step, the launch that step converged with) or the end-of-step state (1) */
+int exa_driver_nfev_hist_of(exa_driver* d, int which, int* hist64, char* err, int errlen);
 /* one component of a quadrature function of the operator, de-blocked on the host: which = 0 begin-of-step state, 1 end-of-step state (28),
  * 2 begin stress, 3 end stress (6); out receives E * Q doubles ordered [element][point] (diagnostics: nFEval maps, parity tools) */
 int exa_driver_get_qf_component(exa_driver* d, int which, int comp, double* out, char* err, int errlen);

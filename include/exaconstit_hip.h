@@ -53,6 +53,8 @@ typedef struct {
 exa_ctx* exa_create(const exa_config* cfg, int* err);          /* ECMechXtalModel ctor, src/mechanics_ecmech.hpp:126-262 */
 void     exa_destroy(exa_ctx* ctx);
 const char* exa_last_error(const exa_ctx* ctx);                /* MFEM_ABORT text equivalent */
+const char* exa_build_id(void);                                /* 12 hex digits: hash of the library's sources at build time */
+const char* exa_kernel_build_id(void);                         /* ... of the device code and its compile flags alone: stamped into the counter files under profiles/ */
 int exa_num_state_vars(const exa_ctx* ctx);                    /* numHist + ne + 1 = 28, src/mechanics_ecmech.hpp:136-141 */
 int exa_nodes_per_elem(const exa_ctx* ctx);
 int exa_qpts_per_elem(const exa_ctx* ctx);
@@ -95,7 +97,10 @@ int exa_model_setup_lvec(exa_ctx* ctx, double dt, const double* coords_lvec_dev 
  * separate exa_grad_setup pass exists on this path.  After it exa_grad_apply_lvec is valid once exa_grad_set_coords has named the
  * coordinates (the same coords_lvec).  Preconditions: p = 1 full integration, EXA_QLAYOUT_EB64, exa_set_connectivity,
  * exa_set_tangent_form(EXA_TANGENT_DEV5_BULK), partial assembly or matrix-free element assembly.  The entry points that read the
- * full 46-double records (exa_grad_apply on E-vectors, exa_grad_diagonal, exa_grad_get_ea) still need exa_grad_setup. */
+ * full 46-double records (exa_grad_apply on E-vectors, exa_grad_diagonal, exa_grad_get_ea) still need exa_grad_setup.
+ * jacobian_out_dev may be NULL: the Jacobians are then not written at all (72 B per point less traffic) - on this route both integrator
+ * actions can take the geometry from the nodal coordinates (exa_grad_set_coords + exa_residual_lvec with a NULL Jacobian field); a
+ * caller that wants volume averages afterwards fills a Jacobian field once with exa_restrict + exa_jacobians. */
 int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* coords_lvec_dev, const double* vel_lvec_dev,
                                  const double* stress0_dev, const double* state0_dev,
                                  double* stress1_dev, double* state1_dev, double* jacobian_out_dev, exa_stream s);
@@ -191,7 +196,9 @@ int exa_set_ea_matrix_free(exa_ctx* ctx, int on);
  * are the reproducible route (what the stand-alone driver then takes).  Default off. */
 int exa_set_deterministic(exa_ctx* ctx, int on);
 /* fused AssemblePA + AddMultPA + E->L: y_L += B^T sigma (p = 1 full integration; p = 2 full integration and B-bar, where the
- * element-average gradients are refreshed from the Jacobians first: ICExaNLFIntegrator::AssemblePA + AddMultPA) */
+ * element-average gradients are refreshed from the Jacobians first: ICExaNLFIntegrator::AssemblePA + AddMultPA).
+ * p = 1 full integration: jacobian_dev may be NULL when exa_grad_set_coords has named the nodal coordinates of the configuration -
+ * adj(J) is then recomputed from them (the scatter gathers the connectivity anyway) instead of read from a Jacobian field. */
 int exa_residual_lvec(exa_ctx* ctx, const double* jacobian_dev, const double* stress1_dev, double* y_lvec_dev, exa_stream s);
 /* volume average  sum_q W detJ val / sum_q W detJ  (src/mechanics_kernels.hpp:19-134); out_host[vdim] (+ volume in out_host[vdim]).
  * Synchronises the stream. */
