@@ -66,6 +66,7 @@ enum { KIN_VOCE = 0, KIN_VOCE_NL = 1, KIN_KMBALD = 2,
                               // its 12 powers in other registers, and the merge costs ~100 v_mov / v_and per evaluation (9 % of the launch's VALU work)
 constexpr int kin_base(int k) { return k & 3; }
 constexpr bool kin_pq1(int k) { return (k & KIN_PQ1) != 0; }
+constexpr bool kin_sc_exp(int k) { return kin_base(k) == KIN_KMBALD_GA; }   // exp_n coefficients through scalar registers (see exp_n)
 constexpr int kin_xn_ct(int k) { return (k & KIN_XN49) ? 49 : 0; }   // compile-time power-law exponent (0: run-time choice)
 constexpr bool kin_is_km(int k) { return kin_base(k) == KIN_KMBALD || kin_base(k) == KIN_KMBALD_GA; }
 
@@ -150,17 +151,61 @@ ECM_DI double frcp(double x) {
 #ifndef ECM_KM_EXP
 #define ECM_KM_EXP 1   // A/B switch: 0 = library exp(), 1 = this routine, 2 = this routine, interleaving left to the compiler
 #endif
-template <int N, bool FAST>   // FAST = false: library routine (the general instantiations, whose register allocation the routine upsets)
+// a double constant that is materialised in a scalar register pair where it is used.  Left alone, the compiler hoists the polynomial
+// coefficients of exp_n / log_near1 out of the Newton loop INTO VECTOR REGISTERS (v_fmac wants its addend in the destination register) - 28
+// VGPRs for the exp coefficients alone, the logarithm's went to scratch and were re-loaded, one dependent round trip each, inside the
+// slip-system loop of the Kocks-Mecking kernels.  The volatile asm pins the materialisation (two s_mov, no VALU work) to the point of use.
+#ifndef ECM_SCONST
+#define ECM_SCONST 1
+#endif
+ECM_DI double sconst(double c) {
+#if ECM_SCONST
+   asm volatile("" : "+s"(c));
+#endif
+   return c;
+}
+#ifndef ECM_SCONST_EXP
+#define ECM_SCONST_EXP 1   // ... in exp_n (A/B switch)
+#endif
+template <bool SC> ECM_DI double sconst_e(double c) { return (ECM_SCONST_EXP && SC) ? sconst(c) : c; }
+// sin and cos of a moderate angle (rotation increments: |x| below ~1e5): Cody-Waite reduction by pi/2 in two parts and the fdlibm kernel
+// polynomials on |r| <= pi/4, |error| ~ 1 ulp.  Takes the place of the library sincos in the large-angle branches of the exponential map,
+// which are rarely taken but whose 12 polynomial coefficients the compiler kept in vector registers - or in scratch - across the whole
+// Newton loop (see sconst)
+ECM_DI void sincos_s(const double x, double& sn, double& cs) {
+   const double k = rint(x * sconst(6.36619772367581382433e-01));
+   double r = fma(-k, sconst(1.57079632673412561417e+00), x);
+   r = fma(-k, sconst(6.07710050650619224932e-11), r);
+   const double z = r * r;
+   double ps = sconst(1.58969099521155010221e-10);
+   ps = fma(ps, z, sconst(-2.50507602534068634195e-08)); ps = fma(ps, z, sconst(2.75573137070700676789e-06));
+   ps = fma(ps, z, sconst(-1.98412698298579493134e-04)); ps = fma(ps, z, sconst(8.33333333332248946124e-03));
+   ps = fma(ps, z, sconst(-1.66666666666666324348e-01));
+   const double s0 = fma(r * z, ps, r);
+   double pc = sconst(-1.13596475577881948265e-11);
+   pc = fma(pc, z, sconst(2.08757232129817482790e-09)); pc = fma(pc, z, sconst(-2.75573143513906633035e-07));
+   pc = fma(pc, z, sconst(2.48015872894767294178e-05)); pc = fma(pc, z, sconst(-1.38888888888741095749e-03));
+   pc = fma(pc, z, sconst(4.16666666666666019037e-02));
+   const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+   const int q = (int)k & 3;
+   const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+   sn = (q & 2) ? -sa : sa;
+   cs = (q == 1 || q == 2) ? -ca : ca;
+}
+
+// SC: coefficients through sconst.  Measured at 128^3: athermal-threshold (BCC) kernel 7.95 -> 7.61 ms with, batched FCC kernel 16.8 -> 18.2 ms (36
+// exponentials per evaluation there: the 28 scalar moves per value get in the way), so the kernel kind decides (kin_sc_exp)
+template <int N, bool FAST, bool SC = true>   // FAST = false: library routine (the general instantiations, whose register allocation the routine upsets)
 ECM_DI void exp_n(double v[N]) {
    if constexpr (ECM_KM_EXP != 0 && FAST) {
    constexpr double tab[14] = { 1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
       1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0 };
 #pragma unroll
    for (int a = 0; a < N; a++) {
-      const double x = fmin(fmax(v[a], -800.0), 720.0); const double n = rint(x * tab[0]); double r = fma(n, tab[1], x); r = fma(n, tab[2], r);
-      double p = fma(tab[3], r, tab[4]);
+      const double x = fmin(fmax(v[a], -800.0), 720.0); const double n = rint(x * sconst_e<SC>(tab[0])); double r = fma(n, sconst_e<SC>(tab[1]), x); r = fma(n, sconst_e<SC>(tab[2]), r);
+      double p = fma(sconst_e<SC>(tab[3]), r, sconst_e<SC>(tab[4]));
 #pragma unroll
-      for (int k = 5; k < 14; k++) p = fma(p, r, tab[k]);
+      for (int k = 5; k < 14; k++) p = fma(p, r, sconst_e<SC>(tab[k]));
       p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0); v[a] = ldexp(p, (int)n);
 #if ECM_KM_EXP == 1
       asm volatile("" : "+v"(v[a]));
@@ -180,9 +225,9 @@ ECM_DI double log_near1(double x) {
    double s = w * di;
    s = fma(fma(-s, d, w), di, s);
    const double s2 = s * s;
-   double P = 1.0 / 17.0;
-   P = fma(P, s2, 1.0 / 15.0); P = fma(P, s2, 1.0 / 13.0); P = fma(P, s2, 1.0 / 11.0); P = fma(P, s2, 1.0 / 9.0);
-   P = fma(P, s2, 1.0 / 7.0); P = fma(P, s2, 1.0 / 5.0); P = fma(P, s2, 1.0 / 3.0);
+   double P = sconst(1.0 / 17.0);
+   P = fma(P, s2, sconst(1.0 / 15.0)); P = fma(P, s2, sconst(1.0 / 13.0)); P = fma(P, s2, sconst(1.0 / 11.0)); P = fma(P, s2, sconst(1.0 / 9.0));
+   P = fma(P, s2, sconst(1.0 / 7.0)); P = fma(P, s2, sconst(1.0 / 5.0)); P = fma(P, s2, sconst(1.0 / 3.0));
    const double s_2 = s + s;
    return fma(s_2 * s2, P, s_2);
 }
@@ -239,7 +284,7 @@ ECM_DI void exp_map(const double xi[3], double A[9], double Tr[9]) {
       b = 0.5 * (1.0 - th2 * (1.0 / 12.0) * (1.0 - th2 * (1.0 / 30.0) * (1.0 - th2 * (1.0 / 56.0))));
       c = (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0))));
    } else {
-      const double th = sqrt(th2); double sn, cs; sincos(th, &sn, &cs);
+      const double th = sqrt(th2); double sn, cs; sincos_s(th, sn, cs);
       a = sn / th; b = (1.0 - cs) / th2; c = (th - sn) / (th2 * th);
    }
    const double x = xi[0], y = xi[1], z = xi[2];
@@ -402,7 +447,7 @@ constexpr int KD = ECM_KD;   // systems per group of the cheap classes in the de
 #define ECM_KM_DEFER 1   // athermal-threshold (BCC) variant: window systems are treated one per lane after the group loop (eval_rj)
 #endif
 constexpr int KW = ECM_KW;   // slip systems evaluated together by the Kocks-Mecking kinetics (ILP vs registers; tuned on MI355X)
-template <bool WITHD, int KW = ECM_KW, bool PQ1 = false>
+template <bool WITHD, int KW = ECM_KW, bool PQ1 = false, bool SC = true>
 ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double tau[KW], double gdot[KW], double dg[KW]) {
    const double g_i = mp.with_g_athermal ? 1.0 / mp.tau_a : 1.0 / kv.g;
    const double gAth = mp.with_g_athermal ? kv.g : mp.tau_a;
@@ -421,7 +466,7 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
       double ex[KW], gr[KW], dgr[KW];
 #pragma unroll
       for (int a = 0; a < KW; a++) ex[a] = -fmax(xr[a], 0.0);
-      exp_n<KW, PQ1>(ex);
+      exp_n<KW, PQ1, SC>(ex);
 #pragma unroll
       for (int a = 0; a < KW; a++) {
          const bool small = xr[a] < EPS_SQRT;
@@ -460,11 +505,11 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
          }
 #pragma unroll
          for (int a = 0; a < KW; a++) ef[a] = eaf[a];
-         exp_n<KW, PQ1>(ef);
+         exp_n<KW, PQ1, SC>(ef);
          if (any_b) {
 #pragma unroll
             for (int a = 0; a < KW; a++) eb[a] = eab[a];
-            exp_n<KW, PQ1>(eb);
+            exp_n<KW, PQ1, SC>(eb);
          } else {
 #pragma unroll
             for (int a = 0; a < KW; a++) eb[a] = 0.0;
@@ -472,7 +517,14 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
 #pragma unroll
          for (int a = 0; a < KW; a++) pw[a] = 0.0;
          if (any_tail) {   // power-law tail: only above t_min = (1e-60)^m (rare for large 1/m)
-            if (mp.xn_int > 0) {
+            if constexpr (PQ1 && ECM_KM_LOG_NEAR1) {
+               // p == q == 1 instantiation: the host selects it only when the tail's window (t_min, t_max] lies in [0.75, 1.25] and 1/m is not an
+               // integer (model_kernels.hip, km_pq1), so the short-series logarithm is the only form compiled in - the general log() brought
+               // eight more coefficients into the register file of the whole Newton loop
+#pragma unroll
+               for (int a = 0; a < KW; a++) pw[a] = mp.xn * log_near1(at0[a]);
+               exp_n<KW, PQ1, SC>(pw);
+            } else if (mp.xn_int > 0) {
                double b[KW];
 #pragma unroll
                for (int a = 0; a < KW; a++) { pw[a] = 1.0; b[a] = at0[a]; }
@@ -491,11 +543,11 @@ ECM_DI void kmbald_gdot4(const MatParams& mp, const KinVals& kv, const double ta
                // (1e-60^m, 1e45^m): logarithm by the short series (other lanes compute a finite value that is not used)
 #pragma unroll
                for (int a = 0; a < KW; a++) pw[a] = mp.xn * log_near1(at0[a]);
-               exp_n<KW, PQ1>(pw);
+               exp_n<KW, PQ1, SC>(pw);
             } else {
 #pragma unroll
                for (int a = 0; a < KW; a++) pw[a] = mp.xn * log(fmax(at0[a], 1.0e-300));
-               exp_n<KW, PQ1>(pw);
+               exp_n<KW, PQ1, SC>(pw);
             }
          }
 #pragma unroll
@@ -593,6 +645,9 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #define ECM_KM_FORMS_CSE 2   // athermal-threshold Kocks-Mecking kernel: cheap classes through the factored slip forms: 0 never, 1 always, 2 in the
                              // p == q == 1 instantiation only.  Measured at 128^3: general instantiation 12.7 ms against 12.3 (448 B of scratch
                              // instead of 320: spill latency), p == q == 1 instantiation 9.6 ms against 10.4 (profiles/r03_kernel_experiments.txt)
+#endif
+#ifndef ECM_KM_PEND_INSERT
+#define ECM_KM_PEND_INSERT 1   // athermal-threshold Kocks-Mecking kernel, factored-forms path: window systems inserted into the per-system arrays (eval_rj; A/B switch)
 #endif
 #ifndef ECM_TANGENT_FIRST
 #define ECM_TANGENT_FIRST 1   // epilogue order: tangent before the state / stress outputs (see point_update)
@@ -784,7 +839,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
             double exv[NSLIP];
 #pragma unroll
             for (int a = 0; a < NSLIP; a++) exv[a] = -fmax(xr[a], 0.0);
-            exp_n<NSLIP, kin_pq1(KIN)>(exv);
+            exp_n<NSLIP, kin_pq1(KIN), kin_sc_exp(KIN)>(exv);
 #pragma unroll
             for (int a = 0; a < NSLIP; a++) {
                const double ex = exv[a];
@@ -792,6 +847,24 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
                const double gr = small ? pb.kv.gam_r * xr[a] : pb.kv.gam_r * (1.0 - ex);
                const double dgr = (small ? pb.kv.gam_r : pb.kv.gam_r * ex) * wi;
                if (xr[a] >= 0.0) { gd[a] = copysign(gr, tau[a]); dg[a] = dgr; }
+            }
+         }
+         if (ECM_KM_PEND_INSERT) {
+            // window systems, one per lane and pass: the rate and its derivative are INSERTED into gd[] / dg[] (compare-and-select over the 12
+            // static slots) and the factored forms below then run once over all 12 systems.  The loop no longer carries the 38 accumulators of
+            // D^p, W^p and the two Jacobian blocks plus a table row (they were what the allocator spilled inside the Newton loop), only the 24
+            // per-system values
+            while (__ballot(pend != 0) != 0ull) {
+               if (pend != 0) {
+                  const int a = __ffs((int)pend) - 1; pend &= pend - 1;
+                  double t1 = 0.0;
+#pragma unroll
+                  for (int s2 = 0; s2 < NSLIP; s2++) t1 = (a == s2) ? tau[s2] : t1;
+                  double tau1[1] = { t1 }, gd1[1], dg1[1] = { 0.0 };
+                  kmbald_gdot4<WITHJ, 1, kin_pq1(KIN), kin_sc_exp(KIN)>(mp, pb.kv, tau1, gd1, dg1);
+#pragma unroll
+                  for (int s2 = 0; s2 < NSLIP; s2++) { gd[s2] = (a == s2) ? gd1[0] : gd[s2]; if (WITHJ) dg[s2] = (a == s2) ? dg1[0] : dg[s2]; }
+               }
             }
          }
 #pragma unroll
@@ -828,7 +901,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
             double ex[KD];
 #pragma unroll
             for (int a = 0; a < KD; a++) ex[a] = -fmax(xr[a], 0.0);
-            exp_n<KD, kin_pq1(KIN)>(ex);
+            exp_n<KD, kin_pq1(KIN), kin_sc_exp(KIN)>(ex);
 #pragma unroll
             for (int a = 0; a < KD; a++) {
                const bool small = xr[a] < EPS_SQRT;
@@ -861,6 +934,8 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
          }
       }
       }
+      constexpr bool PEND_DONE = ECM_KM_PEND_INSERT && (ECM_KM_FORMS_CSE == 1 || (ECM_KM_FORMS_CSE == 2 && kin_pq1(KIN)));   // handled above
+      if constexpr (!PEND_DONE)
       while (__ballot(pend != 0) != 0ull) {      // one pending window system per lane and pass
          if (pend != 0) {
             const int a = __ffs((int)pend) - 1; pend &= pend - 1;
@@ -868,7 +943,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 #pragma unroll
             for (int c = 0; c < 8; c++) pq[c] = pb.pqt ? pb.pqt[8 * a + c] : PQ_TAB[a][c];      // lane-varying row: LDS copy of the 768-byte table
             double tau1[1] = { pq[0] * k[0] + pq[1] * k[1] + pq[2] * k[2] + pq[3] * k[3] + pq[4] * k[4] }, gd1[1], dg1[1];
-            kmbald_gdot4<WITHJ, 1, kin_pq1(KIN)>(mp, pb.kv, tau1, gd1, dg1);
+            kmbald_gdot4<WITHJ, 1, kin_pq1(KIN), kin_sc_exp(KIN)>(mp, pb.kv, tau1, gd1, dg1);
             if (gdot_out) gdot_out[a * pb.gs] = gd1[0];
             dis += tau1[0] * gd1[0]; shr += fabs(gd1[0]);
 #pragma unroll
@@ -903,7 +978,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
       double tau[NSLIP], gd[NSLIP], dg[NSLIP];
       slip_tau12(ks, tau);
 #pragma unroll
-      for (int a0 = 0; a0 < NSLIP; a0 += ECM_KB) kmbald_gdot4<WITHJ, ECM_KB, true>(mp, pb.kv, tau + a0, gd + a0, dg + a0);
+      for (int a0 = 0; a0 < NSLIP; a0 += ECM_KB) kmbald_gdot4<WITHJ, ECM_KB, true, kin_sc_exp(KIN)>(mp, pb.kv, tau + a0, gd + a0, dg + a0);
 #pragma unroll
       for (int a = 0; a < NSLIP; a++) {
          if (gdot_out) gdot_out[a * pb.gs] = gd[a];
@@ -927,7 +1002,7 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
             for (int c = 0; c < 8; c++) pq[a][c] = PQ_TAB[a0 + a][c];
             tau[a] = pq[a][0] * k[0] + pq[a][1] * k[1] + pq[a][2] * k[2] + pq[a][3] * k[3] + pq[a][4] * k[4];
          }
-         kmbald_gdot4<WITHJ, ECM_KW, kin_pq1(KIN)>(mp, pb.kv, tau, gd, dg);
+         kmbald_gdot4<WITHJ, ECM_KW, kin_pq1(KIN), kin_sc_exp(KIN)>(mp, pb.kv, tau, gd, dg);
 #pragma unroll
          for (int a = 0; a < KW; a++) {
             if (gdot_out) gdot_out[(a0 + a) * pb.gs] = gd[a];
@@ -1018,7 +1093,7 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
 
 // slip rates at the converged point (Kocks-Mecking family, ECM_KM_GDOT_AT_END): one more pass through the kinetics (no derivatives) instead
 // of 12 global stores per evaluation - on gfx9 every scratch reload of the Newton loop otherwise waits for those stores (vmcnt)
-template <bool PQ1>
+template <bool PQ1, bool SC>
 ECM_DI void km_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out) {
    const double k[5] = { mp.kd0 * e_f[0], mp.kd0 * e_f[1], mp.kd2 * e_f[2], mp.kd2 * e_f[3], mp.kd2 * e_f[4] };
 #pragma unroll 1
@@ -1026,7 +1101,7 @@ ECM_DI void km_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[
       double tau[KW], gd[KW];
 #pragma unroll
       for (int a = 0; a < KW; a++) tau[a] = PQ_TAB[a0 + a][0] * k[0] + PQ_TAB[a0 + a][1] * k[1] + PQ_TAB[a0 + a][2] * k[2] + PQ_TAB[a0 + a][3] * k[3] + PQ_TAB[a0 + a][4] * k[4];
-      kmbald_gdot4<false, ECM_KW, PQ1>(mp, pb.kv, tau, gd, nullptr);
+      kmbald_gdot4<false, ECM_KW, PQ1, SC>(mp, pb.kv, tau, gd, nullptr);
 #pragma unroll
       for (int a = 0; a < KW; a++) stg(&gdot_out[(a0 + a) * pb.gs], gd[a]);
    }
@@ -1483,7 +1558,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
       const double th2 = xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2];
       double cq, sq;   // cos(th/2), sin(th/2)/th
       if (th2 < 1.0e-4) { const double h2 = 0.25 * th2; cq = 1.0 - 0.5 * h2 * (1.0 - h2 * (1.0 / 12.0) * (1.0 - h2 * (1.0 / 30.0))); sq = 0.5 * (1.0 - h2 * (1.0 / 6.0) * (1.0 - h2 * (1.0 / 20.0) * (1.0 - h2 * (1.0 / 42.0)))); }
-      else { const double th = sqrt(th2); double sn, cs; sincos(0.5 * th, &sn, &cs); cq = cs; sq = sn / th; }
+      else { const double th = sqrt(th2); double sn, cs; sincos_s(0.5 * th, sn, cs); cq = cs; sq = sn / th; }
       const double a[4] = { cq, sq * xi[0], sq * xi[1], sq * xi[2] };
       qf[0] = qn[0] * a[0] - qn[1] * a[1] - qn[2] * a[2] - qn[3] * a[3];
       qf[1] = qn[0] * a[1] + qn[1] * a[0] + qn[2] * a[3] - qn[3] * a[2];
@@ -1514,7 +1589,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
       double eNew = ECM_CD(CD_ENEW);
       eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * (ECM_CD(CD_WRKOLD) + wrk_new);
       if constexpr (!kin_is_km(KIN)) voce_slip_rates<kin_xn_ct(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS, dis_rate, shrate);
-      else if (ECM_KM_GDOT_AT_END) km_slip_rates<kin_pq1(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS);
+      else if (ECM_KM_GDOT_AT_END) km_slip_rates<kin_pq1(KIN), kin_sc_exp(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS);
       stg(&sv1[(H_SHRATE) * QS], shrate);
       stg(&sv1[(H_SHR) * QS], (ECM_EPI_NO_LOADS ? ECM_ST(st, ST_PB + PB_SHR0) : ldg(&sv0[(H_SHR) * QS])) + shrate * dt);
       stg(&sv1[(H_FLOW) * QS], ((deff_keep > TINY_SQRT) ? dis_rate * dt : 0.0) + (ECM_EPI_NO_LOADS ? ECM_ST(st, ST_PB + PB_FLOW0) : ldg(&sv0[(H_FLOW) * QS])));   // accumulated plastic work

@@ -324,7 +324,8 @@ static void launch_model_rec(exa_ctx* ctx, double dt, double* J, const double* v
 // compiled in (ecmdev::KIN_PQ1: same arithmetic, no pow() code); EXA_KM_PQ1=off keeps the general instantiation for A/B runs
 static bool km_pq1(const exa_ctx* ctx) {
    const char* e = std::getenv("EXA_KM_PQ1");   // read per launch: the tests flip it inside one process
-   return !(e && std::strcmp(e, "off") == 0) && ctx->mp.p == 1.0 && ctx->mp.q == 1.0;
+   // (the instantiation has the short-series logarithm of the power-law tail compiled in: ecm_device.hpp, kmbald_gdot4)
+   return !(e && std::strcmp(e, "off") == 0) && ctx->mp.p == 1.0 && ctx->mp.q == 1.0 && ctx->mp.xn_int == 0 && ctx->mp.t_min >= 0.75 && ctx->mp.t_max <= 1.25;
 }
 
 // Voce sets whose power-law exponent 1/m - 1 is 49 (m = 0.02: the shipped sets) run the instantiation with the exponent compiled in
