@@ -1261,7 +1261,7 @@ ECM_DI void jac_mult_T(const MatParams& mp, const Prob& pb, const Jac& J, const 
 // half (x_e = Jee^-1 rhs_e) and the start-up product disappears: 39 FP64 operations fewer per Newton step.  Both starts leave an error
 // of (contraction)^2 ~ 1e-8 of an O(1) quantity after two sweeps (x_r* itself here, Jrr^-1 Jre x_e* there).
 #ifndef ECM_GS_START0
-#define ECM_GS_START0 0   // measured at 128^3 (profiles/r04_kernel_experiments.txt): 4.85 ms either way, so the round-3 form stays
+#define ECM_GS_START0 1   // measured at 128^3 (profiles/r04_kernel_experiments.txt): nothing while the launch waited on scratch and stores (4.85 ms either way), 4.43 -> 4.35 ms once it was issue-bound again
 #endif
 #ifndef ECM_EXP_NSWEEP
 #define ECM_EXP_NSWEEP 0   // timing experiment: number of sweeps of the Newton step (0 = the product's two)
