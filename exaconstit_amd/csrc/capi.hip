@@ -48,8 +48,9 @@ extern "C" {
 
 exa_ctx* exa_create(const exa_config* cfg, int* err) {
    auto set = [&](int e) { if (err) *err = e; };
-   // p = 1 and p = 2 are the orders every entry point is built and tested for; point ids of the tail-split list are 32-bit
-   if (!cfg || cfg->nelems <= 0 || cfg->order < 1 || cfg->order > 2) { set(EXA_ERR_ARG); return nullptr; }
+   // p = 1 and p = 2 have tuned kernels for every entry point; orders 3 ... 6 (what the reference's own unit tests run at:
+   // test/mechanics_test.cpp:54,187,313,471,630) go through the run-time-order kernels.  Point ids of the tail-split list are 32-bit
+   if (!cfg || cfg->nelems <= 0 || cfg->order < 1 || cfg->order > 6) { set(EXA_ERR_ARG); return nullptr; }
    { const int64_t np1 = cfg->order + 1; if ((int64_t)cfg->nelems * np1 * np1 * np1 >= (int64_t)INT32_MAX) { set(EXA_ERR_ARG); return nullptr; } }
    exa_ctx* ctx = new exa_ctx();
    ctx->cfg = *cfg; ctx->cfg.props = nullptr;

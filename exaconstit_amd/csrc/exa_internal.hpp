@@ -80,6 +80,20 @@ __device__ __forceinline__ QView qview(int W, int Q, int64_t e, int q) {
    if (QB) return { ((((e >> 6) * Q + q) * (int64_t)W) << 6) + (e & 63), 64 };
    return { (int64_t)W * (q + (int64_t)Q * e), 1 };
 }
+// Shape-derivative table (n,3,Q) of the reference element: the kernels that walk it stage it in LDS when it is small (p = 1: 1.5 KB, p = 2:
+// 17 KB) and read it from global memory at the orders the reference's unit tests also run (p = 3: 96 KB ... p = 6: 2.8 MB); one rule for
+// the kernel (stage_shape) and for the launch (exa_g_lds_bytes)
+constexpr int64_t EXA_G_LDS_MAX_DOUBLES = 6144;
+static inline __host__ __device__ bool exa_g_in_lds(int n, int Q) { return (int64_t)n * 3 * Q <= EXA_G_LDS_MAX_DOUBLES; }
+static inline size_t exa_g_lds_bytes(int n, int Q) { return exa_g_in_lds(n, Q) ? sizeof(double) * (size_t)n * 3 * Q : 0; }
+#ifdef __HIPCC__
+__device__ __forceinline__ const double* stage_shape(double* lds, const double* __restrict__ G, int n, int Q) {
+   if (!exa_g_in_lds(n, Q)) return G;      // kernel-uniform
+   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) lds[i] = G[i];
+   __syncthreads();
+   return lds;
+}
+#endif
 static inline size_t exa_qf_doubles(const exa_ctx* ctx, int vdim) {
    return ctx->qblk ? (size_t)vdim * 64 * ctx->Q * ((ctx->E + 63) / 64) : (size_t)vdim * ctx->P;
 }

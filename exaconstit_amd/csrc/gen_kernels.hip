@@ -38,9 +38,8 @@ __device__ __forceinline__ void b_row(int c, const double b[3], double v, double
 template <bool QB>
 __global__ void k_eds(const int Q, const int n, const int E, const double* __restrict__ W, const double* __restrict__ G,
                       const double* __restrict__ J, double* __restrict__ eDS) {
-   extern __shared__ double sG[];
-   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
-   __syncthreads();
+   extern __shared__ double sG_lds[];
+   const double* sG = stage_shape(sG_lds, G, n, Q);
    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= (int64_t)n * E) return;
    const int a = (int)(t % n); const int64_t e = t / n;
@@ -58,9 +57,8 @@ __global__ void k_eds(const int Q, const int n, const int E, const double* __res
 // Y(a,c,e) += sum_q detJ W B-bar(a,c,:) . sigma ; one thread per (node, element)
 __global__ void k_residual_bbar(const int Q, const int n, const int E, const double* __restrict__ W, const double* __restrict__ G,
                                 const double* __restrict__ J, const double* __restrict__ S, const double* __restrict__ eDS, double* __restrict__ Y) {
-   extern __shared__ double sG[];
-   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
-   __syncthreads();
+   extern __shared__ double sG_lds[];
+   const double* sG = stage_shape(sG_lds, G, n, Q);
    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= (int64_t)n * E) return;
    const int a = (int)(t % n); const int64_t e = t / n;
@@ -88,9 +86,8 @@ template <int N, bool BBAR>
 __global__ __launch_bounds__(PA_BLK) void k_assemble_ea_gen(const int E, const double* __restrict__ pa, const double* __restrict__ G, const double* __restrict__ W,
                                                             const double* __restrict__ eDS, double* __restrict__ emat) {
    constexpr int Q = N, ND = 3 * N;
-   extern __shared__ double sG[];
-   for (int i = threadIdx.x; i < N * 3 * Q; i += blockDim.x) sG[i] = G[i];
-   __syncthreads();
+   extern __shared__ double sG_lds[];
+   const double* sG = stage_shape(sG_lds, G, N, Q);
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
    const int cj = blockIdx.y, aj = cj % N, kj = cj / N;
    if (e >= E) return;
@@ -163,6 +160,71 @@ __global__ __launch_bounds__(PA_BLK) void k_ea_apply_gen(const int E, const doub
       if (LVEC) atomicAdd(&y[conn[(j % N) + N * e] + (int64_t)nnodes * (j / N)], s);
       else y[j + (int64_t)ND * e] += s;
    }
+}
+
+// ---- any order (run-time n): the element-assembly kernels for the orders above 2, which the reference's own unit tests use (order 3:
+// test/mechanics_test.cpp:313,471).  Nothing is held per lane but a 3-entry accumulator: grid (block of 64 elements, column dof, row node),
+// the record of a point is re-read by every (column, row node) pair - slow by design, these orders are outside every BASELINE config.
+template <bool BBAR>
+__global__ __launch_bounds__(PA_BLK) void k_assemble_ea_rt(const int n, const int Q, const int E, const double* __restrict__ pa, const double* __restrict__ G,
+                                                           const double* __restrict__ W, const double* __restrict__ eDS, double* __restrict__ emat) {
+   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   const int cj = blockIdx.y, aj = cj % n, kj = cj / n, a = blockIdx.z;
+   if (e >= E) return;
+   const int ND = 3 * n;
+   double r[3] = { 0, 0, 0 };
+   double gej[3] = { 0, 0, 0 }, gea[3] = { 0, 0, 0 };
+   if (BBAR) for (int c = 0; c < 3; c++) { gej[c] = eDS[eds_off(e, n, aj, c)]; gea[c] = eDS[eds_off(e, n, a, c)]; }
+   for (int q = 0; q < Q; q++) {
+      const double2* rec = reinterpret_cast<const double2*>(pa + pa_off(blk, Q, q, 0)) + lane;
+      double v[PA_SLOTS];
+#pragma unroll
+      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = rec[pr * PA_BLK]; v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
+      const double* Ct = v; const double* adj = v + 36;
+      const double detJ = v[45] / W[q];
+      const double* Gq = G + (int64_t)3 * n * q;
+      double bj[3];
+      { const double g0 = Gq[aj], g1 = Gq[aj + n], g2 = Gq[aj + 2 * n];
+        for (int t = 0; t < 3; t++) bj[t] = g0 * adj[t] + g1 * adj[3 + t] + g2 * adj[6 + t]; }
+      double epsj[6]; b_row(kj, bj, BBAR ? (detJ * gej[kj] - bj[kj]) * (1.0 / 3.0) : 0.0, epsj);
+      double cb[6];
+#pragma unroll
+      for (int u = 0; u < 6; u++) { double s = 0; for (int w = 0; w < 6; w++) s += Ct[u + 6 * w] * epsj[w]; cb[u] = s; }
+      const double cb012 = cb[0] + cb[1] + cb[2];
+      const double g0 = Gq[a], g1 = Gq[a + n], g2 = Gq[a + 2 * n];
+      const double b0 = g0 * adj[0] + g1 * adj[3] + g2 * adj[6], b1 = g0 * adj[1] + g1 * adj[4] + g2 * adj[7], b2 = g0 * adj[2] + g1 * adj[5] + g2 * adj[8];
+      double r0 = b0 * cb[0] + b2 * cb[4] + b1 * cb[5];
+      double r1 = b1 * cb[1] + b2 * cb[3] + b0 * cb[5];
+      double r2 = b2 * cb[2] + b1 * cb[3] + b0 * cb[4];
+      if (BBAR) {
+         r0 += (detJ * gea[0] - b0) * (1.0 / 3.0) * cb012;
+         r1 += (detJ * gea[1] - b1) * (1.0 / 3.0) * cb012;
+         r2 += (detJ * gea[2] - b2) * (1.0 / 3.0) * cb012;
+      }
+      r[0] += r0; r[1] += r1; r[2] += r2;
+   }
+   for (int c = 0; c < 3; c++) emat[eag_off(blk, ND, cj, a + n * c) + lane] = r[c];
+}
+
+// y(j,e) += sum_i A(i,j,e) x(i,e): grid (block of 64 elements, column dof j)
+template <bool LVEC>
+__global__ __launch_bounds__(PA_BLK) void k_ea_apply_rt(const int n, const int E, const double* __restrict__ emat, const double* __restrict__ x, double* __restrict__ y,
+                                                        const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
+                                                        const double* __restrict__ gate) {
+   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   const int j = blockIdx.y, ND = 3 * n;
+   if (e >= E) return;
+   if (gate != nullptr && gate[0] != 0.0) return;
+   const double* col = emat + eag_off(blk, ND, j, 0) + lane;
+   double s = 0;
+   for (int i = 0; i < ND; i++) {
+      double xi;
+      if (LVEC) { const int64_t idx = conn[(i % n) + (int64_t)n * e] + (int64_t)nnodes * (i / n); xi = (mask != nullptr && mask[idx]) ? 0.0 : x[idx]; }
+      else xi = x[i + (int64_t)ND * e];
+      s += col[(int64_t)i * PA_BLK] * xi;
+   }
+   if (LVEC) atomicAdd(&y[conn[(j % n) + (int64_t)n * e] + (int64_t)nnodes * (j / n)], s);
+   else y[j + (int64_t)ND * e] += s;
 }
 
 // ---- matrix-free action for p = 2 (27 nodes, 27 points), plain or B-bar, on L-vectors ---------------------------------------------
@@ -386,9 +448,8 @@ __global__ __launch_bounds__(PA_BLK) void k_ea_export_gen(const int E, const int
 // generic partial-assembly gradient action: stage 1 (one thread per point) T = adj ( Ct : sym( (G x_e) adj ) )
 __global__ void k_pa_apply_stage1(const int Q, const int n, const int64_t P, const double* __restrict__ G, const double* __restrict__ pa,
                                   const double* __restrict__ X, double* __restrict__ Tb) {
-   extern __shared__ double sG[];
-   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
-   __syncthreads();
+   extern __shared__ double sG_lds[];
+   const double* sG = stage_shape(sG_lds, G, n, Q);
    const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (ip >= P) return;
    const int q = (int)(ip % Q); const int64_t e = ip / Q;
@@ -413,9 +474,8 @@ __global__ void k_pa_apply_stage1(const int Q, const int n, const int64_t P, con
 
 // diag(a,c,e) += sum_q b(a)^T Ct_c b(a) for any order (reference src/mechanics_integrators.cpp:702-743)
 __global__ void k_pa_diag_gen(const int Q, const int n, const int E, const double* __restrict__ G, const double* __restrict__ pa, double* __restrict__ Y) {
-   extern __shared__ double sG[];
-   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
-   __syncthreads();
+   extern __shared__ double sG_lds[];
+   const double* sG = stage_shape(sG_lds, G, n, Q);
    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= (int64_t)n * E) return;
    const int a = (int)(t % n); const int64_t e = t / n;
@@ -441,24 +501,28 @@ int exa_launch_residual_apply_from(exa_ctx* ctx, const double* D, double* Y, hip
 int exa_launch_eds(exa_ctx* ctx, const double* J, hipStream_t s);
 
 int exa_launch_eds(exa_ctx* ctx, const double* J, hipStream_t s) {
-   if (ctx->qblk) hipLaunchKernelGGL(k_eds<true>, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, ctx->eDS);
-   else hipLaunchKernelGGL(k_eds<false>, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, ctx->eDS);
+   if (ctx->qblk) hipLaunchKernelGGL(k_eds<true>, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, ctx->eDS);
+   else hipLaunchKernelGGL(k_eds<false>, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, ctx->eDS);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_residual_bbar(exa_ctx* ctx, const double* J, const double* S, double* Y, hipStream_t s) {
-   hipLaunchKernelGGL(k_residual_bbar, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, S, ctx->eDS, Y);
+   hipLaunchKernelGGL(k_residual_bbar, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->E, ctx->W_dev, ctx->G_dev, J, S, ctx->eDS, Y);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_assemble_ea_gen(exa_ctx* ctx, hipStream_t s) {
    const bool bbar = ctx->cfg.integ == EXA_INTEG_BBAR;
-   const dim3 grid(nblk(ctx->E, PA_BLK), 3 * ctx->n); const size_t lds = sizeof(double) * ctx->n * 3 * ctx->Q;
+   const dim3 grid(nblk(ctx->E, PA_BLK), 3 * ctx->n); const size_t lds = exa_g_lds_bytes(ctx->n, ctx->Q);
    if (ctx->n == 8) {
       if (bbar) hipLaunchKernelGGL((k_assemble_ea_gen<8, true>), grid, dim3(PA_BLK), lds, s, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
       else hipLaunchKernelGGL((k_assemble_ea_gen<8, false>), grid, dim3(PA_BLK), lds, s, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
    } else if (ctx->n == 27) {
       if (bbar) hipLaunchKernelGGL((k_assemble_ea_gen<27, true>), grid, dim3(PA_BLK), lds, s, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
       else hipLaunchKernelGGL((k_assemble_ea_gen<27, false>), grid, dim3(PA_BLK), lds, s, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
-   } else { ctx->err = "element assembly is built for p = 1 and p = 2"; return EXA_ERR_UNSUPPORTED; }
+   } else {   // any other order: run-time kernels
+      const dim3 g3(nblk(ctx->E, PA_BLK), 3 * ctx->n, ctx->n);
+      if (bbar) hipLaunchKernelGGL((k_assemble_ea_rt<true>), g3, dim3(PA_BLK), 0, s, ctx->n, ctx->Q, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
+      else hipLaunchKernelGGL((k_assemble_ea_rt<false>), g3, dim3(PA_BLK), 0, s, ctx->n, ctx->Q, ctx->E, ctx->pa, ctx->G_dev, ctx->W_dev, ctx->eDS, ctx->emat);
+   }
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_ea_apply_gen(exa_ctx* ctx, const double* x, double* y, bool lvec, const uint8_t* mask, const double* gate, hipStream_t s) {
@@ -469,7 +533,11 @@ int exa_launch_ea_apply_gen(exa_ctx* ctx, const double* x, double* y, bool lvec,
    } else if (ctx->n == 27) {
       if (lvec) hipLaunchKernelGGL((k_ea_apply_gen<27, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
       else hipLaunchKernelGGL((k_ea_apply_gen<27, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
-   } else { ctx->err = "element assembly is built for p = 1 and p = 2"; return EXA_ERR_UNSUPPORTED; }
+   } else {
+      const dim3 g2(nb, 3 * ctx->n);
+      if (lvec) hipLaunchKernelGGL((k_ea_apply_rt<true>), g2, dim3(PA_BLK), 0, s, ctx->n, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
+      else hipLaunchKernelGGL((k_ea_apply_rt<false>), g2, dim3(PA_BLK), 0, s, ctx->n, ctx->E, ctx->emat, x, y, ctx->conn, ctx->nnodes, mask, gate);
+   }
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 // one-dimensional basis tables of the p = 2 kernels + a check of the node numbering they have compiled in
@@ -521,11 +589,11 @@ int exa_launch_ea_export_gen(exa_ctx* ctx, double* out, hipStream_t s) {
 }
 // generic PA action on E-vectors: stage 1 into the (3,3,Q,E) scratch `dmat`, stage 2 = the AddMultPA contraction
 int exa_launch_pa_apply_gen(exa_ctx* ctx, const double* x, double* y, hipStream_t s) {
-   hipLaunchKernelGGL(k_pa_apply_stage1, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, ctx->pa, x, ctx->tbuf);
+   hipLaunchKernelGGL(k_pa_apply_stage1, dim3(nblk(ctx->P, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, ctx->pa, x, ctx->tbuf);
    EXA_HIP_CHECK(ctx, hipGetLastError());
    return exa_launch_residual_apply_from(ctx, ctx->tbuf, y, s);
 }
 int exa_launch_pa_diag_gen(exa_ctx* ctx, double* y, hipStream_t s) {
-   hipLaunchKernelGGL(k_pa_diag_gen, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, ctx->pa, y);
+   hipLaunchKernelGGL(k_pa_diag_gen, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, ctx->pa, y);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }

@@ -94,15 +94,16 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
    extern __shared__ double sG[];
    const bool rows_by_wave = QB && !tail_mode;
    const int wpb = (int)(blockDim.x >> 6);
-   const int tab = P2F ? 0 : n * 3 * (rows_by_wave ? wpb : Q);
+   const bool g_lds = !P2F && exa_g_in_lds(n, rows_by_wave ? wpb : Q);   // orders above 2: the table stays in global memory (exa_internal.hpp)
+   const int tab = g_lds ? n * 3 * (rows_by_wave ? wpb : Q) : 0;
    // Kocks-Mecking: the slip table (12 rows of 8) behind the stash, for the rows that are read by lane-varying index (ecm_device.hpp, eval_rj)
    const int pqo = tab + ecmdev::ST_SLOTS * ECM_STASH_STRIDE;
-   if (!P2F) for (int i = threadIdx.x; i < tab; i += blockDim.x) {
+   if (g_lds) for (int i = threadIdx.x; i < tab; i += blockDim.x) {
       const int row = i / (3 * n), k = i - row * (3 * n);
       sG[i] = G[3 * n * (rows_by_wave ? (int)((bidx * wpb + row) % Q) : row) + k];
    }
    if (ecmdev::kin_is_km(KIN)) for (int i = threadIdx.x; i < 8 * ecmdev::NSLIP; i += blockDim.x) sG[pqo + i] = (&ecmdev::PQ_TAB[0][0])[i];
-   if (!P2F || ecmdev::kin_is_km(KIN)) __syncthreads();
+   if (g_lds || ecmdev::kin_is_km(KIN)) __syncthreads();
    if (tail_mode) {   // dense pass over the points the capped launch handed over: thread t owns point tail[1 + t]
       const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
       if (t >= tail[0]) return;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
    if (!tail_mode && e * Q >= P) return;
    constexpr int QS = QB ? 64 : 1;
    const QView vJ = qview<QB>(9, Q, e, q);
-   const double* Gq = sG + 3 * n * (rows_by_wave ? (int)(threadIdx.x >> 6) : q);
+   const double* Gq = g_lds ? sG + 3 * n * (rows_by_wave ? (int)(threadIdx.x >> 6) : q) : G + 3 * n * q;
    double J11, J21, J31, J12, J22, J32, J13, J23, J33;
    double tsc = 0.0;   // REC: dt W_q / detJ
    double L[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -278,7 +279,8 @@ int exa_launch_nfev_hist(exa_ctx* ctx, const double* state, int* hist_dev, hipSt
 // second cap, lists what it cuts off itself for a third launch.
 // dynamic LDS of a launch of k_model_setup: shape rows (per wave for the element-blocked full launch, the whole table otherwise) + stash + slip table
 static size_t model_lds_bytes(const exa_ctx* ctx, bool km, bool p2f, bool qb, int tail_mode) {
-   const size_t rows = p2f ? 0 : (size_t)ctx->n * 3 * ((qb && !tail_mode) ? (size_t)(EXA_MODEL_BS / 64) : (size_t)ctx->Q);
+   const int nrow = (qb && !tail_mode) ? EXA_MODEL_BS / 64 : ctx->Q;
+   const size_t rows = (p2f || !exa_g_in_lds(ctx->n, nrow)) ? 0 : (size_t)ctx->n * 3 * nrow;
    return sizeof(double) * (rows + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE + (km ? (size_t)8 * ecmdev::NSLIP : (size_t)0));
 }
 

@@ -52,9 +52,8 @@ __global__ void k_jacobians_from_geom(const int Q, const int64_t P, const double
 
 template <bool QB>
 __global__ void k_jacobians(const int Q, const int n, const int64_t P, const double* __restrict__ G, const double* __restrict__ xe, double* __restrict__ J) {
-   extern __shared__ double sG[];
-   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
-   __syncthreads();
+   extern __shared__ double sG_lds[];
+   const double* sG = stage_shape(sG_lds, G, n, Q);
    const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (ip >= P) return;
    const int q = (int)(ip % Q); const int64_t e = ip / Q;
@@ -74,9 +73,8 @@ __global__ void k_jacobians(const int Q, const int n, const int64_t P, const dou
 template <bool QB>
 __global__ void k_grad_calc(const int Q, const int n, const int64_t P, const double* __restrict__ J, const double* __restrict__ G,
                             const double* __restrict__ fe, double* __restrict__ out) {
-   extern __shared__ double sG[];
-   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
-   __syncthreads();
+   extern __shared__ double sG_lds[];
+   const double* sG = stage_shape(sG_lds, G, n, Q);
    const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (ip >= P) return;
    const int q = (int)(ip % Q); const int64_t e = ip / Q;
@@ -111,9 +109,8 @@ __global__ void k_residual_setup(const int Q, const int64_t P, const double* __r
 
 // Y(i,k,e) += sum_q sum_j G(i,j,q) D(j,k,q,e);  one thread per (node, element)
 __global__ void k_residual_apply(const int Q, const int n, const int E, const double* __restrict__ G, const double* __restrict__ D, double* __restrict__ Y) {
-   extern __shared__ double sG[];
-   for (int i = threadIdx.x; i < n * 3 * Q; i += blockDim.x) sG[i] = G[i];
-   __syncthreads();
+   extern __shared__ double sG_lds[];
+   const double* sG = stage_shape(sG_lds, G, n, Q);
    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= (int64_t)n * E) return;
    const int i = (int)(t % n); const int64_t e = t / n;
@@ -584,8 +581,8 @@ __global__ void k_vol_avg_partial(const int Q, const int64_t P, const int vdim, 
 static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 int exa_launch_jacobians(exa_ctx* ctx, const double* xe, double* J, hipStream_t s) {
-   if (ctx->qblk) hipLaunchKernelGGL(k_jacobians<true>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, xe, J);
-   else hipLaunchKernelGGL(k_jacobians<false>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, xe, J);
+   if (ctx->qblk) hipLaunchKernelGGL(k_jacobians<true>, dim3(nblk(ctx->P, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, xe, J);
+   else hipLaunchKernelGGL(k_jacobians<false>, dim3(nblk(ctx->P, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->P, ctx->G_dev, xe, J);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_jacobians_from_geom(exa_ctx* ctx, const double* gj, double* J, hipStream_t s) {
@@ -594,8 +591,8 @@ int exa_launch_jacobians_from_geom(exa_ctx* ctx, const double* gj, double* J, hi
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_grad_calc(exa_ctx* ctx, const double* J, const double* fe, double* out, hipStream_t s) {
-   if (ctx->qblk) hipLaunchKernelGGL(k_grad_calc<true>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, J, ctx->G_dev, fe, out);
-   else hipLaunchKernelGGL(k_grad_calc<false>, dim3(nblk(ctx->P, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->P, J, ctx->G_dev, fe, out);
+   if (ctx->qblk) hipLaunchKernelGGL(k_grad_calc<true>, dim3(nblk(ctx->P, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->P, J, ctx->G_dev, fe, out);
+   else hipLaunchKernelGGL(k_grad_calc<false>, dim3(nblk(ctx->P, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->P, J, ctx->G_dev, fe, out);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_residual_setup(exa_ctx* ctx, const double* J, const double* S, hipStream_t s) {
@@ -603,11 +600,11 @@ int exa_launch_residual_setup(exa_ctx* ctx, const double* J, const double* S, hi
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_residual_apply(exa_ctx* ctx, double* Y, hipStream_t s) {
-   hipLaunchKernelGGL(k_residual_apply, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, ctx->dmat, Y);
+   hipLaunchKernelGGL(k_residual_apply, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, ctx->dmat, Y);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_residual_apply_from(exa_ctx* ctx, const double* D, double* Y, hipStream_t s) {
-   hipLaunchKernelGGL(k_residual_apply, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), sizeof(double) * ctx->n * 3 * ctx->Q, s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, D, Y);
+   hipLaunchKernelGGL(k_residual_apply, dim3(nblk((int64_t)ctx->n * ctx->E, 256)), dim3(256), exa_g_lds_bytes(ctx->n, ctx->Q), s, ctx->Q, ctx->n, ctx->E, ctx->G_dev, D, Y);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_det_prepare(exa_ctx* ctx);   // capi.hip: builds the node -> element table on first use

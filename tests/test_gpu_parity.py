@@ -440,8 +440,11 @@ def test_element_blocked_layout_matches_aos(oracle, model, pkey):
         for k in a:
             tol = 1e-13 if k in ("J", "vgrad", "dp") else 1e-11      # the fused kernel's thread mapping differs (same arithmetic per point)
             assert rel_l2(b[k], a[k]) < tol, (assembly, k)
-    with pytest.raises(RuntimeError):                    # p = 3 is refused at exa_create: orders 1 and 2 are what every entry point is built for
-        L.Context(0, _props(orc, "voce"), 298.0, 3, 8)
+    with pytest.raises(RuntimeError):                    # orders up to 6 (the reference's unit tests) exist; 7 is refused at exa_create
+        L.Context(0, _props(orc, "voce"), 298.0, 7, 8)
+    p3 = L.Context(0, _props(orc, "voce"), 298.0, 3, 8)
+    assert L.exa_set_quadrature_layout(p3.h, L.EXA_QLAYOUT_EB64) == -4      # the element-blocked layout is built for p = 1 and p = 2
+    p3.close()
     bb = L.Context(0, _props(orc, "voce"), 298.0, 1, 8, assembly=L.EXA_ASSEMBLY_EA, integ=L.EXA_INTEG_BBAR)
     assert L.exa_set_quadrature_layout(bb.h, L.EXA_QLAYOUT_EB64) == -4      # built for p = 1 full integration and p = 2
     bb.close()
@@ -601,7 +604,7 @@ def test_abi_error_behaviour(oracle):
     dev = hipref.Dev()
     props = _props(orc, "voce")
     err = C.c_int(0)
-    for bad in (dict(nelems=0), dict(order=4), dict(integ=7), dict(integ=1, assembly=0)):
+    for bad in (dict(nelems=0), dict(order=7), dict(integ=7), dict(integ=1, assembly=0)):
         kw = dict(model=0, nelems=8, order=1, assembly=0, integ=0); kw.update(bad)
         cfg = L.ExaConfig(kw["model"], len(props), props.ctypes.data_as(C.POINTER(C.c_double)), 298.0, kw["order"], kw["nelems"], kw["assembly"], kw["integ"], -1)
         assert not L.exa_create(C.byref(cfg), C.byref(err)) and err.value < 0, bad
