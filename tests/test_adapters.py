@@ -36,7 +36,9 @@ def test_adapter_header_refuses_to_compile_without_mfem(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("model,pfile,ea,order,bbar", [(0, "props_cp_voce.txt", 0, 1, 0), (5, "props_cp_mts.txt", 0, 1, 0), (0, "props_cp_voce.txt", 1, 1, 0),
                                                         (0, "props_cp_voce.txt", 1, 1, 1), (0, "props_cp_voce.txt", 1, 2, 0), (0, "props_cp_voce.txt", 1, 2, 1),
-                                                        (0, "props_cp_voce.txt", 0, 2, 0)])
+                                                        (0, "props_cp_voce.txt", 0, 2, 0),
+                                                        # the orders of the reference's own integrator unit tests (test/mechanics_test.cpp:54,313,471)
+                                                        (0, "props_cp_voce.txt", 0, 3, 0), (0, "props_cp_voce.txt", 1, 3, 0), (0, "props_cp_voce.txt", 1, 3, 1)])
 def test_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, ea, order, bbar):
     """order = 2 and bbar = true (ICExaNLFIntegrator users, reference src/mechanics_integrators.hpp:78-124: element assembly only, like the
     reference's B-bar integrator) go through the same adapter classes: HipExaModel(..., order, nelems, assembly, bbar)."""
