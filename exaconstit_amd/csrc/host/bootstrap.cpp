@@ -24,6 +24,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <vector>
 #include "../../../include/exaconstit_driver.h"
 
 namespace {
@@ -33,8 +34,11 @@ bool env_int(const char* name, int& out) {
    if (!e || !*e) return false;
    char* end = nullptr; const long v = std::strtol(e, &end, 10);
    if (end == e) return false;
+   while (*end == ' ' || *end == '\t') end++;
+   if (*end != 0) return false;      // "8x", "2,3": not a number
    out = (int)v; return true;
 }
+bool env_set(const char* name) { const char* e = std::getenv(name); return e && *e; }
 
 void set_err(char* err, int errlen, const std::string& m) { if (err && errlen > 0) { std::snprintf(err, (size_t)errlen, "%s", m.c_str()); } }
 
@@ -59,19 +63,34 @@ Endpoint endpoint() {
 
 extern "C" {
 
-// rank / size / local rank from the launcher's environment; 0 / 1 / 0 when there is none (plain `mechanics -opt ...`)
+// rank / size / local rank from the launcher's environment; 0 / 1 / 0 when there is none (plain `mechanics -opt ...`).
+// Rank and size always come from the SAME launcher family.  Families whose variables also exist outside a launch are opt-in: SLURM_PROCID /
+// SLURM_NTASKS count only inside an srun step (SLURM_STEP_ID; an sbatch script without srun exports them too), RANK / WORLD_SIZE only with
+// a rendez-vous address (MASTER_ADDR, which torchrun-style launchers always export) - otherwise a plain `mechanics -opt x.toml` in such
+// an environment would wait for peers that never come.  The source is reported on stderr whenever more than one rank is found.
 int exa_bootstrap_env(int* rank, int* nranks, int* local_rank) {
-   int r = 0, n = 1, l = -1;
-   static const char* const rk[] = { "EXA_RANK", "PMI_RANK", "PMIX_RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID", "RANK" };
-   static const char* const nk[] = { "EXA_NRANKS", "PMI_SIZE", "OMPI_COMM_WORLD_SIZE", "SLURM_NTASKS", "WORLD_SIZE" };
-   static const char* const lk[] = { "EXA_LOCAL_RANK", "MPI_LOCALRANKID", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "LOCAL_RANK" };
-   bool have_r = false, have_n = false;
-   for (const char* k : rk) if (env_int(k, r)) { have_r = true; break; }
-   for (const char* k : nk) if (env_int(k, n)) { have_n = true; break; }
-   for (const char* k : lk) if (env_int(k, l)) break;
-   if (!have_r || !have_n) { r = 0; n = 1; }
-   if (n < 1 || r < 0 || r >= n) return -1;
+   struct Family { const char* name; const char* rk; const char* nk; const char* lk; bool enabled; };
+   const Family fam[] = {
+      { "EXA_RANK / EXA_NRANKS", "EXA_RANK", "EXA_NRANKS", "EXA_LOCAL_RANK", true },
+      { "MPICH / hydra (PMI_RANK, PMI_SIZE)", "PMI_RANK", "PMI_SIZE", "MPI_LOCALRANKID", true },
+      { "Open MPI (OMPI_COMM_WORLD_*)", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_RANK", true },
+      { "srun (SLURM_PROCID, SLURM_NTASKS)", "SLURM_PROCID", "SLURM_NTASKS", "SLURM_LOCALID", env_set("SLURM_STEP_ID") },
+      { "torchrun-style (RANK, WORLD_SIZE)", "RANK", "WORLD_SIZE", "LOCAL_RANK", env_set("MASTER_ADDR") || env_set("EXA_MASTER_ADDR") },
+   };
+   int r = 0, n = 1, l = -1; const char* src = nullptr;
+   for (const Family& f : fam) {
+      int fr, fn;
+      const bool hr = env_int(f.rk, fr), hn = env_int(f.nk, fn);
+      if (!hr && !hn) continue;
+      if (!f.enabled) continue;
+      if (hr != hn) { std::fprintf(stderr, "exa_bootstrap: %s: only one of rank / size is set\n", f.name); return -1; }
+      r = fr; n = fn; src = f.name;
+      if (!env_int(f.lk, l)) l = -1;
+      break;
+   }
+   if (n < 1 || r < 0 || r >= n) { std::fprintf(stderr, "exa_bootstrap: %s: rank %d of %d is not a valid rank\n", src ? src : "?", r, n); return -1; }
    if (l < 0) l = r;   // one node: the local rank is the rank
+   if (n > 1 || env_set("EXA_VERBOSE")) std::fprintf(stderr, "exa_bootstrap: rank %d of %d (local rank %d) from %s\n", r, n, l, src ? src : "no launcher: one rank");
    *rank = r; *nranks = n; *local_rank = l;
    return 0;
 }
@@ -85,29 +104,41 @@ int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double time
    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s > 0 ? timeout_s : 120.0);
    try {
       if (rank == 0) {
+         // listen on the rendez-vous address itself (loopback by default), not on every interface
+         addrinfo hints{}; hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM; hints.ai_flags = AI_PASSIVE;
+         addrinfo* res = nullptr;
+         sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)ep.port); sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+         if (::getaddrinfo(ep.addr.c_str(), nullptr, &hints, &res) == 0 && res) { sa.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr; ::freeaddrinfo(res); }
          const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
          if (ls < 0) throw std::runtime_error(std::string("socket: ") + std::strerror(errno));
+         struct Closer { int fd; ~Closer() { if (fd >= 0) ::close(fd); } } ls_guard{ ls };
          int one = 1; ::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-         sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)ep.port); sa.sin_addr.s_addr = htonl(INADDR_ANY);
-         if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0) { const std::string m = std::string("bind port ") + std::to_string(ep.port) + ": " + std::strerror(errno); ::close(ls); throw std::runtime_error(m); }
-         if (::listen(ls, nranks) != 0) { ::close(ls); throw std::runtime_error(std::string("listen: ") + std::strerror(errno)); }
+         if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0) {
+            sa.sin_addr.s_addr = htonl(INADDR_ANY);      // the address is not local to rank 0 (NAT, alias): fall back to all interfaces
+            if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0) throw std::runtime_error(std::string("bind ") + ep.addr + ":" + std::to_string(ep.port) + ": " + std::strerror(errno));
+         }
+         if (::listen(ls, nranks) != 0) throw std::runtime_error(std::string("listen: ") + std::strerror(errno));
+         std::vector<char> served_rank((size_t)nranks, 0);
          int served = 0;
          while (served < nranks - 1) {
             timeval tv{}; const double left = std::chrono::duration<double>(t_end - std::chrono::steady_clock::now()).count();
-            if (left <= 0) { ::close(ls); throw std::runtime_error("rendez-vous timed out: " + std::to_string(served) + " of " + std::to_string(nranks - 1) + " peers connected"); }
+            if (left <= 0) throw std::runtime_error("rendez-vous on " + ep.addr + ":" + std::to_string(ep.port) + " timed out: " + std::to_string(served) + " of " + std::to_string(nranks - 1) +
+                                                    " peers connected (is every rank started, and with the same [EXA_]MASTER_ADDR / PORT?)");
             tv.tv_sec = (long)left; tv.tv_usec = (long)((left - (long)left) * 1e6);
             fd_set fds; FD_ZERO(&fds); FD_SET(ls, &fds);
             if (::select(ls + 1, &fds, nullptr, nullptr, &tv) <= 0) continue;
             const int fd = ::accept(ls, nullptr, nullptr);
             if (fd < 0) continue;
-            timeval rt{ 10, 0 }; ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rt, sizeof(rt));
+            Closer fd_guard{ fd };
+            timeval rt{ 10, 0 }; ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rt, sizeof(rt)); ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &rt, sizeof(rt));
             uint32_t hello[2] = { 0, 0 };
-            try { recv_all(fd, hello, sizeof(hello)); } catch (...) { ::close(fd); continue; }
-            if (hello[0] != kMagic || hello[1] == 0 || hello[1] >= (uint32_t)nranks) { ::close(fd); continue; }
-            send_all(fd, buf, (size_t)nbytes);
-            ::close(fd); served++;
+            try {
+               recv_all(fd, hello, sizeof(hello));
+               if (hello[0] != kMagic || hello[1] == 0 || hello[1] >= (uint32_t)nranks) continue;      // not one of ours
+               send_all(fd, buf, (size_t)nbytes);      // (a rank that retries is served again, but counted once)
+            } catch (...) { continue; }                // a peer that went away does not end the rendez-vous
+            if (!served_rank[hello[1]]) { served_rank[hello[1]] = 1; served++; }
          }
-         ::close(ls);
       } else {
          addrinfo hints{}; hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
          addrinfo* res = nullptr;

@@ -34,7 +34,8 @@ int exa_bootstrap(int* rank, int* nranks, void* uid128, char* err, int errlen) {
    std::memset(uid128, 0, 128);
    if (*nranks > 1) {
       if (*rank == 0 && exa_rccl_unique_id(uid128) != 0) { set_err(err, errlen, "exa_bootstrap: ncclGetUniqueId failed"); return -1; }
-      if (exa_bootstrap_bcast(*rank, *nranks, uid128, 128, 300.0, err, errlen) != 0) return -1;
+      double tmo = 60.0; if (const char* t = std::getenv("EXA_RENDEZVOUS_TIMEOUT")) { const double v = std::atof(t); if (v > 0) tmo = v; }
+      if (exa_bootstrap_bcast(*rank, *nranks, uid128, 128, tmo, err, errlen) != 0) return -1;
    }
    return 0;
 }

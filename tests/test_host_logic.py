@@ -218,6 +218,8 @@ def test_launcher_bootstrap_rendezvous(style):
     for rank in (2, 1, 0):
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PMI_RANK", "PMI_SIZE", "EXA_RANK", "EXA_NRANKS", "MASTER_PORT", "MASTER_ADDR")}
         env.update({names[0]: str(rank), names[1]: "3", names[2]: str(rank), "EXA_MASTER_PORT": str(port)})
+        if style == "torchrun":
+            env["MASTER_ADDR"] = "127.0.0.1"      # RANK / WORLD_SIZE count only with a rendez-vous address, which torchrun always exports
         procs.append((rank, subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
         if rank == 1:
             time.sleep(0.3)
@@ -236,6 +238,27 @@ def test_bootstrap_without_launcher():
         assert L.exa_bootstrap_env(C.byref(r), C.byref(n), C.byref(l)) == 0 and (r.value, n.value, l.value) == (0, 1, 0)
         os.environ["EXA_RANK"] = "5"; os.environ["EXA_NRANKS"] = "4"
         assert L.exa_bootstrap_env(C.byref(r), C.byref(n), C.byref(l)) != 0      # rank outside the group
+        os.environ.pop("EXA_RANK"); os.environ.pop("EXA_NRANKS")
+        # generic variables that also exist outside a launch do not turn a plain run into rank 0 of N (an sbatch script without srun, a
+        # container that exports WORLD_SIZE): they count only inside an srun step / with a rendez-vous address
+        for extra, want in (({"SLURM_PROCID": "0", "SLURM_NTASKS": "4"}, (0, 1, 0)), ({"SLURM_PROCID": "1", "SLURM_NTASKS": "4", "SLURM_STEP_ID": "0", "SLURM_LOCALID": "1"}, (1, 4, 1)),
+                            ({"RANK": "0", "WORLD_SIZE": "8"}, (0, 1, 0)), ({"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "3", "MASTER_ADDR": "127.0.0.1"}, (3, 8, 3)),
+                            ({"PMI_RANK": "2", "PMI_SIZE": "4", "WORLD_SIZE": "16"}, (2, 4, 2))):      # rank and size from ONE family
+            keep = {k: os.environ.pop(k) for k in ("MASTER_ADDR", "EXA_MASTER_ADDR", "SLURM_STEP_ID") if k in os.environ}
+            os.environ.update(extra)
+            try:
+                assert L.exa_bootstrap_env(C.byref(r), C.byref(n), C.byref(l)) == 0 and (r.value, n.value, l.value) == want, (extra, r.value, n.value, l.value)
+            finally:
+                for k in extra:
+                    os.environ.pop(k, None)
+                os.environ.update(keep)
+        for bad in ({"EXA_RANK": "1", "EXA_NRANKS": "2x"}, {"PMI_RANK": "1"}):      # trailing garbage / half a family
+            os.environ.update(bad)
+            try:
+                assert L.exa_bootstrap_env(C.byref(r), C.byref(n), C.byref(l)) != 0, bad
+            finally:
+                for k in bad:
+                    os.environ.pop(k, None)
     finally:
         os.environ.pop("EXA_RANK", None); os.environ.pop("EXA_NRANKS", None); os.environ.update(saved)
 
