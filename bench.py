@@ -139,17 +139,26 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if os.environ.get("EXA_BENCH_SAME_DEVICE"):   # plumbing check of the multi-rank path on a one-GPU box (all ranks share device 0)
-        local = 0
+    ndev = torch.cuda.device_count()
+    # more ranks than devices (a one-GPU box running `torchrun --nproc-per-node 2 bench.py --gpus 2`): RCCL and torch's nccl backend refuse
+    # two ranks on one device, so torch's group runs on gloo and the library's ranks talk through its shared-device inter-process transport
+    # (plumbing check of the launch path, not a performance configuration; the JSON line says which transport ran)
+    shared = world > ndev or bool(os.environ.get("EXA_BENCH_SAME_DEVICE"))
+    if shared:
+        local = local % max(ndev, 1) if not os.environ.get("EXA_BENCH_SAME_DEVICE") else 0
+        os.environ.setdefault("EXA_TRANSPORT", "ipc")
     torch.cuda.set_device(local)
     uid = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         buf = (C.c_ubyte * 128)()
         if rank == 0:
-            assert L.exa_rccl_unique_id(buf) == 0
-        t = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+            assert L.exa_comm_unique_id(buf, world) == 0
+        t = torch.tensor(list(buf), dtype=torch.uint8, device="cpu" if shared else "cuda")
         dist.broadcast(t, 0)
         uid = (C.c_ubyte * 128)(*t.cpu().tolist())
 
@@ -162,7 +171,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -263,6 +272,7 @@ def main():
     t_pcg_wall = max_over_ranks(time.perf_counter() - t0)
     pcg_ms = max_over_ranks(pc["pcg_ms"]); apply_ms = max_over_ranks(pc["apply_ms"]) / args.pcg_iters
     pcg_it_s = pc["iters"] / (pcg_ms * 1e-3)
+    comm_ranks, comm_transport = drv.comm_info()
     if rank == 0:
         ndof_local = L.exa_driver_local_dofs(drv.h)
         # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench): bytes/qpt x local qpts.  The counter
@@ -321,6 +331,8 @@ def main():
                        "state": (f"real Newton/PCG solve of the reference schedule, {args.solve_steps} steps; timed passes = the converged (last) residual evaluation of step {args.solve_steps}"
                                  if args.solve_steps > 0 else "kinematically driven (10 prescribed-velocity passes)"),
                        "qpts": P_global, "decomposition": f"{world} block(s)"},
+            "comm": {"transport": comm_transport, "ranks_reported_by_transport": comm_ranks,
+                     "note": "rccl: ncclCommCount of the library's communicator; ipc: shared-device inter-process transport (more ranks than devices)"},
             "pcg_iters_per_s": pcg_it_s, "pcg_iters": pc["iters"], "pcg_ms_per_iter": pcg_ms / max(pc["iters"], 1),
             "pcg_wall_s": t_pcg_wall, "nonconverged_points": m["failed"],
             "local_solver_evals": dict(hist_dict(nfev), note="residual/Jacobian evaluations of the 8-unknown point solve per quadrature point (rank 0), last timed pass"),

@@ -2,8 +2,14 @@
 #include "driver.hpp"
 #include "roctx.hpp"
 #include <rccl/rccl.h>
+#include <atomic>
 #include <chrono>
+#include <memory>
+#include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <dlfcn.h>
 #include <link.h>
 #include <algorithm>
@@ -32,6 +38,7 @@ struct RcclApi {
    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -55,6 +62,7 @@ RcclApi& rccl() {
       api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
       api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
       api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+      api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
       api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
       api.Send = (decltype(api.Send))sym("ncclSend");
       api.Recv = (decltype(api.Recv))sym("ncclRecv");
@@ -97,6 +105,89 @@ void Comm::loopback_destroy(const void* id128) {
    LoopbackGroup* g; std::memcpy(&g, (const char*)id128 + 8, sizeof(g)); delete g;
 }
 
+// ---- inter-process transport for ranks that share ONE device (test / plumbing transport, like the loopback group but across processes) -----
+// RCCL refuses two ranks on one device, so `mpirun -np 2 mechanics ...` or `torchrun --nproc-per-node 2 bench.py --gpus 2` could never run
+// end to end on a one-GPU box: launcher environment, TCP rendez-vous, local-rank -> device mapping, per-rank files, torch's communicator
+// beside this library's.  With EXA_TRANSPORT=ipc (or automatically when there are more ranks than visible devices) rank 0 hands out an id
+// of this kind instead of a RCCL id.  Control data lives in a POSIX shared-memory segment named after the id; the halo segments travel
+// device-to-device through hipIpcMemHandle mappings of the neighbours' send buffers; reductions go through the segment in rank order.
+// Exchanges are host-synchronous (stream sync + barrier), so this is NOT a performance path.
+constexpr int IPC_MAX_RANKS = 64, IPC_MAX_NBR = 32, IPC_MAX_RED = 32;
+struct IpcShared {
+   std::atomic<uint32_t> ready; uint32_t n;
+   std::atomic<uint64_t> arrived, generation;
+   double red[IPC_MAX_RANKS][IPC_MAX_RED];
+   hipIpcMemHandle_t sbuf[IPC_MAX_RANKS]; uint64_t sbuf_len[IPC_MAX_RANKS];
+   int32_t nnbr[IPC_MAX_RANKS]; int32_t nbr_rank[IPC_MAX_RANKS][IPC_MAX_NBR]; uint64_t seg_off[IPC_MAX_RANKS][IPC_MAX_NBR + 1];
+};
+struct IpcGroup {
+   IpcShared* sh = nullptr; int n = 0, rank = 0; std::string name;
+   std::vector<double*> peer_sbuf;      // neighbours' send buffers mapped into this process (by rank; nullptr: not a neighbour)
+   void barrier() {
+      const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+      const uint64_t g = sh->generation.load(std::memory_order_acquire);
+      if (sh->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint64_t)n) { sh->arrived.store(0, std::memory_order_release); sh->generation.fetch_add(1, std::memory_order_acq_rel); }
+      else while (sh->generation.load(std::memory_order_acquire) == g) {
+         std::this_thread::yield();
+         if (std::chrono::steady_clock::now() > t_end) throw std::runtime_error("ipc transport: a rank did not reach the barrier within 120 s (did a peer fail?)");
+      }
+   }
+   ~IpcGroup() {
+      for (double* p : peer_sbuf) if (p) (void)hipIpcCloseMemHandle(p);
+      if (sh) ::munmap(sh, sizeof(IpcShared));
+   }
+};
+static const char kIpcMagic[8] = { 'E', 'X', 'A', 'I', 'P', 'C', '0', '1' };
+static std::string ipc_name(const void* uid) {
+   static const char* hex = "0123456789abcdef"; std::string s = "/exaipc_";
+   for (int i = 8; i < 24; i++) { const unsigned char c = ((const unsigned char*)uid)[i]; s += hex[c >> 4]; s += hex[c & 15]; }
+   return s;
+}
+static IpcGroup* ipc_attach(const void* uid, int rank, int nranks) {
+   if (nranks > IPC_MAX_RANKS) throw std::runtime_error("ipc transport: too many ranks");
+   auto g = std::make_unique<IpcGroup>(); g->n = nranks; g->rank = rank; g->name = ipc_name(uid); g->peer_sbuf.assign((size_t)nranks, nullptr);
+   const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(60);
+   int fd = -1;
+   if (rank == 0) {
+      ::shm_unlink(g->name.c_str());
+      fd = ::shm_open(g->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0 || ::ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) throw std::runtime_error(std::string("ipc transport: shm_open ") + g->name + ": " + std::strerror(errno));
+   } else {
+      while ((fd = ::shm_open(g->name.c_str(), O_RDWR, 0600)) < 0) {
+         if (std::chrono::steady_clock::now() > t_end) throw std::runtime_error("ipc transport: rank 0's segment " + g->name + " did not appear");
+         std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      }
+      struct stat st; while (::fstat(fd, &st) == 0 && (size_t)st.st_size < sizeof(IpcShared)) { if (std::chrono::steady_clock::now() > t_end) throw std::runtime_error("ipc transport: segment not sized"); std::this_thread::sleep_for(std::chrono::milliseconds(5)); }
+   }
+   void* m = ::mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+   ::close(fd);
+   if (m == MAP_FAILED) throw std::runtime_error("ipc transport: mmap failed");
+   g->sh = (IpcShared*)m;
+   if (rank == 0) { g->sh->n = (uint32_t)nranks; g->sh->arrived.store(0); g->sh->generation.store(0); g->sh->ready.store(1, std::memory_order_release); }   // (a fresh segment is zero-filled)
+   else while (g->sh->ready.load(std::memory_order_acquire) != 1) { if (std::chrono::steady_clock::now() > t_end) throw std::runtime_error("ipc transport: rank 0 never became ready"); std::this_thread::yield(); }
+   if ((int)g->sh->n != nranks) throw std::runtime_error("ipc transport: group size mismatch");
+   g->barrier();                                   // everybody is attached: the name can go
+   if (rank == 0) ::shm_unlink(g->name.c_str());
+   return g.release();
+}
+void Comm::ipc_unique_id(void* out128) {
+   std::memset(out128, 0, 128); std::memcpy(out128, kIpcMagic, 8);
+   FILE* f = std::fopen("/dev/urandom", "rb");
+   if (!f || std::fread((char*)out128 + 8, 1, 16, f) != 16) { const uint64_t t = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint64_t)::getpid() << 32); std::memcpy((char*)out128 + 8, &t, 8); }
+   if (f) std::fclose(f);
+}
+bool Comm::want_ipc_transport(int nranks) {
+   if (const char* e = std::getenv("EXA_TRANSPORT")) { if (std::string(e) == "ipc") return true; if (std::string(e) == "rccl") return false; }
+   int nd = 0; return nranks > 1 && hipGetDeviceCount(&nd) == hipSuccess && nd > 0 && nranks > nd;      // more ranks than devices: RCCL cannot serve them
+}
+
+int Comm::reported_ranks() const {
+   if (comm_) { int n = 0; nccl_check(rccl().CommCount((ncclComm_t)comm_, &n), "ncclCommCount"); return n; }
+   if (ipc_) return (int)((IpcGroup*)ipc_)->sh->n;
+   if (loop_) return ((LoopbackGroup*)loop_)->n;
+   return 1;
+}
+
 void Comm::get_unique_id(void* out128) { ncclUniqueId id; nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId"); std::memcpy(out128, &id, sizeof(id)); }
 
 void Comm::init(int rank_, int nranks_, const void* uid, bool force_rccl) {
@@ -107,6 +198,8 @@ void Comm::init(int rank_, int nranks_, const void* uid, bool force_rccl) {
       LoopbackGroup* g; std::memcpy(&g, (const char*)uid + 8, sizeof(g));
       if (g->n != nranks) throw std::runtime_error("Comm::init: loopback group size mismatch");
       loop_ = g;
+   } else if (uid && std::memcmp(uid, kIpcMagic, 8) == 0 && nranks > 1) {
+      ipc_ = ipc_attach(uid, rank, nranks);
    } else if (nranks > 1 || force_) {
       ncclUniqueId id;
       if (uid) std::memcpy(&id, uid, sizeof(id));
@@ -118,12 +211,27 @@ void Comm::init(int rank_, int nranks_, const void* uid, bool force_rccl) {
    tmp_.alloc(64);
 }
 Comm::~Comm() {
+   delete (IpcGroup*)ipc_;
    if (comm_) rccl().CommDestroy((ncclComm_t)comm_);
    if (cs_) { (void)hipStreamDestroy(cs_); (void)hipEventDestroy(ev_ready_); (void)hipEventDestroy(ev_done_); }
 }
 
 // op: 0 sum, 1 min, 2 max; host-synchronous, rank-ordered (deterministic)
 void Comm::loopback_reduce(double* dev, int n, int op, hipStream_t s) {
+   if (ipc_) {
+      IpcGroup* g = (IpcGroup*)ipc_;
+      if (n > IPC_MAX_RED) throw std::runtime_error("ipc transport: reduction too long");
+      double mine[IPC_MAX_RED];
+      EXA_HC(hipMemcpyAsync(mine, dev, sizeof(double) * n, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+      for (int i = 0; i < n; i++) g->sh->red[rank][i] = mine[i];
+      g->barrier();
+      double r[IPC_MAX_RED];
+      for (int i = 0; i < n; i++) r[i] = g->sh->red[0][i];
+      for (int k = 1; k < g->n; k++) for (int i = 0; i < n; i++) { const double v = g->sh->red[k][i]; r[i] = op == 0 ? r[i] + v : (op == 1 ? std::min(r[i], v) : std::max(r[i], v)); }
+      g->barrier();   // everybody has read before the next reduction overwrites
+      EXA_HC(hipMemcpyAsync(dev, r, sizeof(double) * n, hipMemcpyHostToDevice, s)); EXA_HC(hipStreamSynchronize(s));
+      return;
+   }
    LoopbackGroup* g = (LoopbackGroup*)loop_;
    std::vector<double>& mine = g->red[rank]; mine.resize(n);
    EXA_HC(hipMemcpyAsync(mine.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
@@ -134,17 +242,17 @@ void Comm::loopback_reduce(double* dev, int n, int op, hipStream_t s) {
    EXA_HC(hipMemcpyAsync(dev, r.data(), sizeof(double) * n, hipMemcpyHostToDevice, s)); EXA_HC(hipStreamSynchronize(s));
 }
 void Comm::allreduce_sum(double* dev, int n, hipStream_t s) {
-   if (loop_) { if (nranks > 1) loopback_reduce(dev, n, 0, s); return; }
+   if (loop_ || ipc_) { if (nranks > 1) loopback_reduce(dev, n, 0, s); return; }
    if (nranks > 1 || force_) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)comm_, s), "ncclAllReduce");
 }
 void Comm::allreduce_min(double* dev, int n, hipStream_t s) {
-   if (loop_) { if (nranks > 1) loopback_reduce(dev, n, 1, s); return; }
+   if (loop_ || ipc_) { if (nranks > 1) loopback_reduce(dev, n, 1, s); return; }
    if (nranks > 1 || force_) nccl_check(rccl().AllReduce(dev, dev, n, ncclDouble, ncclMin, (ncclComm_t)comm_, s), "ncclAllReduce");
 }
 
 double Comm::max_over_ranks(double v) {
    if (nranks == 1) return v;
-   if (loop_) { EXA_HC(hipMemcpy(tmp_.p, &v, sizeof(double), hipMemcpyHostToDevice)); loopback_reduce(tmp_.p, 1, 2, nullptr); EXA_HC(hipMemcpy(&v, tmp_.p, sizeof(double), hipMemcpyDeviceToHost)); return v; }
+   if (loop_ || ipc_) { EXA_HC(hipMemcpy(tmp_.p, &v, sizeof(double), hipMemcpyHostToDevice)); loopback_reduce(tmp_.p, 1, 2, nullptr); EXA_HC(hipMemcpy(&v, tmp_.p, sizeof(double), hipMemcpyDeviceToHost)); return v; }
    EXA_HC(hipMemcpy(tmp_.p, &v, sizeof(double), hipMemcpyHostToDevice));
    nccl_check(rccl().AllReduce(tmp_.p, tmp_.p, 1, ncclDouble, ncclMax, (ncclComm_t)comm_, nullptr), "ncclAllReduce");
    EXA_HC(hipMemcpy(&v, tmp_.p, sizeof(double), hipMemcpyDeviceToHost));
@@ -181,6 +289,21 @@ void Comm::setup_halo(const Partition& part) {
    for (const Neighbor& nb : part.nbrs) { all.insert(all.end(), nb.dofs.begin(), nb.dofs.end()); seg_off_.push_back(all.size()); }
    idx_all_.release(); sbuf_all_.release(); rbuf_all_.release();
    if (!all.empty()) { idx_all_.alloc(all.size()); idx_all_.upload(all); sbuf_all_.alloc(all.size()); rbuf_all_.alloc(all.size()); }
+   if (ipc_) {   // publish this rank's send buffer and segment table, then map the neighbours' send buffers
+      IpcGroup* g = (IpcGroup*)ipc_; IpcShared* sh = g->sh;
+      if (part.nbrs.size() > (size_t)IPC_MAX_NBR) throw std::runtime_error("ipc transport: too many neighbours");
+      for (double*& p : g->peer_sbuf) if (p) { (void)hipIpcCloseMemHandle(p); p = nullptr; }
+      sh->nnbr[rank] = (int32_t)part.nbrs.size(); sh->sbuf_len[rank] = all.size();
+      for (size_t i = 0; i < part.nbrs.size(); i++) { sh->nbr_rank[rank][i] = part.nbrs[i].rank; sh->seg_off[rank][i] = seg_off_[i]; }
+      sh->seg_off[rank][part.nbrs.size()] = seg_off_.back();
+      if (!all.empty()) EXA_HC(hipIpcGetMemHandle(&sh->sbuf[rank], sbuf_all_.p));
+      g->barrier();
+      for (const Neighbor& nb : part.nbrs) if (!g->peer_sbuf[nb.rank]) {
+         void* p = nullptr; EXA_HC(hipIpcOpenMemHandle(&p, sh->sbuf[nb.rank], hipIpcMemLazyEnablePeerAccess));
+         g->peer_sbuf[nb.rank] = (double*)p;
+      }
+      g->barrier();
+   }
 }
 
 void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
@@ -213,6 +336,20 @@ void Comm::exchange(const Partition& part, hipStream_t s) {
    auto sb = [&](size_t i) { return sbuf_all_.p + seg_off_[i]; };
    auto rb = [&](size_t i) { return rbuf_all_.p + seg_off_[i]; };
    auto cnt = [&](size_t i) { return seg_off_[i + 1] - seg_off_[i]; };
+   if (ipc_) {
+      IpcGroup* g = (IpcGroup*)ipc_; const IpcShared* sh = g->sh;
+      EXA_HC(hipStreamSynchronize(s));      // my send buffer is packed
+      g->barrier();                         // ... and so is everybody else's
+      for (size_t i = 0; i < nb; i++) {     // my slot i talks to rank r; r's slot that talks to me holds what I receive (same dof order on both sides)
+         const int r = part.nbrs[i].rank; int k = -1;
+         for (int j = 0; j < sh->nnbr[r]; j++) if (sh->nbr_rank[r][j] == rank) { k = j; break; }
+         if (k < 0 || sh->seg_off[r][k + 1] - sh->seg_off[r][k] != cnt(i)) throw std::runtime_error("ipc halo: asymmetric neighbour lists");
+         EXA_HC(hipMemcpyAsync(rb(i), g->peer_sbuf[r] + sh->seg_off[r][k], sizeof(double) * cnt(i), hipMemcpyDeviceToDevice, s));
+      }
+      EXA_HC(hipStreamSynchronize(s));
+      g->barrier();                         // nobody repacks its send buffer before everybody has read it
+      return;
+   }
    if (loop_) {
       LoopbackGroup* g = (LoopbackGroup*)loop_;
       g->sendbuf[rank].resize(nb); g->nbr_rank[rank].resize(nb);

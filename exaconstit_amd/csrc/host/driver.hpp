@@ -27,6 +27,11 @@ class Comm {
    // force_rccl: run the RCCL calls on a one-rank communicator too (what EXA_FORCE_RCCL=1 selects from the environment)
    void init(int rank_, int nranks_, const void* nccl_unique_id /*128 bytes, identical on all ranks*/, bool force_rccl = false);
    static void get_unique_id(void* out128);
+   // inter-process transport for ranks that share a device (driver.hip): an id of that kind, and whether this launch needs it
+   static void ipc_unique_id(void* out128);
+   static bool want_ipc_transport(int nranks);
+   int reported_ranks() const;            // what the transport itself says (ncclCommCount for RCCL)
+   const char* transport() const { return ipc_ ? "ipc" : (loop_ ? "loopback" : (comm_ ? "rccl" : "none")); }
    // in-process loopback transport for tests: several ranks (one host thread each) on ONE device, host-synchronous exchanges
    static void loopback_create(int nranks, void* out128);
    static void loopback_destroy(const void* id128);
@@ -47,7 +52,7 @@ class Comm {
  private:
    void unpack(double* y, hipStream_t s);
    void loopback_reduce(double* dev, int n, int op, hipStream_t s);
-   void* comm_ = nullptr; void* loop_ = nullptr; bool force_ = false;
+   void* comm_ = nullptr; void* loop_ = nullptr; void* ipc_ = nullptr; bool force_ = false;
    DevBuf<int32_t> idx_all_; DevBuf<double> sbuf_all_, rbuf_all_; std::vector<size_t> seg_off_{ 0 };   // concatenated neighbour segments
    DevBuf<double> tmp_;
    hipStream_t cs_ = nullptr; hipEvent_t ev_ready_ = nullptr, ev_done_ = nullptr;   // communication stream of halo_begin / halo_end

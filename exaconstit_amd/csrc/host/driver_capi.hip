@@ -33,7 +33,7 @@ int exa_bootstrap(int* rank, int* nranks, void* uid128, char* err, int errlen) {
    if (hipSetDevice(lr % nd) != hipSuccess) { set_err(err, errlen, "exa_bootstrap: hipSetDevice failed"); return -1; }
    std::memset(uid128, 0, 128);
    if (*nranks > 1) {
-      if (*rank == 0 && exa_rccl_unique_id(uid128) != 0) { set_err(err, errlen, "exa_bootstrap: ncclGetUniqueId failed"); return -1; }
+      if (*rank == 0 && exa_comm_unique_id(uid128, *nranks) != 0) { set_err(err, errlen, "exa_bootstrap: ncclGetUniqueId failed"); return -1; }
       double tmo = 60.0; if (const char* t = std::getenv("EXA_RENDEZVOUS_TIMEOUT")) { const double v = std::atof(t); if (v > 0) tmo = v; }
       if (exa_bootstrap_bcast(*rank, *nranks, uid128, 128, tmo, err, errlen) != 0) return -1;
    }
@@ -52,6 +52,21 @@ int exa_rccl_microbench(int iters, int n, double* out2, char* err, int errlen) {
 
 int exa_rccl_unique_id(void* out128) {
    try { Comm::get_unique_id(out128); return 0; } catch (const std::exception& e) { std::fprintf(stderr, "exa_rccl_unique_id: %s\n", e.what()); return -1; }
+}
+
+// the id rank 0 hands out for a group of `nranks`: a RCCL unique id, or - when the ranks have to share devices (more ranks than visible
+// devices, or EXA_TRANSPORT=ipc) - the id of the inter-process transport of host/driver.hip (class Comm)
+int exa_comm_unique_id(void* out128, int nranks) {
+   try { if (Comm::want_ipc_transport(nranks)) Comm::ipc_unique_id(out128); else Comm::get_unique_id(out128); return 0; }
+   catch (const std::exception& e) { std::fprintf(stderr, "exa_comm_unique_id: %s\n", e.what()); return -1; }
+}
+// out2 = { ranks the transport itself reports (ncclCommCount for RCCL), kind: 0 none (one rank), 1 rccl, 2 ipc (shared device), 3 in-process loopback }
+int exa_driver_comm_info(exa_driver* d, int* out2) {
+   try {
+      const Comm& c = d->sd->comm; const std::string t = c.transport();
+      out2[0] = c.reported_ranks(); out2[1] = t == "rccl" ? 1 : (t == "ipc" ? 2 : (t == "loopback" ? 3 : 0));
+      return 0;
+   } catch (const std::exception& e) { std::fprintf(stderr, "exa_driver_comm_info: %s\n", e.what()); return -1; }
 }
 
 int exa_loopback_group_create(int nranks, void* out128) { try { Comm::loopback_create(nranks, out128); return 0; } catch (...) { return -1; } }

@@ -145,6 +145,8 @@ class ExaSynthConfig(C.Structure):
 
 
 exa_rccl_unique_id = _sig("exa_rccl_unique_id", C.c_int, C.c_void_p)
+exa_comm_unique_id = _sig("exa_comm_unique_id", C.c_int, C.c_void_p, C.c_int)
+exa_driver_comm_info = _sig("exa_driver_comm_info", C.c_int, C.c_void_p, C.POINTER(C.c_int))
 exa_loopback_group_create = _sig("exa_loopback_group_create", C.c_int, C.c_int, C.c_void_p)
 exa_loopback_group_destroy = _sig("exa_loopback_group_destroy", None, C.c_void_p)
 exa_driver_create = _sig("exa_driver_create", C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int)
@@ -267,6 +269,12 @@ class Driver:
         h = np.zeros(64, dtype=np.int32)
         self._chk(exa_driver_nfev_hist_of(self.h, which, h.ctypes.data_as(C.POINTER(C.c_int)), self._err, 512))
         return h
+
+    def comm_info(self):
+        """(rank count the transport reports - ncclCommCount for RCCL -, transport name)"""
+        o = (C.c_int * 2)()
+        assert exa_driver_comm_info(self.h, o) == 0
+        return int(o[0]), ("none", "rccl", "ipc", "loopback")[o[1]]
 
     def reset_timers(self):
         exa_driver_reset_timers(self.h)

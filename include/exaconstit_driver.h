@@ -30,6 +30,11 @@ typedef struct {
 } exa_synth_config;
 
 int exa_rccl_unique_id(void* out128);
+/* the id rank 0 hands to a group of nranks: a RCCL unique id, or the id of the inter-process shared-device transport when RCCL cannot serve
+ * the launch (more ranks than visible devices - RCCL refuses two ranks on one device - or EXA_TRANSPORT=ipc).  bench.py and exa_bootstrap use it. */
+int exa_comm_unique_id(void* out128, int nranks);
+/* out2 = { rank count the transport itself reports (ncclCommCount for RCCL), kind: 0 none, 1 rccl, 2 ipc, 3 in-process loopback } */
+int exa_driver_comm_info(exa_driver* d, int* out2);
 /* latency floor of the RCCL calls of one PCG iteration on this device (one-rank communicator): out2 = { us per 16-byte all-reduce,
  * us per grouped send/recv of n doubles to the own rank } */
 int exa_rccl_microbench(int iters, int n, double* out2, char* err, int errlen);

@@ -18,15 +18,20 @@ def main():
     import torch
     import exaconstit_amd.lib as L
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    ndev = torch.cuda.device_count()
+    shared = world > ndev                 # more ranks than devices: RCCL (and torch's nccl backend) refuse two ranks on one device
+    torch.cuda.set_device(local % ndev)
     uid = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         buf = (C.c_ubyte * 128)()
         if rank == 0:
-            assert L.exa_rccl_unique_id(buf) == 0
-        t = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+            assert L.exa_comm_unique_id(buf, world) == 0      # a RCCL id, or the id of the shared-device inter-process transport
+        t = torch.tensor(list(buf), dtype=torch.uint8, device="cpu" if shared else "cuda")
         dist.broadcast(t, 0)
         uid = (C.c_ubyte * 128)(*t.cpu().tolist())
     d = L.Driver.from_toml(toml, out_dir=os.path.dirname(out), rank=rank, nranks=world, uid=uid, jacobi=jacobi, write_files=False)
@@ -35,9 +40,10 @@ def main():
         ok = ok and d.step(ti)
     s = d.avgs(0, 6)
     newton, krylov, calls = d.stats()
+    comm_ranks, transport = d.comm_info()
     if rank == 0:
         with open(out, "w") as f:
-            json.dump(dict(ok=bool(ok), world=world, forced=bool(os.environ.get("EXA_FORCE_RCCL")), avg_stress=s.tolist(),
+            json.dump(dict(ok=bool(ok), world=world, comm_ranks=comm_ranks, transport=transport, forced=bool(os.environ.get("EXA_FORCE_RCCL")), avg_stress=s.tolist(),
                            newton=[int(x) for x in newton], krylov=[int(x) for x in krylov]), f)
     d.close()
     if world > 1:

@@ -60,11 +60,9 @@ def test_executable_under_mpirun_one_rank(tmp_path):
     _check_against_golden(tmp_path, "mtsdd_bcc")
 
 
-def test_executable_two_ranks_over_rccl(tmp_path):
-    """The reference's regression command line, `mpirun -np 2 mechanics -opt voce_pa.toml` (test/test_mechanics.py:38): needs two GPUs."""
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+def test_executable_two_ranks(tmp_path):
+    """The reference's regression command line, `mpirun -np 2 mechanics -opt voce_pa.toml` (test/test_mechanics.py:38).  Two GPUs: RCCL; one
+    GPU: both ranks map to device 0 and exa_bootstrap hands out the id of the shared-device inter-process transport instead of a RCCL id."""
     mpirun = _mpirun()
     toml = _stage(tmp_path, "voce_pa")
     env = dict(os.environ, EXA_MASTER_PORT="29533")

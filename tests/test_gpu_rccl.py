@@ -2,8 +2,8 @@
 src/mechanics_driver.cpp:312, src/system_driver.cpp:167, src/mechanics_kernels.hpp:119,124) on hardware.
   * one GPU: EXA_FORCE_RCCL=1 runs every RCCL call on a one-rank communicator (the loopback tests of test_gpu_multirank.py cover the
     partition logic, this covers the library calls);
-  * two or more GPUs: a torchrun-launched 2-rank run against the one-rank run (skipped on a one-GPU box; the driver's 8-GPU
-    scaling run uses the same path through bench.py)."""
+  * a torchrun-launched 2-rank run against the one-rank run: over RCCL with two or more GPUs, through the shared-device inter-process
+    transport on a one-GPU box (the driver's 8-GPU scaling run uses the same launch path through bench.py)."""
 import json
 import os
 import subprocess
@@ -45,14 +45,35 @@ def test_forced_rccl_on_one_rank(oracle, tmp_path, case, jacobi):
     assert all(abs(x - y) <= max(3, 0.03 * x) for x, y in zip(plain["krylov"], forced["krylov"]))
 
 
-def test_two_ranks_over_rccl(oracle, tmp_path):
+def test_two_ranks_two_processes(oracle, tmp_path):
+    """torchrun --nproc-per-node 2: two processes, TCP rendez-vous of torch beside this library's communicator, per-rank device mapping.  With
+    two GPUs the ranks talk over RCCL; on a one-GPU box RCCL refuses the second rank on the device, and the same launch goes through the
+    shared-device inter-process transport (POSIX shared memory + hipIpcMemHandle, host/driver.hip) - every line but the RCCL calls, which
+    test_forced_rccl_on_one_rank covers."""
     import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device); the one-GPU box covers the calls through EXA_FORCE_RCCL")
     n = 5
     one = _worker(tmp_path, "one", "voce_pa", n)
     two = _worker(tmp_path, "two", "voce_pa", n, nproc=2)
-    assert one["ok"] and two["ok"] and two["world"] == 2
+    assert one["ok"] and two["ok"] and two["world"] == 2 and two["comm_ranks"] == 2
+    assert two["transport"] == ("rccl" if torch.cuda.device_count() >= 2 else "ipc")
     a, b = np.array(one["avg_stress"]), np.array(two["avg_stress"])
     assert np.max(np.abs(a - b)) < 1e-9 * np.abs(a).max()
     assert one["newton"] == two["newton"]
+
+
+def test_bench_two_ranks_under_torchrun(tmp_path):
+    """The driver's scaling launch line, `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`, with N = 2: torch's process
+    group and the library's own communicator side by side, max-over-ranks timing, one JSON line from rank 0 that names the transport and the
+    rank count the transport itself reports (ncclCommCount over RCCL; the shared-device transport on a one-GPU box)."""
+    import torch
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, EXA_BENCH_N="32", EXA_BENCH_SOLVE_STEPS="3"); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the driver's line carries no size flags)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29573",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["comm"]["ranks_reported_by_transport"] == 2
+    assert d["comm"]["transport"] == ("rccl" if torch.cuda.device_count() >= 2 else "ipc")
+    assert d["nonconverged_points"] == 0 and d["value"] > 0 and d["newton_pcg_solve"]["steps"] == 3
