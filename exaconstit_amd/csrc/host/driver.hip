@@ -487,7 +487,12 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    // is the A/B switch.  part.E_bdr > 0 only after Partition::order_boundary_first (SystemDriver).
    {
       const bool ea_rec = opt.assembly == Assembly::EA && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1");
-      overlap_ = fast_p1_ && lvec_grad_ && !det && part.E_bdr > 0 && !part.nbrs.empty() && (opt.assembly == Assembly::PA || ea_rec) && !env_is_off("EXA_HALO_OVERLAP");
+      // Over RCCL the overlapped form is OPT-IN (EXA_HALO_OVERLAP=on) until a run on two or more GPUs has passed with it: it issues the grouped
+      // send/recv on a second stream of the communicator that carries the PCG all-reduces, and no box with two devices has been available to
+      // this repo yet (the shared-device transports exercise the stream / event choreography, not RCCL's two-stream behaviour)
+      const char* ho = std::getenv("EXA_HALO_OVERLAP");
+      const bool want = ho ? std::string(ho) != "off" && std::string(ho) != "0" : std::string(comm.transport()) != "rccl";
+      overlap_ = fast_p1_ && lvec_grad_ && !det && part.E_bdr > 0 && !part.nbrs.empty() && (opt.assembly == Assembly::PA || ea_rec) && want;
       nblk_bdr_ = (part.E_bdr + 63) / 64;
    }
 }
@@ -692,12 +697,16 @@ void NonlinearMechOperator::GradMult(const double* x, double* y, bool constraine
       // blocks that touch shared nodes, exchange of the shared dofs on the communication stream, interior blocks meanwhile, unpack last
       const uint8_t* m = constrained ? ess_mask.p : nullptr;
       const int nball = (E_ + 63) / 64;
-      abi_check(ctx_, exa_grad_apply_lvec_blocks(ctx_, x, y, m, done_flag, 0, nblk_bdr_, stream_), "exa_grad_apply_lvec_blocks");
-      comm_.halo_begin(part_, y, stream_);
-      abi_check(ctx_, exa_grad_apply_lvec_blocks(ctx_, x, y, m, done_flag, nblk_bdr_, nball - nblk_bdr_, stream_), "exa_grad_apply_lvec_blocks");
-      comm_.halo_end(part_, y, stream_);
-      if (constrained && !skip_out_mask) vk_mask_zero(nd_, ess_mask.p, y, stream_);
-      return;
+      const int rc0 = exa_grad_apply_lvec_blocks(ctx_, x, y, m, done_flag, 0, nblk_bdr_, stream_);
+      if (rc0 == EXA_ERR_UNSUPPORTED) overlap_ = false;   // the context cannot run block ranges (nothing has been added to y): whole action + halo_sum from now on
+      else {
+         abi_check(ctx_, rc0, "exa_grad_apply_lvec_blocks");
+         comm_.halo_begin(part_, y, stream_);
+         abi_check(ctx_, exa_grad_apply_lvec_blocks(ctx_, x, y, m, done_flag, nblk_bdr_, nball - nblk_bdr_, stream_), "exa_grad_apply_lvec_blocks");
+         comm_.halo_end(part_, y, stream_);
+         if (constrained && !skip_out_mask) vk_mask_zero(nd_, ess_mask.p, y, stream_);
+         return;
+      }
    }
    if (lvec_grad_) abi_check(ctx_, exa_grad_apply_lvec_gated(ctx_, x, y, constrained ? ess_mask.p : nullptr, done_flag, stream_), "exa_grad_apply_lvec");
    else {   // generic-order partial assembly: mask, L->E, AddMultGradPA, E->L (spec reference src/mechanics_operator_ext.cpp:143-157)

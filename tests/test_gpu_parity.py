@@ -4,8 +4,8 @@ Tolerances (FP64 everywhere; north star: stress within 1e-6 rel-L2 of the CPU re
   stress / state / velocity gradient : rel-L2 <= 1e-9   (both sides converge the same 8x8 point problem to 1e-10 scaled)
   tangent                            : rel-L2 <= 1e-7
   integrator actions                 : rel-L2 <= 1e-12  (pure linear algebra)
-The function-evaluation counter (state slot 3) depends on branch decisions of the trust-region solver at rounding level and
-is excluded.
+The function-evaluation counter (state slot 3) follows the iteration path: it must agree with the oracle at >= 99.9 % of the points and
+never differ by more than one (include/exaconstit_hip.h, state layout; measured: profiles/r04_nfev_agreement.txt).
 """
 import ctypes as C
 
