@@ -62,6 +62,12 @@ exa_ctx* exa_create(const exa_config* cfg, int* err) {
    ctx->nstatev = ecmdev::NSTATEV;
    if (cfg->device >= 0) { if (hipSetDevice(cfg->device) != hipSuccess) { delete ctx; set(EXA_ERR_HIP); return nullptr; } }
    if (hipGetDevice(&ctx->device) != hipSuccess) { std::fprintf(stderr, "exa_create: no HIP device available\n"); delete ctx; set(EXA_ERR_HIP); return nullptr; }
+   if (ecmdev::kin_is_km(ctx->mp.kin) && (ctx->mp.p != 1.0 || ctx->mp.q != 1.0)) {
+      // the one reference-held vector that exercises this regime (test/data/mtsdd_full_auto_stress.txt) is not reproduced by the CPU restatement
+      // the kernels are checked against: say so once per process instead of running silently
+      static bool told = false;
+      if (!told) { told = true; std::fprintf(stderr, "exaconstit_hip: Kocks-Mecking kinetics with p = %g, q = %g: the regime p, q != 1 is not pinned to a reference vector (DESIGN.md section 5)\n", ctx->mp.p, ctx->mp.q); }
+   }
    exa_build_ref_elem(ctx->p, ctx->G_host, ctx->W_host);
    bool ok = true;
    ok = ok && hipMalloc(&ctx->G_dev, sizeof(double) * ctx->G_host.size()) == hipSuccess;

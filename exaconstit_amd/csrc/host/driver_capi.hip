@@ -99,6 +99,12 @@ exa_driver* exa_driver_create_synthetic(const exa_synth_config* c, int rank, int
       // uniaxial z-tension with three symmetry planes (reference test/data/voce_pa.toml [BCs])
       BCEntry bc; bc.step = 1; bc.ids = { 1, 2, 3, 4 }; bc.comps = { 3, 1, 2, 3 }; bc.vals = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, c->vz };
       opt.bcs.push_back(bc);
+      double vz = c->vz;
+      for (int i = 0; i < c->nrev; i++) {   // cyclic loading (reference test/data/voce_full_cyclic.toml: changing_ess_bcs with update_steps)
+         vz = -vz;
+         BCEntry rb = bc; rb.step = c->rev_steps[i]; rb.vals.back() = vz;
+         opt.bcs.push_back(rb);
+      }
       std::vector<double> props(c->props, c->props + c->nprops);
       const size_t Eg = (size_t)c->N * c->N * c->N;
       std::vector<double> quats(c->quats, c->quats + 4 * Eg);

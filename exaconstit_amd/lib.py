@@ -141,7 +141,8 @@ class ExaSynthConfig(C.Structure):
                 ("temp_k", C.c_double), ("quats", C.POINTER(C.c_double)), ("assembly", C.c_int), ("nrls", C.c_int), ("jacobi", C.c_int),
                 ("newton_iter", C.c_int), ("newton_rel", C.c_double), ("newton_abs", C.c_double),
                 ("krylov_iter", C.c_int), ("krylov_rel", C.c_double), ("krylov_abs", C.c_double),
-                ("nsteps", C.c_int), ("dts", C.POINTER(C.c_double)), ("vz", C.c_double), ("order", C.c_int), ("bbar", C.c_int)]
+                ("nsteps", C.c_int), ("dts", C.POINTER(C.c_double)), ("vz", C.c_double), ("order", C.c_int), ("bbar", C.c_int),
+                ("nrev", C.c_int), ("rev_steps", C.POINTER(C.c_int))]
 
 
 exa_rccl_unique_id = _sig("exa_rccl_unique_id", C.c_int, C.c_void_p)
@@ -199,14 +200,15 @@ class Driver:
 
     @classmethod
     def synthetic(cls, N, props, quats, dts, bcc=False, slip=0, temp_k=298.0, assembly=0, nrls=False, jacobi=False,
-                  newton=(25, 5e-5, 5e-10), krylov=(1000, 1e-7, 1e-27), vz=1.0e-3, rank=0, nranks=1, uid=None, order=1, bbar=False):
+                  newton=(25, 5e-5, 5e-10), krylov=(1000, 1e-7, 1e-27), vz=1.0e-3, rank=0, nranks=1, uid=None, order=1, bbar=False, reversals=()):
         import numpy as np
         props = np.ascontiguousarray(props, dtype=np.float64)
         quats = np.ascontiguousarray(quats, dtype=np.float64)
         dts = np.ascontiguousarray(dts, dtype=np.float64)
         dp = C.POINTER(C.c_double)
         cfg = ExaSynthConfig(N, int(bcc), slip, len(props), props.ctypes.data_as(dp), temp_k, quats.ctypes.data_as(dp), assembly, int(nrls),
-                             int(jacobi), newton[0], newton[1], newton[2], krylov[0], krylov[1], krylov[2], len(dts), dts.ctypes.data_as(dp), vz, order, int(bbar))
+                             int(jacobi), newton[0], newton[1], newton[2], krylov[0], krylov[1], krylov[2], len(dts), dts.ctypes.data_as(dp), vz, order, int(bbar),
+                             len(reversals), (C.c_int * max(len(reversals), 1))(*[int(r) for r in reversals]))
         err = C.create_string_buffer(512)
         h = exa_driver_create_synthetic(C.byref(cfg), rank, nranks, uid, err, 512)
         return cls(h, err)

@@ -27,6 +27,8 @@ typedef struct {
    double vz;                  /* z-velocity of the top face */
    int order;                  /* H1 order p (1 or 2; 0 = 1) */
    int bbar;                   /* 1: B-bar integrator (element assembly only) */
+   int nrev; const int* rev_steps;   /* load reversals: the top-face velocity changes sign at these steps (the cyclic schedule of the reference's
+                                * voce_full_cyclic.toml: update_steps 11, 31, 51, 71); each one is a boundary-condition change with its corrector solve */
 } exa_synth_config;
 
 int exa_rccl_unique_id(void* out128);

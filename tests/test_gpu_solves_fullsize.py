@@ -24,7 +24,8 @@ def _props(orc):
     return np.loadtxt(os.path.join(orc.REFDATA, "props_cp_voce.txt")).ravel()
 
 
-def _run(L, N, props, quats, nranks=1, **kw):
+def _run(L, N, props, quats, nranks=1, dts=None, **kw):
+    DTS = globals()["DTS"] if dts is None else np.asarray(dts, dtype=np.float64)
     gid = None
     if nranks > 1:
         gid = (C.c_ubyte * 128)()
@@ -107,6 +108,27 @@ def test_config5_64_p2_bbar_ea_eight_ranks(oracle):
     r1 = _run(L, N, props, quats, **kw)
     r8 = _run(L, N, props, quats, nranks=8, **kw)
     _same_run(r1, r8, 1e-6)
+
+
+def test_config5_as_written_through_the_first_reversal(oracle):
+    """BASELINE config 5 as written: 64^3 triquadratic elements, B-bar integrator, element assembly, NRLS, the cyclic schedule of the reference's
+    test/data/voce_full_cyclic.toml (dt = 0.1, sign of the top-face velocity flips at step 11: a boundary-condition change with its SolveInit
+    corrector) through the first load reversal and the elastic unloading that follows - 13 steps, one rank against eight (loopback) ranks:
+    same Newton history, averages to 1e-6, no failed point, and the stress really turns around."""
+    import exaconstit_amd.lib as L
+    N = 64
+    props = _props(oracle); quats = hipref.random_quats(N ** 3).ravel()
+    kw = dict(order=2, bbar=True, assembly=1, nrls=True, dts=[0.1] * 13, reversals=(11,))
+    r1 = _run(L, N, props, quats, **kw)
+    r8 = _run(L, N, props, quats, nranks=8, **kw)
+    _same_run(r1, r8, 1e-6)
+    szz = r1["avgs"][0][:, 2]
+    assert len(szz) == 13 and np.all(np.diff(szz[:10]) > 0) and szz[9] > 0.03      # loading into the plastic regime (GPa)
+    assert szz[10] < szz[9] and szz[12] < szz[10]                                   # unloading after the reversal
+    d = r1["diag"][0]
+    print("config 5 as written (64^3 p=2 B-bar EA NRLS, 13 steps, reversal at 11): newton", list(r1["stats"][0][0]), "krylov", list(r1["stats"][0][1]),
+          "sigma_zz", [float("%.5g" % v) for v in szz], "pcg solves at the cap:", d["pcg_not_converged"], "worst reduction at the cap: %.2e" % d["pcg_worst_capped_reduction"])
+    assert d["pcg_not_converged"] == 0 or d["pcg_worst_capped_reduction"] < 1e-2
 
 
 @pytest.mark.parametrize("bcc", [True, False])
