@@ -1107,6 +1107,56 @@ ECM_DI void km_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[
    }
 }
 
+// the same for the athermal-threshold (BCC) kernel, organised like its evaluation: cheap classes of all 12 systems with static indices (one
+// exponential per drag-limited system), then one window system per lane and pass, inserted into the 12 slots (ECM_KM_GDOT_GA; the grouped
+// form above pays the window phases in nearly every group of this variant)
+#ifndef ECM_KM_GDOT_GA
+#define ECM_KM_GDOT_GA 1
+#endif
+template <bool PQ1, bool SC>
+ECM_DI void km_slip_rates_ga(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out) {
+   const double ks[5] = { mp.pk0 * e_f[0], mp.pk1 * e_f[1], mp.pk2 * e_f[2], mp.pk2 * e_f[3], mp.pk2 * e_f[4] };
+   const double g_ia = 1.0 / mp.tau_a, gAth = pb.kv.g, wi = 1.0 / mp.wrD;
+   double tau[NSLIP], gd[NSLIP], xr[NSLIP];
+   slip_tau12(ks, tau);
+   unsigned pend = 0; bool any_drag = false;
+#pragma unroll
+   for (int a = 0; a < NSLIP; a++) {
+      const double at = fabs(tau[a]);
+      xr[a] = (at - gAth) * wi;
+      const bool live = (tau[a] != 0.0) && (xr[a] > 0.0), over = fmax(0.0, at - gAth) * g_ia > mp.t_max;
+      gd[a] = 0.0;
+      if (live && !over) pend |= 1u << a;
+      if (!(live && over)) xr[a] = -1.0; else any_drag = true;
+   }
+   if (any_drag) {
+      double exv[NSLIP];
+#pragma unroll
+      for (int a = 0; a < NSLIP; a++) exv[a] = -fmax(xr[a], 0.0);
+      exp_n<NSLIP, PQ1, SC>(exv);
+#pragma unroll
+      for (int a = 0; a < NSLIP; a++) {
+         const bool small = xr[a] < EPS_SQRT;
+         const double gr = small ? pb.kv.gam_r * xr[a] : pb.kv.gam_r * (1.0 - exv[a]);
+         if (xr[a] >= 0.0) gd[a] = copysign(gr, tau[a]);
+      }
+   }
+   while (__ballot(pend != 0) != 0ull) {
+      if (pend != 0) {
+         const int a = __ffs((int)pend) - 1; pend &= pend - 1;
+         double t1 = 0.0;
+#pragma unroll
+         for (int s2 = 0; s2 < NSLIP; s2++) t1 = (a == s2) ? tau[s2] : t1;
+         double tau1[1] = { t1 }, gd1[1];
+         kmbald_gdot4<false, 1, PQ1, SC>(mp, pb.kv, tau1, gd1, nullptr);
+#pragma unroll
+         for (int s2 = 0; s2 < NSLIP; s2++) gd[s2] = (a == s2) ? gd1[0] : gd[s2];
+      }
+   }
+#pragma unroll
+   for (int a = 0; a < NSLIP; a++) stg(&gdot_out[a * pb.gs], gd[a]);
+}
+
 // ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
 ECM_DI void load_tr(const Jac& J, double Tr[9]) { for (int c = 0; c < 9; c++) Tr[c] = J.Tr[c]; }
 ECM_DI void load_dl(const Jac& J, double d[5]) { for (int c = 0; c < 5; c++) d[c] = J.dl[c]; }
@@ -1589,7 +1639,11 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
       double eNew = ECM_CD(CD_ENEW);
       eNew += 0.25 * (ECM_CD(CD_VOLD) + vNew) * dt * (ECM_CD(CD_WRKOLD) + wrk_new);
       if constexpr (!kin_is_km(KIN)) voce_slip_rates<kin_xn_ct(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS, dis_rate, shrate);
-      else if (ECM_KM_GDOT_AT_END) km_slip_rates<kin_pq1(KIN), kin_sc_exp(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS);
+      else if (ECM_KM_GDOT_AT_END) {
+         // (the runtime flag is always set in this instantiation, see eval_rj; only the p == q == 1 kernel has the factored forms of the evaluation)
+         if (ECM_KM_GDOT_GA && kin_base(KIN) == KIN_KMBALD_GA && kin_pq1(KIN) && mp.with_g_athermal) km_slip_rates_ga<kin_pq1(KIN), kin_sc_exp(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS);
+         else km_slip_rates<kin_pq1(KIN), kin_sc_exp(KIN)>(mp, pb, e_f, sv1 + H_GDOT * QS);
+      }
       stg(&sv1[(H_SHRATE) * QS], shrate);
       stg(&sv1[(H_SHR) * QS], (ECM_EPI_NO_LOADS ? ECM_ST(st, ST_PB + PB_SHR0) : ldg(&sv0[(H_SHR) * QS])) + shrate * dt);
       stg(&sv1[(H_FLOW) * QS], ((deff_keep > TINY_SQRT) ? dis_rate * dt : 0.0) + (ECM_EPI_NO_LOADS ? ECM_ST(st, ST_PB + PB_FLOW0) : ldg(&sv0[(H_FLOW) * QS])));   // accumulated plastic work
