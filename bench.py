@@ -140,27 +140,30 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     ndev = torch.cuda.device_count()
-    # more ranks than devices (a one-GPU box running `torchrun --nproc-per-node 2 bench.py --gpus 2`): RCCL and torch's nccl backend refuse
-    # two ranks on one device, so torch's group runs on gloo and the library's ranks talk through its shared-device inter-process transport
-    # (plumbing check of the launch path, not a performance configuration; the JSON line says which transport ran)
-    shared = world > ndev or bool(os.environ.get("EXA_BENCH_SAME_DEVICE"))
-    if shared:
-        local = local % max(ndev, 1) if not os.environ.get("EXA_BENCH_SAME_DEVICE") else 0
-        os.environ.setdefault("EXA_TRANSPORT", "ipc")
+    local = local % max(ndev, 1)          # (a launcher that shows every rank one device numbers it 0)
     torch.cuda.set_device(local)
-    uid = None
+    uid = None; shared = False
     if world > 1:
+        # torch's group only carries the barrier, the max-over-ranks of the wall time and the 128-byte id: host-side data, so it runs on gloo
+        # and cannot interfere with the library's own RCCL communicator (which carries every collective of the solve).  The ranks compare
+        # the identity of their devices: one rank per physical GPU -> RCCL over xGMI; several ranks on one GPU (a one-GPU box running
+        # `torchrun --nproc-per-node 2 bench.py --gpus 2`) -> the library's shared-device inter-process transport, since RCCL refuses two
+        # ranks on one device (plumbing check of the launch path, not a performance configuration; the JSON line names the transport)
+        import socket
         import torch.distributed as dist
-        if shared:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("gloo")
+        pr = torch.cuda.get_device_properties(local)
+        ident = (socket.gethostname(), str(getattr(pr, "uuid", "")), getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", -1), getattr(pr, "pci_domain_id", -1))
+        ids = [None] * world
+        dist.all_gather_object(ids, ident)
+        shared = len(set(ids)) < world or bool(os.environ.get("EXA_BENCH_SAME_DEVICE"))
+        os.environ["EXA_TRANSPORT"] = "ipc" if shared else "rccl"
         buf = (C.c_ubyte * 128)()
         if rank == 0:
             assert L.exa_comm_unique_id(buf, world) == 0
-        t = torch.tensor(list(buf), dtype=torch.uint8, device="cpu" if shared else "cuda")
+        t = torch.tensor(list(buf), dtype=torch.uint8)
         dist.broadcast(t, 0)
-        uid = (C.c_ubyte * 128)(*t.cpu().tolist())
+        uid = (C.c_ubyte * 128)(*t.tolist())
 
     def barrier():
         torch.cuda.synchronize()
@@ -171,7 +174,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if shared else "cuda")
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 

@@ -649,6 +649,9 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #ifndef ECM_KM_PEND_INSERT
 #define ECM_KM_PEND_INSERT 1   // athermal-threshold Kocks-Mecking kernel, factored-forms path: window systems inserted into the per-system arrays (eval_rj; A/B switch)
 #endif
+#ifndef ECM_TANGENT_WX
+#define ECM_TANGENT_WX 1   // tangent block as (Q5 Kt)(S^-1 Q5^T) with the rotated coupling through the equivariance of M35 (point_update; A/B switch)
+#endif
 #ifndef ECM_TANGENT_FIRST
 #define ECM_TANGENT_FIRST 1   // epilogue order: tangent before the state / stress outputs (see point_update)
 #endif
@@ -1664,6 +1667,191 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
 #ifndef ECM_NO_TANGENT
    // ---- tangent (last: it overwrites the parking area): lattice-frame d sigma'/d D' by implicit differentiation on the converged
    // factorisation, rotated to the sample frame, then to Voigt (engineering shear) + bulk term, column-major
+   // Two forms of the same arithmetic: the W X form (ECM_TANGENT_WX) for the Voce kinds - 170 multiply-adds fewer, 4.62 -> 4.30 ms at 128^3 - and the
+   // round-3 chain for the Kocks-Mecking kinds, whose register allocation the W X form upsets (BCC p = q = 1: 4 -> 37 spills)
+   if constexpr (ECM_TANGENT_WX != 0 && !kin_is_km(KIN))
+   {
+      // J [xe; xr] = [e_c; 0] with Jee = M Kd, Jre = B Kd, Jer = -E (E = M35(d_lat) Tr), xr eliminated exactly:
+      //   y = Kd xe,  (M + E G) y = e_c,  G = Jrr^-1 B,  xr = -G y   =>   Llat = (I/J + M35(s') Tr G) (M + E G)^-1
+      // explicit 5x5 rotation of deviatoric 5-vectors (columns = images of the unit vectors)
+      double Q5[5][5];
+#pragma unroll
+      for (int l = 0; l < 5; l++) {
+         double e[5] = { 0, 0, 0, 0, 0 }, out[5]; e[l] = 1.0;
+         rot_vecd(Cf, e, out);
+#pragma unroll
+         for (int k = 0; k < 5; k++) Q5[k][l] = out[k];
+      }
+      double D55[5][5];   // sample-frame deviatoric tangent block (times dt)
+      // (Voce kinds only: in the Kocks-Mecking kernels the W X form costs registers they do not have - BCC 4 -> 37 spills, elastic pass 3.4 -> 4.1 ms)
+      constexpr bool WX = true;
+      double Llat[WX ? 1 : 5][5];
+      bool okT;
+      {
+         double Ri[9]; okT = rot_block_inverse(pb, J, Ri);
+         // G <- Tr Jrr^-1 B: both couplings enter as M35(.) Tr G, so Tr is folded into G once (27 + 45 multiply-adds) instead of into each M35
+         double G[3][5];
+         {
+            double Tr[9]; load_tr(J, Tr);
+            double TRi[9];
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+#pragma unroll
+               for (int i = 0; i < 3; i++) TRi[3 * m + i] = Tr[3 * m] * Ri[i] + Tr[3 * m + 1] * Ri[3 + i] + Tr[3 * m + 2] * Ri[6 + i];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+               for (int j = 0; j < 5; j++) G[i][j] = TRi[3 * i] * J.B[0][j] + TRi[3 * i + 1] * J.B[1][j] + TRi[3 * i + 2] * J.B[2][j];
+         }
+         double S[5][5];
+         {
+            double dl[5]; load_dl(J, dl);
+            double Md[5][3]; m35(dl, Md);
+            const double kdi0 = pb.dt_ri * mp.ikd0, kdi2 = pb.dt_ri * mp.ikd2;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+#pragma unroll
+               for (int j = 0; j < 5; j++) S[k][j] = J.A[sidx(k, j)] + ((k == j) ? (k < 2 ? kdi0 : kdi2) : 0.0) + Md[k][0] * G[0][j] + Md[k][1] * G[1][j] + Md[k][2] * G[2][j];
+            }
+         }
+         // un-pivoted LU of S (M is SPD and dominates the O(|D| dt) coupling), then Y = S^-1 column by column
+#pragma unroll
+         for (int k = 0; k < 5; k++) {
+            okT = okT && (S[k][k] > 0.0);
+            const double inv = frcp(S[k][k]);
+            S[k][k] = inv;
+#pragma unroll
+            for (int i = k + 1; i < 5; i++) {
+               const double l = S[i][k] * inv; S[i][k] = l;
+#pragma unroll
+               for (int j = k + 1; j < 5; j++) S[i][j] -= l * S[k][j];
+            }
+         }
+         if constexpr (WX) {
+         // D55 = Q5 Llat Q5^T = (Q5 Kt) (S^-1 Q5^T) =: W X.  W = detV_ri Q5 + M35(s_sm) (Cf G): the map w -> vecd(S W - W S) is equivariant under the
+         // rotation (Q5 M35(s) w = M35(Q5 s) (Cf w)), so the rotated coupling costs 45 + 65 multiply-adds instead of 75 + 125; X is five
+         // forward / backward substitutions with the columns of Q5^T as right-hand sides.  375 + 110 multiply-adds where the chain
+         // S^-1 -> Kt S^-1 -> Q5 (.) -> (.) Q5^T took 555 (same numbers in another order of summation)
+         {
+            double CG[3][5];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+               for (int j = 0; j < 5; j++) CG[i][j] = Cf[3 * i] * G[0][j] + Cf[3 * i + 1] * G[1][j] + Cf[3 * i + 2] * G[2][j];
+            double s_sm5[5]; rot_vecd(Cf, s_lat, s_sm5);
+            double Mr[5][3]; m35(s_sm5, Mr);
+            double Wm[5][5], X[5][5];
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+               for (int j = 0; j < 5; j++) Wm[k][j] = fma(detV_ri, Q5[k][j], Mr[k][0] * CG[0][j] + Mr[k][1] * CG[1][j] + Mr[k][2] * CG[2][j]);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {       // column c of X = S^-1 (row c of Q5)
+               double y[5];
+#pragma unroll
+               for (int i = 0; i < 5; i++) { double t = Q5[c][i]; for (int j = 0; j < i; j++) t -= S[i][j] * y[j]; y[i] = t; }
+#pragma unroll
+               for (int i = 4; i >= 0; i--) { double t = y[i]; for (int j = i + 1; j < 5; j++) t -= S[i][j] * y[j]; y[i] = t * S[i][i]; }
+#pragma unroll
+               for (int l = 0; l < 5; l++) X[l][c] = y[l];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+               for (int c = 0; c < 5; c++) D55[k][c] = Wm[k][0] * X[0][c] + Wm[k][1] * X[1][c] + Wm[k][2] * X[2][c] + Wm[k][3] * X[3][c] + Wm[k][4] * X[4][c];
+         }
+         } else {
+         double Kt[5][5];   // detV_ri I + M35(s_lat) (Tr G)
+         {
+            double Ms[5][3]; m35(s_lat, Ms);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+#pragma unroll
+               for (int j = 0; j < 5; j++) Kt[k][j] = ((k == j) ? detV_ri : 0.0) + Ms[k][0] * G[0][j] + Ms[k][1] * G[1][j] + Ms[k][2] * G[2][j];
+            }
+         }
+#pragma unroll
+         for (int c = 0; c < 5; c++) {
+            double y[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) {       // forward: L y = e_c (entries above c stay zero)
+               double t = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+               for (int j = c; j < i; j++) t -= S[i][j] * y[j];
+               y[i] = (i < c) ? 0.0 : t;
+            }
+#pragma unroll
+            for (int i = 4; i >= 0; i--) {      // backward: U y = y
+               double t = y[i];
+#pragma unroll
+               for (int j = i + 1; j < 5; j++) t -= S[i][j] * y[j];
+               y[i] = t * S[i][i];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) Llat[k][c] = Kt[k][0] * y[0] + Kt[k][1] * y[1] + Kt[k][2] * y[2] + Kt[k][3] * y[3] + Kt[k][4] * y[4];
+         }
+               }
+      }
+      if constexpr (!WX) {  // D55 = Q5 Llat Q5^T
+         double T1[5][5];
+#pragma unroll
+         for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) { double v = 0; for (int l = 0; l < 5; l++) v += Q5[k][l] * Llat[l][c]; T1[k][c] = v; }
+#pragma unroll
+         for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) { double v = 0; for (int l = 0; l < 5; l++) v += T1[k][l] * Q5[c][l]; D55[k][c] = v; }
+      }
+      if constexpr (REC) {
+         const double rsc = ECM_CD(CD_TSC);
+         const double dsc = rsc * pb.dt_ri * (okT ? 1.0 : 0.0);
+         double Dm[26];
+#pragma unroll
+         for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) Dm[k + 5 * c] = D55[k][c] * dsc;
+         if (trd) {
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+               for (int c = k + 1; c < 5; c++) { const double v = Dm[k + 5 * c]; Dm[k + 5 * c] = Dm[c + 5 * k]; Dm[c + 5 * k] = v; }
+         }
+         Dm[25] = bulkNew * rsc;
+         double2* rc = reinterpret_cast<double2*>(cmat);
+#ifdef ECM_EXP_TAN_NOSTORE   // timing experiment: the tangent arithmetic without its 13 record stores (one store of a checksum keeps it alive)
+         { double a = 0.0, b = 0.0; for (int pr = 0; pr < 13; pr++) { a += Dm[2 * pr]; b += Dm[2 * pr + 1]; } rc[0] = make_double2(a, b); }
+#else
+#pragma unroll
+         for (int pr = 0; pr < 13; pr++) rc[pr * 64] = make_double2(Dm[2 * pr], Dm[2 * pr + 1]);
+#endif
+      } else {
+      const double dti = pb.dt_ri * (okT ? 1.0 : 0.0);
+      double T2a[5][6];   // D55 S56 / dt  (d_vecd = S56 eps_svec(eng. shear) / dt)
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+         const double* D = D55[k];
+         T2a[k][0] = (SQR2I * D[0] - SQR6I * D[1]) * dti;
+         T2a[k][1] = (-SQR2I * D[0] - SQR6I * D[1]) * dti;
+         T2a[k][2] = (2.0 * SQR6I * D[1]) * dti;
+         T2a[k][3] = (SQR2I * D[4]) * dti;
+         T2a[k][4] = (SQR2I * D[3]) * dti;
+         T2a[k][5] = (SQR2I * D[2]) * dti;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+         double T2[5];
+#pragma unroll
+         for (int k = 0; k < 5; k++) T2[k] = T2a[k][j];
+         const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
+         const double bk = (j < 3) ? bulkNew : 0.0;
+         // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[(i + 6 j) * QS]
+         stg(&cmat[(0 + 6 * j) * QS], t1 - t2 + bk); stg(&cmat[(1 + 6 * j) * QS], -t1 - t2 + bk); stg(&cmat[(2 + 6 * j) * QS], SQR2B3 * T2[1] + bk);
+         stg(&cmat[(3 + 6 * j) * QS], SQR2I * T2[4]); stg(&cmat[(4 + 6 * j) * QS], SQR2I * T2[3]); stg(&cmat[(5 + 6 * j) * QS], SQR2I * T2[2]);
+      }
+      }
+   }
+   else
    {
       // J [xe; xr] = [e_c; 0] with Jee = M Kd, Jre = B Kd, Jer = -E (E = M35(d_lat) Tr), xr eliminated exactly:
       //   y = Kd xe,  (M + E G) y = e_c,  G = Jrr^-1 B,  xr = -G y   =>   Llat = (I/J + M35(s') Tr G) (M + E G)^-1
