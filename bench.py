@@ -152,8 +152,8 @@ def main():
         import socket
         import torch.distributed as dist
         dist.init_process_group("gloo")
-        pr = torch.cuda.get_device_properties(local)
-        ident = (socket.gethostname(), str(getattr(pr, "uuid", "")), getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", -1), getattr(pr, "pci_domain_id", -1))
+        pci = C.create_string_buffer(64)
+        ident = (socket.gethostname(), pci.value.decode() if L.exa_device_identity(pci, 64) == 0 else f"device-index-{local}-of-{ndev}")
         ids = [None] * world
         dist.all_gather_object(ids, ident)
         shared = len(set(ids)) < world or bool(os.environ.get("EXA_BENCH_SAME_DEVICE"))

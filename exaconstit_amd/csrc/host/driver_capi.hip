@@ -54,6 +54,13 @@ int exa_rccl_unique_id(void* out128) {
    try { Comm::get_unique_id(out128); return 0; } catch (const std::exception& e) { std::fprintf(stderr, "exa_rccl_unique_id: %s\n", e.what()); return -1; }
 }
 
+// PCI bus id ("0000:c1:00.0") of the calling thread's current device: what the launchers compare to tell one rank per physical GPU from several
+// ranks on one GPU, whatever device numbering each rank sees
+int exa_device_identity(char* out, int len) {
+   int dev = 0;
+   if (!out || len < 16 || hipGetDevice(&dev) != hipSuccess) return -1;
+   return hipDeviceGetPCIBusId(out, len, dev) == hipSuccess ? 0 : -1;
+}
 // the id rank 0 hands out for a group of `nranks`: a RCCL unique id, or - when the ranks have to share devices (more ranks than visible
 // devices, or EXA_TRANSPORT=ipc) - the id of the inter-process transport of host/driver.hip (class Comm)
 int exa_comm_unique_id(void* out128, int nranks) {

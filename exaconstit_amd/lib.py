@@ -147,6 +147,7 @@ class ExaSynthConfig(C.Structure):
 
 exa_rccl_unique_id = _sig("exa_rccl_unique_id", C.c_int, C.c_void_p)
 exa_comm_unique_id = _sig("exa_comm_unique_id", C.c_int, C.c_void_p, C.c_int)
+exa_device_identity = _sig("exa_device_identity", C.c_int, C.c_char_p, C.c_int)
 exa_driver_comm_info = _sig("exa_driver_comm_info", C.c_int, C.c_void_p, C.POINTER(C.c_int))
 exa_loopback_group_create = _sig("exa_loopback_group_create", C.c_int, C.c_int, C.c_void_p)
 exa_loopback_group_destroy = _sig("exa_loopback_group_destroy", None, C.c_void_p)

@@ -35,6 +35,8 @@ int exa_rccl_unique_id(void* out128);
 /* the id rank 0 hands to a group of nranks: a RCCL unique id, or the id of the inter-process shared-device transport when RCCL cannot serve
  * the launch (more ranks than visible devices - RCCL refuses two ranks on one device - or EXA_TRANSPORT=ipc).  bench.py and exa_bootstrap use it. */
 int exa_comm_unique_id(void* out128, int nranks);
+/* PCI bus id of the current device ("0000:c1:00.0"): lets a launcher tell one rank per physical GPU from several ranks on one GPU */
+int exa_device_identity(char* out, int len);
 /* out2 = { rank count the transport itself reports (ncclCommCount for RCCL), kind: 0 none, 1 rccl, 2 ipc, 3 in-process loopback } */
 int exa_driver_comm_info(exa_driver* d, int* out2);
 /* latency floor of the RCCL calls of one PCG iteration on this device (one-rank communicator): out2 = { us per 16-byte all-reduce,
