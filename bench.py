@@ -345,19 +345,21 @@ def main():
                          "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS,
                          "traffic": traffic["k_model_setup"] * P_local if "k_model_setup" in traffic else None, "traffic_source": traffic.get("_file"), "kernel_build_id": kid,
                          "bytes_per_qpt": MODEL_BYTES_PER_QPT, "avg_kernel_ms": kern_ms,
-                         "bytes_written_per_qpt_note": ("this launch writes the 26-number gradient record instead of the 36 tangent entries (848 B/qpt moved; "
-                                                        "AssembleGradPA fused in); frac stays priced at SURVEY 8(d)'s 928 B/qpt") if records else None,
+                         "bytes_written_per_qpt_note": ("this launch writes the 26-number gradient record instead of the 36 tangent entries (AssembleGradPA fused in)") if records else None,
                          "fp64_flop_per_qpt": flops, "fp64_tflops": (flops * P_local / (kern_ms * 1e-3) / 1e12) if flops else None,
                          "fp64_vector_frac": (flops * P_local / (kern_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TFLOPS) if flops else None,
                          # FP64 issue roofline: a wave64 FP64 VALU instruction occupies its SIMD for 4 cycles (16 FMA lanes per clock and SIMD = the
                          # 78.6 TFLOP/s vector peak); issue time = instructions per wave x 4 cycles x waves per SIMD / 2.4 GHz
                          "fp64_issue": ({"valu_insts_per_wave": valu_per_wave, "ms_at_full_issue": valu_per_wave * 4.0 * (P_local / 64.0 / 1024.0) / 2.4e9 * 1e3,
                                          "frac": valu_per_wave * 4.0 * (P_local / 64.0 / 1024.0) / 2.4e9 * 1e3 / kern_ms} if valu_per_wave else None),
-                         "note": "the contract's HBM fraction of the ALGORITHMIC bytes (928 B/qpt) is reported in frac; the launch itself is bound by FP64 VALU "
-                                 "issue: SQ counters (profiles/r03_sq_fcc_voce.txt) show the VALU busy 85 % of the wave cycles at 7 660 VALU instructions per wave "
-                                 "(10 709 at the start of round 3, profiles/r03_kernel_experiments.txt), and the chip sustains ~1.85 GHz under this FP64 load, not the "
-                                 "nominal 2.4 GHz the fp64_issue figures are priced at; traffic = L2-boundary bytes from the PMC passes of THIS kernel instantiation "
-                                 "(profiles/r03_pmc_traffic.json; null when not measured for the model); roofline_pcg_apply is the HBM-bound half of the metric"},
+                         "bytes_moved_per_qpt_note": "by construction the launch moves 648 B/qpt (read ~6 velocity / coordinate, 15 state, 6 stress doubles; write 28 state, 6 stress, "
+                                                      "26 record doubles: no Jacobian field, effective shear rate from state slot 0); frac stays priced at SURVEY 8(d)'s 928 B/qpt",
+                         "note": "the contract's HBM fraction of the ALGORITHMIC bytes (928 B/qpt) is reported in frac; the launch is bound by FP64 VALU issue at the clock "
+                                 "the chip sustains at its 1 400 W package limit (~1.93 GHz, not the nominal 2.4 GHz the fp64_issue figures are priced at): SQ counters "
+                                 "(profiles/r04_sq_fcc_voce.txt) show the VALU busy 87 % of the wave cycles, 6 984 VALU instructions per wave of which 6 086 FP64 arithmetic, "
+                                 "no scratch (7 660 instructions / 100 B at the end of round 3, profiles/r04_kernel_experiments.txt); traffic = L2-boundary bytes from the PMC "
+                                 "passes of THIS kernel build and instantiation (profiles/*_pmc_traffic.json with the library's kernel_build_id; null otherwise); "
+                                 "roofline_pcg_apply is the HBM-bound half of the metric"},
             "roofline_pcg_apply": {"kernel": ("k_ea_apply_p1 (element mat-vec)" if ea_streamed else "k_grad_apply_p1<LVEC,GEO,CMP> (AddMultGradPA / matrix-free element-assembly action + gather/scatter)"), "bound": "hbm",
                                    "achieved": moved * P_local / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": moved * P_local / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
