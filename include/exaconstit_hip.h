@@ -36,6 +36,23 @@ enum { EXA_ASSEMBLY_PA = 0, EXA_ASSEMBLY_EA = 1 };
 enum { EXA_INTEG_FULL = 0, EXA_INTEG_BBAR = 1 };
 
 enum { EXA_OK = 0, EXA_ERR_ARG = -1, EXA_ERR_HIP = -2, EXA_ERR_STATE = -3, EXA_ERR_UNSUPPORTED = -4 };
+/* Which entry points are legal in which context (everything else returns EXA_ERR_UNSUPPORTED with a message in exa_last_error):
+ *
+ *   route                         layout   entry points                                                               orders / integrators
+ *   ----------------------------  -------  -------------------------------------------------------------------------  ----------------------------------
+ *   A  E-vector (MFEM adapters)   AOS      exa_jacobians[_from_geom], exa_model_setup, exa_residual_setup/apply,      p = 1..6, full and B-bar (B-bar:
+ *                                          exa_grad_setup, exa_grad_apply, exa_grad_diagonal, exa_grad_get_ea,        element assembly only, like the
+ *                                          exa_restrict / exa_restrict_transpose_add, exa_calc_dp, exa_vol_avg        reference)
+ *   B  fused L-vector             AOS or   A's set-up calls + exa_set_connectivity, exa_model_setup_lvec,             p = 1 full integration; p = 2 full
+ *                                 EB64     exa_residual_lvec, exa_grad_apply_lvec (PA, EA from matrices or - with     and B-bar (EB64: L-vector entries
+ *                                          exa_set_ea_matrix_free - from the point records), exa_grad_set_coords,     only, exa_residual_setup/apply stay
+ *                                          exa_set_tangent_form                                                       AOS); p >= 3: exa_grad_apply_lvec
+ *                                                                                                                     for element assembly only
+ *   C  record route (driver)      EB64     exa_model_setup_lvec_records + exa_grad_set_coords + exa_grad_apply_lvec   p = 1 full integration, PA or
+ *                                          + exa_residual_lvec (Jacobian field optional)                              matrix-free EA, compact tangent form
+ *
+ *   exa_set_deterministic: ordered sums for route B / C at p = 1 full integration; elsewhere the fused entries refuse and route A + exa_restrict_transpose_add is
+ *   the reproducible path.  An adapter that does not care about any of this uses route A and never sees EXA_ERR_UNSUPPORTED. */
 
 typedef struct {
    int model;            /* EXA_* model id */
@@ -183,10 +200,10 @@ int exa_grad_tangent_defect(exa_ctx* ctx, const double* ddsdde_dev, double* defe
  * 24 x 24) or 52 KB (p = 2, 81 x 81) per element.  Built for p = 1 full integration and for p = 2 (plain and B-bar); other
  * contexts keep the assembled path.  The matrices themselves are assembled on the first call that needs them (exa_grad_apply on
  * E-vectors, exa_grad_diagonal, exa_grad_get_ea).  Default: off. */
+int exa_set_ea_matrix_free(exa_ctx* ctx, int on);
 /* self-test hook (tests/test_gpu_point_fixtures.py): the Kocks-Mecking kinetics' own exp and near-1 log evaluated on the device,
  * out[0..n) = exp(x), out[n..2n) = log(x) (the latter meaningful for x in [0.75, 1.25]); no context needed */
 int exa_selftest_km_math(const double* x_dev, double* out_dev, int n, exa_stream s);
-int exa_set_ea_matrix_free(exa_ctx* ctx, int on);
 /* Bit-reproducible E->L sums (reference: mfem::ElementRestriction::MultTranspose; the fused kernels here scatter with FP64 atomics, whose
  * order - and therefore the last bits of the L-vector, and from there every CG iterate - changes from run to run).  With `on` != 0
  * exa_residual_lvec, exa_grad_apply_lvec (partial assembly and element assembly from the point records) and exa_restrict_transpose_add
