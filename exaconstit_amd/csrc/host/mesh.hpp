@@ -16,6 +16,8 @@
 #include <vector>
 #include <algorithm>
 
+void exa_gll_nodes_01(int np, std::vector<double>& x);   // host_tables.cpp
+
 namespace exa_host {
 
 struct Neighbor { int rank; std::vector<int32_t> dofs; };   // local dof = node + NN * comp, identical order on both sides
@@ -81,6 +83,7 @@ struct Partition {
       conn.resize((size_t)n * E); X.resize((size_t)3 * NN); elem_gid.resize(E); weight.resize(NN);
       const std::vector<int> nat = native_order(p);
       const int np = p + 1;
+      std::vector<double> gll; exa_gll_nodes_01(np, gll);
       for (int k = 0; k < ne[2]; k++) for (int j = 0; j < ne[1]; j++) for (int i = 0; i < ne[0]; i++) {
          const int e = i + ne[0] * (j + ne[1] * k);
          elem_gid[e] = (int64_t)(e0[0] + i) + (int64_t)N[0] * ((e0[1] + j) + (int64_t)N[1] * (e0[2] + k));
@@ -89,8 +92,11 @@ struct Partition {
       }
       for (int k = 0; k < nn[2]; k++) for (int j = 0; j < nn[1]; j++) for (int i = 0; i < nn[0]; i++) {
          const int g = i + nn[0] * (j + nn[1] * k);
-         const int gi[3] = { e0[0] * p + i, e0[1] * p + j, e0[2] * p + k };   // equispaced nodes (p <= 2: identical to Gauss-Lobatto)
-         for (int d = 0; d < 3; d++) X[g + (size_t)NN * d] = len[d] * gi[d] / (N[d] * p);
+         const int gi[3] = { e0[0] * p + i, e0[1] * p + j, e0[2] * p + k };   // nodes of an element at the Gauss-Lobatto points of the H1 basis
+         for (int d = 0; d < 3; d++) {
+            const int ge = std::min(gi[d] / p, N[d] - 1), a = gi[d] - ge * p;
+            X[g + (size_t)NN * d] = len[d] * (ge + gll[a]) / N[d];
+         }
          int mult = 1;
          for (int d = 0; d < 3; d++) {
             const int li = (d == 0 ? i : (d == 1 ? j : k));

@@ -213,7 +213,7 @@ struct ExaOptions {
          if (!nc || !ln || nc->arr.size() != 3 || ln->arr.size() != 3) throw std::runtime_error("Must input mesh geometry/discretization for hex_mesh_gen");
          for (int i = 0; i < 3; i++) { ncuts[i] = (int)nc->arr[i].num; length[i] = ln->arr[i].num; }
       } else throw std::runtime_error("Mesh.type must be \"auto\", \"other\" or \"cubit\"");
-      if (order != 1 && order != 2) throw std::runtime_error("Only p_refinement = 1 or 2 is built");
+      if (order < 1 || order > 6) throw std::runtime_error("p_refinement must be between 1 and 6");
    }
 };
 

@@ -28,14 +28,25 @@ void gl_rule(int np, std::vector<double>& x, std::vector<double>& w) {
    }
 }
 
+// Gauss-Lobatto-Legendre points on [0, 1]: the end points and the roots of P'_{np-1} (MFEM's H1 default, BasisType::GaussLobatto);
+// Newton from the Chebyshev-Lobatto points, (1 - z^2) P'_n = n (P_{n-1} - z P_n), (1 - z^2) P''_n = 2 z P'_n - n (n + 1) P_n.
 void gll_nodes(int np, std::vector<double>& x) {
-   x.resize(np);
-   if (np == 2) { x[0] = 0; x[1] = 1; }
-   else if (np == 3) { x[0] = 0; x[1] = 0.5; x[2] = 1; }
-   else if (np == 4) { const double a = 0.5 / std::sqrt(5.0); x[0] = 0; x[1] = 0.5 - a; x[2] = 0.5 + a; x[3] = 1; }
-   else for (int i = 0; i < np; i++) x[i] = 0.5 * (1.0 - std::cos(M_PI * i / (np - 1)));
+   x.assign(np, 0.0);
+   const int n = np - 1;
+   x[n] = 1.0;
+   for (int i = 1; 2 * i <= n; i++) {
+      double z = -std::cos(M_PI * i / n);
+      for (int it = 0; it < 100; it++) {
+         double p0 = 1.0, p1 = z;
+         for (int k = 2; k <= n; k++) { const double p2 = ((2.0 * k - 1.0) * z * p1 - (k - 1.0) * p0) / k; p0 = p1; p1 = p2; }
+         const double om = 1.0 - z * z, d1 = n * (p0 - z * p1) / om, d2 = (2.0 * z * d1 - n * (n + 1.0) * p1) / om;
+         const double dz = d1 / d2; z -= dz;
+         if (std::fabs(dz) < 1e-16) break;
+      }
+      if (2 * i == n) z = 0.0;
+      x[i] = 0.5 * (1.0 + z); x[n - i] = 0.5 * (1.0 - z);
+   }
 }
-
 void lagrange(const std::vector<double>& xn, double x, std::vector<double>& v, std::vector<double>& d) {
    const int np = (int)xn.size();
    v.assign(np, 0.0); d.assign(np, 0.0);
@@ -71,6 +82,8 @@ std::vector<int> native_order(int p) {
 }
 
 }  // namespace
+
+void exa_gll_nodes_01(int np, std::vector<double>& x) { gll_nodes(np, x); }
 
 void exa_build_ref_elem(int p, std::vector<double>& G, std::vector<double>& W) {
    const int np = p + 1, n = np * np * np, Q = n;

@@ -55,11 +55,37 @@ inline void gauss_legendre_01(int np, double* x, double* w) {
    }
 }
 
+// Gauss-Lobatto-Legendre points on [0, 1] (MFEM's H1 nodes, BasisType::GaussLobatto): closed forms up to four points; beyond, the interior
+// points are the roots of P'_n (n = np - 1), bisected between consecutive roots of P_n (which they interlace), with P'_k from the
+// recurrence P'_{k+1} = P'_{k-1} + (2k + 1) P_k.
+inline double legendre_deriv(int n, double z, double* pn = nullptr) {
+   double pkm1 = 1.0, pk = z, dkm1 = 0.0, dk = 1.0;      // P_0, P_1, P'_0, P'_1
+   if (n == 0) { if (pn) *pn = 1.0; return 0.0; }
+   for (int k = 1; k < n; k++) {
+      const double pkp1 = ((2.0 * k + 1.0) * z * pk - k * pkm1) / (k + 1.0);
+      const double dkp1 = dkm1 + (2.0 * k + 1.0) * pk;
+      pkm1 = pk; pk = pkp1; dkm1 = dk; dk = dkp1;
+   }
+   if (pn) *pn = pk;
+   return dk;
+}
 inline void gauss_lobatto_01(int np, double* x) {
-   if (np == 2) { x[0] = 0; x[1] = 1; }
-   else if (np == 3) { x[0] = 0; x[1] = 0.5; x[2] = 1; }
-   else if (np == 4) { const double a = 0.5 / std::sqrt(5.0); x[0] = 0; x[1] = 0.5 - a; x[2] = 0.5 + a; x[3] = 1; }
-   else { for (int i = 0; i < np; i++) x[i] = 0.5 * (1.0 - std::cos(M_PI * i / (np - 1))); }   // (not GLL beyond p=3; self-consistent only)
+   if (np == 2) { x[0] = 0; x[1] = 1; return; }
+   if (np == 3) { x[0] = 0; x[1] = 0.5; x[2] = 1; return; }
+   if (np == 4) { const double a = 0.5 / std::sqrt(5.0); x[0] = 0; x[1] = 0.5 - a; x[2] = 0.5 + a; x[3] = 1; return; }
+   const int n = np - 1;
+   std::vector<double> xg(n), wg(n); gauss_legendre_01(n, xg.data(), wg.data());      // roots of P_n on [0, 1], ascending
+   x[0] = 0.0; x[n] = 1.0;
+   for (int i = 1; i < n; i++) {
+      double lo = 2.0 * xg[i - 1] - 1.0, hi = 2.0 * xg[i] - 1.0, flo = legendre_deriv(n, lo);
+      for (int it = 0; it < 200; it++) {
+         const double mid = 0.5 * (lo + hi), fm = legendre_deriv(n, mid);
+         if ((fm < 0) == (flo < 0)) { lo = mid; flo = fm; } else hi = mid;
+         if (hi - lo < 1e-17) break;
+      }
+      x[i] = 0.5 * (1.0 + 0.5 * (lo + hi));
+   }
+   for (int i = 1; 2 * i <= n; i++) { const double s = 0.5 * (x[i] + (1.0 - x[n - i])); x[i] = s; x[n - i] = 1.0 - s; }
 }
 
 // 1-D Lagrange basis on nodes xn evaluated at x: value and derivative

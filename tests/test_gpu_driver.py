@@ -112,9 +112,11 @@ def _variant_toml(tmp_path, base, edits, tag):
 
 
 @pytest.mark.parametrize("p,assembly,integ,nrls,ref_ser", [(2, "PA", "FULL", False, 0), (2, "EA", "FULL", False, 0),
-                                                           (1, "EA", "BBAR", True, 1), (2, "EA", "BBAR", True, 0)])
+                                                           (1, "EA", "BBAR", True, 1), (2, "EA", "BBAR", True, 0),
+                                                           (3, "PA", "FULL", False, 0), (3, "EA", "BBAR", True, 0)])
 def test_gpu_driver_order2_bbar_matches_oracle(oracle, tmp_path, p, assembly, integ, nrls, ref_ser):
-    """BASELINE config 5 ingredients (p = 2, B-bar, EA, NRLS) on the small regression mesh: GPU driver vs CPU oracle."""
+    """BASELINE config 5 ingredients (p = 2, B-bar, EA, NRLS) on the small regression mesh: GPU driver vs CPU oracle; and the same through the
+    run-time-order kernels at p = 3 (nodes at the Gauss-Lobatto points, as MFEM's H1 basis has them)."""
     import exaconstit_amd.lib as L
     orc = oracle
     n = 4
@@ -133,6 +135,24 @@ def test_gpu_driver_order2_bbar_matches_oracle(oracle, tmp_path, p, assembly, in
     assert np.linalg.norm(s[:, 2:] - ref["avg_stress"][:, 2:]) / np.linalg.norm(ref["avg_stress"][:, 2:]) < 1e-6
     newton, krylov, calls = d.stats()
     assert list(newton) == list(ref["newton_iters"])
+
+
+def test_gpu_driver_order4_pa_equals_ea(oracle, tmp_path):
+    """p_refinement = 4 through the option file: partial assembly and element assembly are the same operator (same averages, Newton counts;
+    Krylov counts within one iteration of each other)."""
+    import exaconstit_amd.lib as L
+    res = {}
+    for assembly in ("PA", "EA"):
+        path = _variant_toml(tmp_path, "voce_pa.toml", [('assembly = "PA"', 'assembly = "%s"' % assembly), ("prefinement = 1", "p_refinement = 4"),
+                                                        ("ref_ser = 1", "ref_ser = 0")], "p4" + assembly)
+        d = L.Driver.from_toml(path, out_dir=str(tmp_path))
+        for ti in range(1, 4):
+            assert d.step(ti)
+        res[assembly] = (d.avgs(0, 6), d.stats())
+    a, b = res["PA"], res["EA"]
+    assert np.linalg.norm(a[0] - b[0]) < 1e-10 * np.linalg.norm(a[0])
+    assert list(a[1][0]) == list(b[1][0])
+    assert np.max(np.abs(np.asarray(a[1][1]) - np.asarray(b[1][1]))) <= 1
 
 
 def test_velocity_gradient_bcs_match_golden(oracle, tmp_path):
