@@ -250,6 +250,11 @@ def main():
                  "pcg_iters_per_s": kit_tot / (kms_tot * 1e-3),
                  "steady_plastic": ({"steps": f"10..{args.solve_steps}", "qpt_updates_per_s_in_kernel": P_global * calls_pl / (ms_pl * 1e-3),
                                      "kernel_ms_per_call": ms_pl / calls_pl,
+                                     "last_step": {"step": rows[-1]["step"], "kernel_ms_per_call": rows[-1]["kernel_ms_per_call"],
+                                                   "qpt_updates_per_s_in_kernel": rows[-1]["qpt_updates_per_s_in_kernel"],
+                                                   "note": "all in-solve launches of the last step (every Newton iterate, not only the converged one); the per-step rate is "
+                                                           "still rising towards it over steps 10.. (per_step): the evaluation counts left by the elastic-plastic transition "
+                                                           "decay from step to step, the timed passes repeat the converged launch of this step"},
                                      "local_solver_evals": dict(hist_dict(hist_pl), note="converged launch of every step >= 10 (rank 0)")} if calls_pl else None),
                  "avg_stress_zz": [float(x) for x in drv.avgs(0, 6)[:, 2]],      # committed steps
                  "model_failed_points": dg["model_failed_points"], "pcg_solves_at_iteration_cap": dg["pcg_not_converged"],

@@ -615,12 +615,18 @@ template void NonlinearMechOperator::Setup<false>(const double*);
 NonlinearMechOperator::EvPair& NonlinearMechOperator::NextModelTimer() {
    if (ev_ring_.empty()) { ev_ring_.resize(64); for (EvPair& e : ev_ring_) { EXA_HC(hipEventCreate(&e.a)); EXA_HC(hipEventCreate(&e.b)); } }
    EvPair& e = ev_ring_[ev_head_]; ev_head_ = (ev_head_ + 1) % (int)ev_ring_.size();
-   if (e.pending) { EXA_HC(hipEventSynchronize(e.b)); float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e.a, e.b)); timers.t_model_ms += ms; e.pending = false; }
+   if (e.pending) ReadTimer(e);
+   e.call = model_calls + 1;
    return e;
+}
+void NonlinearMechOperator::ReadTimer(EvPair& e) {
+   EXA_HC(hipEventSynchronize(e.b)); float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e.a, e.b)); timers.t_model_ms += ms; e.pending = false;
+   static const bool print = std::getenv("EXA_MODEL_TIMES") != nullptr;      // per-launch durations on stderr (measurement aid)
+   if (print) std::fprintf(stderr, "model_launch call %ld: %.4f ms\n", e.call, ms);
 }
 // adds the launches timed since the last call to timers.t_model_ms (waits for the last of them)
 void NonlinearMechOperator::FlushModelTimers() {
-   for (EvPair& e : ev_ring_) if (e.pending) { EXA_HC(hipEventSynchronize(e.b)); float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e.a, e.b)); timers.t_model_ms += ms; e.pending = false; }
+   for (EvPair& e : ev_ring_) if (e.pending) ReadTimer(e);
 }
 // failed local solves of the last constitutive launch, for callers that do not go through ResidualNorm (one 4-byte read-back + sync)
 void NonlinearMechOperator::ReadModelStatus() {

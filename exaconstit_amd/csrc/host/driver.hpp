@@ -134,7 +134,8 @@ class NonlinearMechOperator {
    // Newton reports non-convergence: Time.Auto then cuts dt, otherwise the run stops.
    int model_fail = 0; int64_t model_fail_total = 0;
    bool model_status_pending_ = false;       // a constitutive launch whose failure count has not reached the host yet (ResidualNorm / ReadModelStatus)
-   struct EvPair { hipEvent_t a = nullptr, b = nullptr; bool pending = false; };
+   struct EvPair { hipEvent_t a = nullptr, b = nullptr; bool pending = false; long call = 0; };
+   void ReadTimer(EvPair& e);   // adds a finished launch to timers.t_model_ms (EXA_MODEL_TIMES=1: and prints it)
    EvPair& NextModelTimer(); void FlushModelTimers(); void ReadModelStatus();
    double ResidualNorm(const double* r);
    double dot(const double* a, const double* b);   // weighted, all-reduced, synchronising
