@@ -797,7 +797,7 @@ SystemDriver::SystemDriver(const ExaOptions& opt, int rank, int nranks, const vo
    if (opt.mesh_type == "auto") {
       const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
       part.build(N, opt.length, rank, nranks, opt.order);
-   } else part.build_from_mfem_mesh(opt.resolve(opt.mesh_file), rank, nranks);
+   } else part.build_from_mfem_mesh(opt.resolve(opt.mesh_file), rank, nranks, opt.order);
    if (opt.order == 1) part.order_boundary_first();   // several ranks: elements at shared nodes first (exchange overlapped with the interior, GradMult)
    std::vector<double> props, quats; load_case_data(opt, part, props, quats);
    init(props, quats);

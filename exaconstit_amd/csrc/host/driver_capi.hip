@@ -319,7 +319,7 @@ static void export_partition(const Partition& p, int64_t* info, int32_t* conn, d
 int exa_partition_query(const int* N, int rank, int nranks, int64_t* info, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
                         int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs) {
    Partition p; const double L[3] = { 1.0, 1.0, 1.0 };
-   const int order = (info[7] == 2) ? 2 : 1;   // info[7] is in/out: H1 order on input (0/1 -> 1), nodes per element on output
+   const int order = (info[7] >= 2 && info[7] <= 6) ? (int)info[7] : 1;   // info[7] is in/out: H1 order on input (0/1 -> 1), nodes per element on output
    p.build(N, L, rank, nranks, order);
    export_partition(p, info, conn, X, elem_gid, weight, nbr_rank, nbr_count, nbr_dofs);
    return 0;
@@ -340,6 +340,16 @@ int exa_mesh_partition_query(const char* mesh_path, int rank, int nranks, int64_
                              int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs, char* err, int errlen) {
    try {
       Partition p; p.build_from_mfem_mesh(mesh_path, rank, nranks);
+      export_partition(p, info, conn, X, elem_gid, weight, nbr_rank, nbr_count, nbr_dofs);
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
+// the same at p_refinement = order (1 or 2: edge / face / element nodes added to the trilinear file mesh)
+int exa_mesh_partition_query_order(const char* mesh_path, int rank, int nranks, int order, int64_t* info, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
+                                   int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs, char* err, int errlen) {
+   try {
+      Partition p; p.build_from_mfem_mesh(mesh_path, rank, nranks, order);
       export_partition(p, info, conn, X, elem_gid, weight, nbr_rank, nbr_count, nbr_dofs);
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <map>
 
 void exa_gll_nodes_01(int np, std::vector<double>& x);   // host_tables.cpp
 
@@ -152,7 +153,7 @@ struct Partition {
    // centroids (the reference uses METIS through ParMesh, src/mechanics_driver.cpp:312; any partition gives the same operator) and the
    // rank keeps its elements, the nodes they touch, and one Neighbor per rank it shares nodes with (dofs ordered by global node id on
    // both sides).
-   void build_from_mfem_mesh(const std::string& path, int rank_, int nranks_) {
+   void build_from_mfem_mesh(const std::string& path, int rank_, int nranks_, int order = 1) {
       std::ifstream f(path);
       if (!f) throw std::runtime_error("Cannot open mesh file: " + path);
       auto next_token_line = [&](std::string& line) {   // next non-empty, non-comment line
@@ -202,8 +203,46 @@ struct Partition {
       int maxattr = 0; for (auto& q : bdr) maxattr = std::max(maxattr, q[0]);
       bdr_nodes.assign(maxattr, std::vector<uint8_t>(NN, 0));
       for (auto& q : bdr) for (int a = 0; a < 4; a++) bdr_nodes[q[0] - 1][q[1 + a]] = 1;
+      if (order == 2) elevate_to_p2(bdr);
+      else if (order != 1) throw std::runtime_error("mesh: file meshes run at p_refinement = 1 or 2");
       weight.assign(NN, 1.0); nbrs.clear();
       if (nranks > 1) localize(rcb_owner(nranks));
+   }
+
+   // p_refinement = 2 on a file mesh (the reference raises the order of the nodal space of any mesh, src/mechanics_driver.cpp:300-306): one new
+   // node per edge, per face and per element of the trilinear mesh, at the mean of the vertices it belongs to (which is where the trilinear map
+   // puts the triquadratic nodes); local numbering = native_order(2) (vertices, edges, faces in MFEM's order, centre).  One node per entity
+   // means no orientation bookkeeping - the reason orders above 2 are left to generated meshes.
+   void elevate_to_p2(const std::vector<std::array<int, 5>>& bdr) {
+      static const int Ed[12][2] = { { 0, 1 }, { 1, 2 }, { 3, 2 }, { 0, 3 }, { 4, 5 }, { 5, 6 }, { 7, 6 }, { 4, 7 }, { 0, 4 }, { 1, 5 }, { 2, 6 }, { 3, 7 } };
+      static const int Fc[6][4] = { { 0, 1, 2, 3 }, { 0, 1, 5, 4 }, { 1, 2, 6, 5 }, { 3, 2, 6, 7 }, { 0, 3, 7, 4 }, { 4, 5, 6, 7 } };
+      const int nv = NN;
+      std::map<std::array<int, 2>, int> edge_node; std::map<std::array<int, 4>, int> face_node;
+      std::vector<std::array<double, 3>> xnew;
+      auto coord = [&](int g, int d) { return g < nv ? X[g + (size_t)nv * d] : xnew[g - nv][d]; };
+      auto add_node = [&](const int* vs, int k) { std::array<double, 3> c{ 0, 0, 0 }; for (int i = 0; i < k; i++) for (int d = 0; d < 3; d++) c[d] += X[vs[i] + (size_t)nv * d]; for (int d = 0; d < 3; d++) c[d] /= k; xnew.push_back(c); return nv + (int)xnew.size() - 1; };
+      auto edge_of = [&](int a, int b) { std::array<int, 2> key{ std::min(a, b), std::max(a, b) }; auto it = edge_node.find(key); if (it != edge_node.end()) return it->second; const int vs[2] = { a, b }; const int g = add_node(vs, 2); edge_node.emplace(key, g); return g; };
+      auto face_of = [&](const int* v4) { std::array<int, 4> key{ v4[0], v4[1], v4[2], v4[3] }; std::sort(key.begin(), key.end()); auto it = face_node.find(key); if (it != face_node.end()) return it->second; const int g = add_node(v4, 4); face_node.emplace(key, g); return g; };
+      std::vector<int32_t> c2((size_t)27 * E);
+      for (int e = 0; e < E; e++) {
+         const int32_t* v = &conn[(size_t)8 * e];
+         int32_t* w = &c2[(size_t)27 * e];
+         for (int a = 0; a < 8; a++) w[a] = v[a];
+         for (int k = 0; k < 12; k++) w[8 + k] = edge_of(v[Ed[k][0]], v[Ed[k][1]]);
+         for (int k = 0; k < 6; k++) { const int v4[4] = { v[Fc[k][0]], v[Fc[k][1]], v[Fc[k][2]], v[Fc[k][3]] }; w[20 + k] = face_of(v4); }
+         const int v8[8] = { v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7] };
+         w[26] = add_node(v8, 8);
+      }
+      const int NN2 = nv + (int)xnew.size();
+      std::vector<double> X2((size_t)3 * NN2);
+      for (int g = 0; g < NN2; g++) for (int d = 0; d < 3; d++) X2[g + (size_t)NN2 * d] = coord(g, d);
+      for (auto& b : bdr_nodes) b.resize(NN2, 0);
+      for (auto& q : bdr) {      // a boundary quadrilateral constrains its edge nodes and its face node too
+         for (int a = 0; a < 4; a++) { auto it = edge_node.find({ std::min(q[1 + a], q[1 + (a + 1) % 4]), std::max(q[1 + a], q[1 + (a + 1) % 4]) }); if (it != edge_node.end()) bdr_nodes[q[0] - 1][it->second] = 1; }
+         std::array<int, 4> key{ q[1], q[2], q[3], q[4] }; std::sort(key.begin(), key.end());
+         auto it = face_node.find(key); if (it != face_node.end()) bdr_nodes[q[0] - 1][it->second] = 1;
+      }
+      conn.swap(c2); X.swap(X2); NN = NN2; p = 2; n = 27;
    }
 
    // element -> rank by recursive coordinate bisection: split the longest extent of the centroid cloud at the element count that

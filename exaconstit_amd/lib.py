@@ -179,6 +179,7 @@ exa_driver_bench_pcg = _sig("exa_driver_bench_pcg", C.c_int, C.c_void_p, C.c_int
 exa_choose_newton_cap = _sig("exa_choose_newton_cap", C.c_int, C.POINTER(C.c_int), C.c_double)
 exa_choose_newton_caps = _sig("exa_choose_newton_caps", C.c_int, C.POINTER(C.c_int), C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int))
 exa_options_query = _sig("exa_options_query", C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int)
+exa_mesh_partition_query_order = _sig("exa_mesh_partition_query_order", C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int)
 exa_mesh_partition_query = _sig("exa_mesh_partition_query", C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int)
 exa_partition_query_boundary_first = _sig("exa_partition_query_boundary_first", C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p)
 exa_partition_query = _sig("exa_partition_query", C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)

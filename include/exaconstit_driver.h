@@ -111,6 +111,10 @@ int exa_partition_query(const int* N, int rank, int nranks, int64_t* info8, int3
 int exa_partition_query_boundary_first(const int* N, int rank, int nranks, int order, int64_t* out2, int32_t* conn, int64_t* elem_gid);
 int exa_mesh_partition_query(const char* mesh_path, int rank, int nranks, int64_t* info8, int32_t* conn, double* X, int64_t* elem_gid, double* weight,
                              int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs, char* err, int errlen);
+/* ... at p_refinement = order: 1, or 2 = one node added per edge, face and element of the trilinear file mesh (what the reference's order
+ * elevation of the nodal space gives for straight-sided hexahedra, src/mechanics_driver.cpp:300-306); higher orders: generated meshes only. */
+int exa_mesh_partition_query_order(const char* mesh_path, int rank, int nranks, int order, int64_t* info8, int32_t* conn, double* X, int64_t* elem_gid,
+                                   double* weight, int32_t* nbr_rank, int32_t* nbr_count, int32_t* nbr_dofs, char* err, int errlen);
 #ifdef __cplusplus
 }
 #endif

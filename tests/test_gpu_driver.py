@@ -233,16 +233,18 @@ def test_auto_case_golden_rows_on_gpu(tmp_path):
     assert np.abs(d[:8]).max() < 0.003 and abs(d[8]) < 0.006, d
 
 
-@pytest.mark.parametrize("mesh", ["cube5_nodes.mesh", "cube5_shuffled.mesh"])
-def test_file_mesh_matches_generated_mesh(oracle, tmp_path, mesh):
+@pytest.mark.parametrize("mesh,p", [("cube5_nodes.mesh", 1), ("cube5_shuffled.mesh", 1), ("cube5_shuffled.mesh", 2)])
+def test_file_mesh_matches_generated_mesh(oracle, tmp_path, mesh, p):
     """Mesh.type = "other" (MFEM mesh v1.0 file, reference src/mechanics_driver.cpp:239-241; grain ids = element attributes, boundary ids
     = boundary attributes): the 5^3 RVE read from a file — natural order with a `nodes` grid function, and with elements / vertices
-    permuted — gives the run of the generated mesh (explicit connectivity: no kernel depends on the structured numbering)."""
+    permuted — gives the run of the generated mesh (explicit connectivity: no kernel depends on the structured numbering).  p = 2: the
+    file mesh's order is raised by the reader (one node per edge / face / element)."""
     import exaconstit_amd.lib as L
     orc = oracle
     n = 4
-    auto = _variant_toml(tmp_path, "voce_pa.toml", [("ref_ser = 1", "ref_ser = 0")], "auto5")
-    filem = _variant_toml(tmp_path, "voce_pa.toml", [("ref_ser = 1", "ref_ser = 0"), ('type = "auto"', 'type = "other"'),
+    pe = ("prefinement = 1", "p_refinement = %d" % p)
+    auto = _variant_toml(tmp_path, "voce_pa.toml", [("ref_ser = 1", "ref_ser = 0"), pe], "auto5")
+    filem = _variant_toml(tmp_path, "voce_pa.toml", [("ref_ser = 1", "ref_ser = 0"), pe, ('type = "auto"', 'type = "other"'),
                                                      ('floc = "../../data/cube-hex-ro.mesh"', 'floc = "%s"' % os.path.join(orc.REFDATA, mesh))], "file5")
     out = []
     for path in (auto, filem):
@@ -253,6 +255,8 @@ def test_file_mesh_matches_generated_mesh(oracle, tmp_path, mesh):
         d.close()
     assert np.max(np.abs(out[0][0] - out[1][0])) < 1e-10 * np.abs(out[0][0]).max()
     assert list(out[0][1][0]) == list(out[1][1][0])
+    if p != 1:
+        return
     ref = orc.run_case(orc.load_case(auto), nsteps=n)
     assert np.linalg.norm(out[1][0][:, 2:] - ref["avg_stress"][:, 2:]) / np.linalg.norm(ref["avg_stress"][:, 2:]) < 1e-6
 

@@ -292,3 +292,73 @@ def test_boundary_first_element_order(nranks):
         for seg in (gid[:Eb], gid[Eb:]):
             p = [pos[int(g)] for g in seg]
             assert p == sorted(p)
+
+
+def _mesh_query(path, rank, nr, order):
+    import ctypes as C
+    import exaconstit_amd.lib as L
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    info = (C.c_int64 * 8)(); err = C.create_string_buffer(256)
+    assert L.exa_mesh_partition_query_order(path, rank, nr, order, info, None, None, None, None, None, None, None, err, 256) == 0, err.value
+    E, NN, nnb, shared, n = info[0], info[1], info[2], info[6], info[7]
+    conn = np.zeros(n * E, np.int32); X = np.zeros(3 * NN); gid = np.zeros(E, np.int64); w = np.zeros(NN)
+    nrk = np.zeros(max(nnb, 1), np.int32); ncnt = np.zeros(max(nnb, 1), np.int32); nd = np.zeros(max(shared, 1), np.int32)
+    assert L.exa_mesh_partition_query_order(path, rank, nr, order, info, vp(conn), vp(X), vp(gid), vp(w), vp(nrk), vp(ncnt), vp(nd), err, 256) == 0
+    nb = {}; off = 0
+    for i in range(nnb):
+        nb[int(nrk[i])] = nd[off:off + ncnt[i]].copy(); off += ncnt[i]
+    return dict(E=E, NN=NN, n=n, conn=conn.reshape(E, n), X=X.reshape(3, NN), gid=gid, w=w, nb=nb)
+
+
+def _generated(N, order):
+    import ctypes as C
+    import exaconstit_amd.lib as L
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    Nn = (C.c_int * 3)(N, N, N); info = (C.c_int64 * 8)(); info[7] = order
+    assert L.exa_partition_query(Nn, 0, 1, info, None, None, None, None, None, None, None) == 0
+    E, NN, n = info[0], info[1], info[7]
+    conn = np.zeros(n * E, np.int32); X = np.zeros(3 * NN); gid = np.zeros(E, np.int64); w = np.zeros(NN)
+    info[7] = order
+    assert L.exa_partition_query(Nn, 0, 1, info, vp(conn), vp(X), vp(gid), vp(w), None, None, None) == 0
+    return dict(E=E, NN=NN, n=n, conn=conn.reshape(E, n), X=X.reshape(3, NN))
+
+
+def test_file_mesh_at_order_two_equals_the_generated_mesh():
+    """p_refinement = 2 on an MFEM mesh file: one node per edge / face / element of the trilinear mesh, numbered like the generated
+    triquadratic mesh (vertices, edges, faces, centre) - every element of the 5^3 file mesh carries the node coordinates of the generated
+    5^3 p = 2 mesh, and a partition of it keeps the invariants of the p = 1 partition."""
+    path = os.path.join(REF, "cube5_nodes.mesh").encode()
+    f1 = _mesh_query(path, 0, 1, 1); f2 = _mesh_query(path, 0, 1, 2)
+    assert f1["n"] == 8 and f2["n"] == 27 and f2["E"] == 125 and f2["NN"] == 11 ** 3
+    g = _generated(5, 2)
+    assert g["n"] == 27 and g["NN"] == 11 ** 3
+    scale = f1["X"].max()
+    for e in range(125):
+        assert np.allclose(f2["X"][:, f2["conn"][e]], scale * g["X"][:, g["conn"][e]], atol=1e-14 * scale)
+    assert np.array_equal(f2["conn"][:, :8], f1["conn"])
+    path = os.path.join(REF, "cube5_shuffled.mesh").encode()
+    for nranks in (2, 3):
+        parts = [_mesh_query(path, r, nranks, 2) for r in range(nranks)]
+        assert sorted(np.concatenate([p["gid"] for p in parts]).tolist()) == list(range(125))
+        wsum = {}
+        for p in parts:
+            for i in range(p["NN"]):
+                k = tuple(np.round(p["X"][:, i], 9)); wsum[k] = wsum.get(k, 0.0) + p["w"][i]
+        assert len(wsum) == 11 ** 3 and all(abs(v - 1.0) < 1e-12 for v in wsum.values())
+        for r, p in enumerate(parts):
+            for r2, dofs in p["nb"].items():
+                other = parts[r2]["nb"][r]; m = len(dofs) // 3
+                assert len(dofs) == len(other)
+                assert np.array_equal(p["X"][:, dofs[:m] % p["NN"]], parts[r2]["X"][:, other[:m] % parts[r2]["NN"]])
+
+
+def test_generated_mesh_nodes_sit_at_gauss_lobatto_points():
+    """Orders above 2: the nodes of a generated mesh are the Gauss-Lobatto-Legendre points of each element (MFEM's H1 basis), not equispaced."""
+    g = _generated(2, 4)
+    assert g["n"] == 125 and g["NN"] == 9 ** 3
+    xs = np.unique(np.round(g["X"][0], 12))
+    gll5 = 0.5 * (1.0 + np.array([-1.0, -np.sqrt(3.0 / 7.0), 0.0, np.sqrt(3.0 / 7.0), 1.0]))
+    expect = np.unique(np.round(np.concatenate([0.5 * gll5, 0.5 + 0.5 * gll5]), 12))
+    assert np.allclose(xs, expect, atol=1e-12)
+    g3 = _generated(1, 3)
+    assert np.allclose(np.unique(np.round(g3["X"][0], 12)), [0.0, 0.5 - 0.5 / np.sqrt(5.0), 0.5 + 0.5 / np.sqrt(5.0), 1.0], atol=1e-12)
