@@ -88,15 +88,15 @@ def test_partitioned_order2_bbar_matches_single_rank(oracle, tmp_path):
             assert list(st[0]) == list(ref[1][0])
 
 
-@pytest.mark.parametrize("mesh,nranks", [("cube5_shuffled.mesh", 2), ("cube5_shuffled.mesh", 3), ("cube5_nodes.mesh", 5)])
-def test_file_mesh_partitioned_matches_single_rank(oracle, tmp_path, mesh, nranks):
+@pytest.mark.parametrize("mesh,nranks,p", [("cube5_shuffled.mesh", 2, 1), ("cube5_shuffled.mesh", 3, 1), ("cube5_nodes.mesh", 5, 1), ("cube5_shuffled.mesh", 3, 2)])
+def test_file_mesh_partitioned_matches_single_rank(oracle, tmp_path, mesh, nranks, p):
     """Mesh.type = "other" on several ranks: recursive-coordinate-bisection partition of the file's elements (unstructured neighbour
     lists, nodes shared by up to 8 ranks) gives the one-rank run."""
     import exaconstit_amd.lib as L
     from test_gpu_driver import _variant_toml
     orc = oracle
     os.makedirs(str(tmp_path), exist_ok=True)
-    toml = _variant_toml(tmp_path, "voce_pa.toml", [("ref_ser = 1", "ref_ser = 0"), ('type = "auto"', 'type = "other"'),
+    toml = _variant_toml(tmp_path, "voce_pa.toml", [("ref_ser = 1", "ref_ser = 0"), ("prefinement = 1", "p_refinement = %d" % p), ('type = "auto"', 'type = "other"'),
                                                     ('floc = "../../data/cube-hex-ro.mesh"', 'floc = "%s"' % os.path.join(orc.REFDATA, mesh))], "file5")
     ref = _run_ranks(L, toml, 1, 4, tmp_path / "r1")[0]
     for s, st in _run_ranks(L, toml, nranks, 4, tmp_path / f"r{nranks}"):
