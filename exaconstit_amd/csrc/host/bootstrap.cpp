@@ -15,6 +15,7 @@
 #include <sys/select.h>
 #include <sys/socket.h>
 #include <unistd.h>
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
 #include <cstdint>
@@ -50,6 +51,8 @@ void recv_all(int fd, void* buf, size_t n) {
    char* p = (char*)buf;
    while (n) { const ssize_t k = ::recv(fd, p, n, 0); if (k <= 0) { if (k < 0 && errno == EINTR) continue; throw std::runtime_error(k == 0 ? "recv: peer closed the connection" : std::string("recv: ") + std::strerror(errno)); } p += k; n -= (size_t)k; }
 }
+
+struct Closer { int fd; ~Closer() { if (fd >= 0) ::close(fd); } };   // closes a socket on every way out of a scope
 
 struct Endpoint { std::string addr; int port; };
 Endpoint endpoint() {
@@ -111,7 +114,7 @@ int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double time
          if (::getaddrinfo(ep.addr.c_str(), nullptr, &hints, &res) == 0 && res) { sa.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr; ::freeaddrinfo(res); }
          const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
          if (ls < 0) throw std::runtime_error(std::string("socket: ") + std::strerror(errno));
-         struct Closer { int fd; ~Closer() { if (fd >= 0) ::close(fd); } } ls_guard{ ls };
+         Closer ls_guard{ ls };
          int one = 1; ::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
          if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0) {
             sa.sin_addr.s_addr = htonl(INADDR_ANY);      // the address is not local to rank 0 (NAT, alias): fall back to all interfaces
@@ -153,10 +156,11 @@ int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double time
             std::this_thread::sleep_for(std::chrono::milliseconds(50));
          }
          ::freeaddrinfo(res);
+         Closer fd_guard{ fd };
+         timeval rt{ (long)std::max(10.0, timeout_s > 0 ? timeout_s : 120.0), 0 }; ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rt, sizeof(rt));   // a rank 0 that dies after accept() does not hang its peers
          const uint32_t hello[2] = { kMagic, (uint32_t)rank };
          send_all(fd, hello, sizeof(hello));
          recv_all(fd, buf, (size_t)nbytes);
-         ::close(fd);
       }
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, std::string("exa_bootstrap_bcast (rank ") + std::to_string(rank) + "): " + e.what()); return -1; }
