@@ -88,6 +88,19 @@ def test_partitioned_order2_bbar_matches_single_rank(oracle, tmp_path):
             assert list(st[0]) == list(ref[1][0])
 
 
+def test_partitioned_order3_matches_single_rank(oracle, tmp_path):
+    """p_refinement = 3 (run-time-order kernels, Gauss-Lobatto nodes) on 2 and 3 ranks vs one rank: shared faces carry 16 nodes per element face."""
+    import exaconstit_amd.lib as L
+    from test_gpu_driver import _variant_toml
+    os.makedirs(str(tmp_path), exist_ok=True)
+    toml = _variant_toml(tmp_path, "voce_pa.toml", [("prefinement = 1", "p_refinement = 3"), ("ref_ser = 1", "ref_ser = 0")], "p3")
+    ref = _run_ranks(L, toml, 1, 3, tmp_path / "r1")[0]
+    for nranks in (2, 3):
+        for s, st in _run_ranks(L, toml, nranks, 3, tmp_path / f"r{nranks}"):
+            assert np.max(np.abs(s - ref[0])) < 1e-9 * np.abs(ref[0]).max()
+            assert list(st[0]) == list(ref[1][0])
+
+
 @pytest.mark.parametrize("mesh,nranks,p", [("cube5_shuffled.mesh", 2, 1), ("cube5_shuffled.mesh", 3, 1), ("cube5_nodes.mesh", 5, 1), ("cube5_shuffled.mesh", 3, 2)])
 def test_file_mesh_partitioned_matches_single_rank(oracle, tmp_path, mesh, nranks, p):
     """Mesh.type = "other" on several ranks: recursive-coordinate-bisection partition of the file's elements (unstructured neighbour
