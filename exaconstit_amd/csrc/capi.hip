@@ -7,6 +7,7 @@
 int exa_launch_model_setup(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, hipStream_t);
 int exa_launch_model_setup_rec(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
 int exa_launch_init_state(exa_ctx*, double*, const double*, const double*, hipStream_t);
+int exa_launch_state_normalize(exa_ctx*, double*, hipStream_t);
 int exa_launch_nfev_hist(exa_ctx*, const double*, int*, hipStream_t);
 int exa_launch_selftest_km_math(const double*, double*, int, hipStream_t);
 int exa_launch_calc_dp(exa_ctx*, const double*, double*, hipStream_t);
@@ -120,6 +121,11 @@ int exa_init_state(exa_ctx* ctx, double* state0, const double* quats, exa_stream
    double* hist_dev = ctx->scratch_dev;   // 26 doubles
    EXA_HIP_CHECK(ctx, hipMemcpyAsync(hist_dev, ctx->hist_init, sizeof(double) * ecmdev::NUM_HIST, hipMemcpyHostToDevice, S(s)));
    return exa_launch_init_state(ctx, state0, quats, hist_dev, S(s));
+}
+
+int exa_state_normalize(exa_ctx* ctx, double* state, exa_stream s) {
+   if (!ctx || !state) return fail(ctx, EXA_ERR_ARG, "exa_state_normalize: null pointer");
+   return exa_launch_state_normalize(ctx, state, S(s));
 }
 
 int exa_model_setup(exa_ctx* ctx, double dt, const double* J, const double* vel, const double* stress0, const double* state0,

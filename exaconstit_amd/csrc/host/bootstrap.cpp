@@ -98,13 +98,21 @@ int exa_bootstrap_env(int* rank, int* nranks, int* local_rank) {
    return 0;
 }
 
-// Broadcast `nbytes` from rank 0 to all ranks over TCP (rank 0: listen + accept nranks-1 peers; others: connect with retries).
-// Every peer first sends (magic, rank) so that a stray connection cannot consume a slot.  timeout_s bounds the whole exchange.
-int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double timeout_s, char* err, int errlen) {
-   if (nranks <= 1) return 0;
-   static const uint32_t kMagic = 0x45584131u;   // "EXA1"
+// Gather-and-reply over TCP: every rank contributes `nbytes` (rank 0: listen + accept nranks-1 peers; others: connect with retries, send
+// (magic, rank) - so that a stray connection cannot consume a slot - and their contribution); once everybody has arrived rank 0 calls
+// fn(table of all contributions in rank order) to build the `reply_bytes` answer every rank receives.  nbytes may be 0 and fn null (plain
+// broadcast of rank 0's `reply`).  timeout_s bounds the whole exchange.  A peer that reconnects replaces its earlier connection.
+int exa_bootstrap_gather_reply(int rank, int nranks, const void* mine, int nbytes, void* reply, int reply_bytes, exa_bootstrap_reply_fn fn, void* user,
+                               double timeout_s, char* err, int errlen) {
+   if (nranks <= 1) {
+      if (fn && fn(mine, 1, nbytes, reply, reply_bytes, user) != 0) { set_err(err, errlen, "exa_bootstrap_gather_reply: the reply callback failed"); return -1; }
+      return 0;
+   }
+   static const uint32_t kMagic = 0x45584132u;   // "EXA2"
    const Endpoint ep = endpoint();
    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s > 0 ? timeout_s : 120.0);
+   std::vector<int> peer_fd;      // rank 0: the open connection of every peer (closed on every way out)
+   struct CloseAll { std::vector<int>& v; ~CloseAll() { for (int fd : v) if (fd >= 0) ::close(fd); } } close_all{ peer_fd };
    try {
       if (rank == 0) {
          // listen on the rendez-vous address itself (loopback by default), not on every interface
@@ -121,11 +129,13 @@ int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double time
             if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0) throw std::runtime_error(std::string("bind ") + ep.addr + ":" + std::to_string(ep.port) + ": " + std::strerror(errno));
          }
          if (::listen(ls, nranks) != 0) throw std::runtime_error(std::string("listen: ") + std::strerror(errno));
-         std::vector<char> served_rank((size_t)nranks, 0);
-         int served = 0;
-         while (served < nranks - 1) {
+         peer_fd.assign((size_t)nranks, -1);
+         std::vector<char> table((size_t)nranks * (size_t)nbytes);
+         if (nbytes > 0) std::memcpy(table.data(), mine, (size_t)nbytes);
+         int arrived = 0;
+         while (arrived < nranks - 1) {
             timeval tv{}; const double left = std::chrono::duration<double>(t_end - std::chrono::steady_clock::now()).count();
-            if (left <= 0) throw std::runtime_error("rendez-vous on " + ep.addr + ":" + std::to_string(ep.port) + " timed out: " + std::to_string(served) + " of " + std::to_string(nranks - 1) +
+            if (left <= 0) throw std::runtime_error("rendez-vous on " + ep.addr + ":" + std::to_string(ep.port) + " timed out: " + std::to_string(arrived) + " of " + std::to_string(nranks - 1) +
                                                     " peers connected (is every rank started, and with the same [EXA_]MASTER_ADDR / PORT?)");
             tv.tv_sec = (long)left; tv.tv_usec = (long)((left - (long)left) * 1e6);
             fd_set fds; FD_ZERO(&fds); FD_SET(ls, &fds);
@@ -134,14 +144,19 @@ int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double time
             if (fd < 0) continue;
             Closer fd_guard{ fd };
             timeval rt{ 10, 0 }; ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rt, sizeof(rt)); ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &rt, sizeof(rt));
-            uint32_t hello[2] = { 0, 0 };
+            uint32_t hello[3] = { 0, 0, 0 };
+            std::vector<char> theirs((size_t)nbytes);
             try {
                recv_all(fd, hello, sizeof(hello));
-               if (hello[0] != kMagic || hello[1] == 0 || hello[1] >= (uint32_t)nranks) continue;      // not one of ours
-               send_all(fd, buf, (size_t)nbytes);      // (a rank that retries is served again, but counted once)
+               if (hello[0] != kMagic || hello[1] == 0 || hello[1] >= (uint32_t)nranks || hello[2] != (uint32_t)nbytes) continue;      // not one of ours
+               if (nbytes > 0) recv_all(fd, theirs.data(), (size_t)nbytes);
             } catch (...) { continue; }                // a peer that went away does not end the rendez-vous
-            if (!served_rank[hello[1]]) { served_rank[hello[1]] = 1; served++; }
+            if (nbytes > 0) std::memcpy(table.data() + (size_t)hello[1] * (size_t)nbytes, theirs.data(), (size_t)nbytes);
+            if (peer_fd[hello[1]] >= 0) ::close(peer_fd[hello[1]]); else arrived++;      // (a rank that retries is kept once)
+            peer_fd[hello[1]] = fd; fd_guard.fd = -1;
          }
+         if (fn && fn(table.data(), nranks, nbytes, reply, reply_bytes, user) != 0) throw std::runtime_error("the reply callback failed");
+         for (int r = 1; r < nranks; r++) send_all(peer_fd[r], reply, (size_t)reply_bytes);
       } else {
          addrinfo hints{}; hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
          addrinfo* res = nullptr;
@@ -158,12 +173,18 @@ int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double time
          ::freeaddrinfo(res);
          Closer fd_guard{ fd };
          timeval rt{ (long)std::max(10.0, timeout_s > 0 ? timeout_s : 120.0), 0 }; ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rt, sizeof(rt));   // a rank 0 that dies after accept() does not hang its peers
-         const uint32_t hello[2] = { kMagic, (uint32_t)rank };
+         const uint32_t hello[3] = { kMagic, (uint32_t)rank, (uint32_t)nbytes };
          send_all(fd, hello, sizeof(hello));
-         recv_all(fd, buf, (size_t)nbytes);
+         if (nbytes > 0) send_all(fd, mine, (size_t)nbytes);
+         recv_all(fd, reply, (size_t)reply_bytes);
       }
       return 0;
-   } catch (const std::exception& e) { set_err(err, errlen, std::string("exa_bootstrap_bcast (rank ") + std::to_string(rank) + "): " + e.what()); return -1; }
+   } catch (const std::exception& e) { set_err(err, errlen, std::string("exa_bootstrap (rank ") + std::to_string(rank) + "): " + e.what()); return -1; }
+}
+
+// Broadcast `nbytes` from rank 0 to all ranks (the gather-and-reply exchange with empty contributions)
+int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double timeout_s, char* err, int errlen) {
+   return exa_bootstrap_gather_reply(rank, nranks, nullptr, 0, buf, nbytes, nullptr, nullptr, timeout_s, err, errlen);
 }
 
 }  // extern "C"

@@ -178,7 +178,12 @@ void Comm::ipc_unique_id(void* out128) {
 }
 bool Comm::want_ipc_transport(int nranks) {
    if (const char* e = std::getenv("EXA_TRANSPORT")) { if (std::string(e) == "ipc") return true; if (std::string(e) == "rccl") return false; }
-   int nd = 0; return nranks > 1 && hipGetDeviceCount(&nd) == hipSuccess && nd > 0 && nranks > nd;      // more ranks than devices: RCCL cannot serve them
+   // Without identities (exa_comm_unique_id called by a launcher that did not compare them): ranks of THIS NODE against its visible devices.
+   // The node-local count comes from the launcher when it says so; the global count only stands in for it on a one-node launch.
+   int local = nranks;
+   for (const char* k : { "EXA_LOCAL_NRANKS", "LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE" })
+      if (const char* v = std::getenv(k)) { const int n = std::atoi(v); if (n > 0) { local = n; break; } }
+   int nd = 0; return nranks > 1 && hipGetDeviceCount(&nd) == hipSuccess && nd > 0 && local > nd;      // more ranks than devices on the node: RCCL cannot serve them
 }
 
 int Comm::reported_ranks() const {

@@ -5,6 +5,7 @@
 #include "driver.hpp"
 #include "roctx.hpp"
 #include "../../../include/exaconstit_driver.h"
+#include <unistd.h>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -22,9 +23,43 @@ void set_err(char* err, int n, const std::string& m) { if (err && n > 0) { std::
 
 extern "C" {
 
-// rank / size from the launcher's environment, device = local rank mod visible devices, RCCL unique id from rank 0 to everybody over the
-// TCP rendez-vous of host/bootstrap.cpp: everything `mechanics` needs before exa_driver_create (reference: MPI_Init + MPI_Comm_rank/size,
-// src/mechanics_driver.cpp:119-150)
+// Transport from the identity of the ranks' devices (96-byte records: host name[64], PCI bus id[32]).  RCCL needs one device per rank; the
+// shared-device transport (POSIX shm + hipIpc, host/driver.hip) needs every rank on ONE host.  Counting ranks against visible devices cannot
+// tell the two apart (16 ranks on 2 x 8 GPUs, or one visible device per rank under srun --gpus-per-task=1), identities can.
+int exa_transport_from_identities(const void* ids, int nranks, char* err, int errlen) {
+   const char* t = (const char*)ids;
+   bool one_host = true, shared = false;
+   for (int i = 0; i < nranks; i++) {
+      if (std::strncmp(t, t + 96 * (size_t)i, 64) != 0) one_host = false;
+      for (int j = 0; j < i; j++) if (std::memcmp(t + 96 * (size_t)i, t + 96 * (size_t)j, 96) == 0) shared = true;
+   }
+   const char* e = std::getenv("EXA_TRANSPORT");
+   const std::string force = e ? e : "";
+   if (force == "ipc" || (force != "rccl" && shared)) {
+      if (!one_host) { set_err(err, errlen, "exa_bootstrap: the shared-device transport serves ranks of one host only; this group spans hosts (one GPU per rank and RCCL is the multi-node configuration)"); return -1; }
+      return 2;
+   }
+   if (shared) { set_err(err, errlen, "exa_bootstrap: EXA_TRANSPORT=rccl, but two ranks sit on the same device (RCCL refuses that)"); return -1; }
+   return 1;
+}
+
+namespace {
+int bootstrap_reply(const void* all, int nranks, int nbytes, void* reply, int reply_bytes, void* user) {
+   if (nbytes != 96 || reply_bytes != 132) return -1;
+   char* err = (char*)user;
+   const int kind = exa_transport_from_identities(all, nranks, err, 256);
+   if (kind < 0) { std::memset(reply, 0, 132); int32_t k = -1; std::memcpy((char*)reply + 128, &k, 4); std::snprintf((char*)reply, 128, "%s", err); return 0; }   // every rank learns why
+   try { if (kind == 2) Comm::ipc_unique_id(reply); else Comm::get_unique_id(reply); }
+   catch (const std::exception& e) { std::snprintf(err, 256, "exa_bootstrap: %s", e.what()); return -1; }
+   const int32_t k = kind; std::memcpy((char*)reply + 128, &k, 4);
+   return 0;
+}
+}
+
+// rank / size from the launcher's environment, device = local rank mod visible devices, then ONE TCP rendez-vous (host/bootstrap.cpp): every
+// rank sends the identity of its device, rank 0 decides the transport from them and answers with the unique id of that transport - a RCCL
+// id, or the shared-device transport's when ranks of one host share a GPU.  Everything `mechanics` needs before exa_driver_create (reference:
+// MPI_Init + MPI_Comm_rank/size, src/mechanics_driver.cpp:119-150)
 int exa_bootstrap(int* rank, int* nranks, void* uid128, char* err, int errlen) {
    int lr = 0;
    if (exa_bootstrap_env(rank, nranks, &lr) != 0) { set_err(err, errlen, "exa_bootstrap: inconsistent rank / size in the environment"); return -1; }
@@ -33,9 +68,19 @@ int exa_bootstrap(int* rank, int* nranks, void* uid128, char* err, int errlen) {
    if (hipSetDevice(lr % nd) != hipSuccess) { set_err(err, errlen, "exa_bootstrap: hipSetDevice failed"); return -1; }
    std::memset(uid128, 0, 128);
    if (*nranks > 1) {
-      if (*rank == 0 && exa_comm_unique_id(uid128, *nranks) != 0) { set_err(err, errlen, "exa_bootstrap: ncclGetUniqueId failed"); return -1; }
+      char mine[96]; std::memset(mine, 0, sizeof(mine));
+      if (::gethostname(mine, 63) != 0) std::snprintf(mine, 64, "unknown-host");
+      if (exa_device_identity(mine + 64, 32) != 0) std::snprintf(mine + 64, 32, "device-index-%d-of-%d", lr % nd, nd);
+      char reply[132]; char cb_err[256] = "";
       double tmo = 60.0; if (const char* t = std::getenv("EXA_RENDEZVOUS_TIMEOUT")) { const double v = std::atof(t); if (v > 0) tmo = v; }
-      if (exa_bootstrap_bcast(*rank, *nranks, uid128, 128, tmo, err, errlen) != 0) return -1;
+      if (exa_bootstrap_gather_reply(*rank, *nranks, mine, 96, reply, 132, bootstrap_reply, cb_err, tmo, err, errlen) != 0) {
+         if (cb_err[0]) set_err(err, errlen, cb_err);
+         return -1;
+      }
+      int32_t kind = 0; std::memcpy(&kind, reply + 128, 4);
+      if (kind < 0) { reply[127] = 0; set_err(err, errlen, reply); return -1; }
+      std::memcpy(uid128, reply, 128);
+      if (*rank == 0) std::fprintf(stderr, "exa_bootstrap: %d ranks, transport %s (decided from host names and PCI bus ids)\n", *nranks, kind == 2 ? "ipc (ranks share a device)" : "rccl");
    }
    return 0;
 }
@@ -61,8 +106,9 @@ int exa_device_identity(char* out, int len) {
    if (!out || len < 16 || hipGetDevice(&dev) != hipSuccess) return -1;
    return hipDeviceGetPCIBusId(out, len, dev) == hipSuccess ? 0 : -1;
 }
-// the id rank 0 hands out for a group of `nranks`: a RCCL unique id, or - when the ranks have to share devices (more ranks than visible
-// devices, or EXA_TRANSPORT=ipc) - the id of the inter-process transport of host/driver.hip (class Comm)
+// the id rank 0 hands out for a group of `nranks` when the caller has NOT compared device identities itself: a RCCL unique id, or - with
+// EXA_TRANSPORT=ipc, or when the ranks of this node outnumber its visible devices - the id of the inter-process transport of host/driver.hip
+// (class Comm).  bench.py compares identities and sets EXA_TRANSPORT; exa_bootstrap decides from identities (exa_transport_from_identities).
 int exa_comm_unique_id(void* out128, int nranks) {
    try { if (Comm::want_ipc_transport(nranks)) Comm::ipc_unique_id(out128); else Comm::get_unique_id(out128); return 0; }
    catch (const std::exception& e) { std::fprintf(stderr, "exa_comm_unique_id: %s\n", e.what()); return -1; }

@@ -213,6 +213,20 @@ __global__ void k_init_state(const int Q, const int64_t P, const double* __restr
    sv[IND_VOL * st] = 1.0; sv[IND_EINT * st] = 0.0;
 }
 
+// state slot 0 (effective shear rate) rebuilt from the stored slip rates: the invariant the hardness update relies on when it reads the
+// begin-of-step rate from slot 0 (include/exaconstit_hip.h, "State layout"); for states that were not written by this library
+template <bool QB>
+__global__ void k_state_normalize(const int Q, const int64_t P, double* __restrict__ state) {
+   const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (ip >= P) return;
+   const QView v = qview<QB>(NSTATEV, Q, ip / Q, (int)(ip % Q));
+   double* sv = state + v.base; const int64_t st = v.stride;
+   double sum = 0.0;
+#pragma unroll
+   for (int a = 0; a < NSLIP; a++) sum += fabs(sv[(H_GDOT + a) * st]);
+   sv[H_SHRATE * st] = sum;
+}
+
 // calcDpMat (reference src/mechanics_ecmech.hpp:315-356)
 template <bool QB>
 __global__ void k_calc_dp(const double qsign, const int Q, const int64_t P, const double* __restrict__ state, double* __restrict__ dp) {
@@ -278,6 +292,10 @@ int exa_launch_nfev_hist(exa_ctx* ctx, const double* state, int* hist_dev, hipSt
 // once) takes the list up - from the saved solver state when the context holds the state buffers, from scratch otherwise - and, with a
 // second cap, lists what it cuts off itself for a third launch.
 // dynamic LDS of a launch of k_model_setup: shape rows (per wave for the element-blocked full launch, the whole table otherwise) + stash + slip table
+// The largest shape table that passes exa_g_in_lds is the p = 2 one (27 * 3 * 27 doubles; p = 3 has 64 * 3 * 64 > EXA_G_LDS_MAX_DOUBLES and stays
+// in global memory): with the stash and the slip table it must fit the 64 KB a launch gets without an attribute change.
+static_assert(64 * 3 * 64 > EXA_G_LDS_MAX_DOUBLES, "order-3 shape tables must not be staged in LDS by the constitutive launch");
+static_assert(sizeof(double) * ((size_t)27 * 3 * 27 + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE + 8 * ecmdev::NSLIP) <= 65536, "dynamic LDS of k_model_setup exceeds 64 KB");
 static size_t model_lds_bytes(const exa_ctx* ctx, bool km, bool p2f, bool qb, int tail_mode) {
    const int nrow = (qb && !tail_mode) ? EXA_MODEL_BS / 64 : ctx->Q;
    const size_t rows = (p2f || !exa_g_in_lds(ctx->n, nrow)) ? 0 : (size_t)ctx->n * 3 * nrow;
@@ -450,6 +468,14 @@ int exa_launch_init_state(exa_ctx* ctx, double* state0, const double* quats, con
    const int bs = 256;
    if (ctx->qblk) hipLaunchKernelGGL(k_init_state<true>, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->Q, ctx->P, hist_dev, quats, state0);
    else hipLaunchKernelGGL(k_init_state<false>, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->Q, ctx->P, hist_dev, quats, state0);
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   return EXA_OK;
+}
+
+int exa_launch_state_normalize(exa_ctx* ctx, double* state, hipStream_t s) {
+   const int bs = 256;
+   if (ctx->qblk) hipLaunchKernelGGL(k_state_normalize<true>, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->Q, ctx->P, state);
+   else hipLaunchKernelGGL(k_state_normalize<false>, dim3((unsigned)((ctx->P + bs - 1) / bs)), dim3(bs), 0, s, ctx->Q, ctx->P, state);
    EXA_HIP_CHECK(ctx, hipGetLastError());
    return EXA_OK;
 }

@@ -58,6 +58,7 @@ exa_get_quadrature_layout = _sig("exa_get_quadrature_layout", C.c_int, C.c_void_
 exa_qf_size = _sig("exa_qf_size", C.c_int64, C.c_void_p, C.c_int)
 EXA_QLAYOUT_AOS, EXA_QLAYOUT_EB64 = 0, 1
 exa_init_state = _sig("exa_init_state", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
+exa_state_normalize = _sig("exa_state_normalize", C.c_int, C.c_void_p, dptr, C.c_void_p)
 exa_model_setup = _sig("exa_model_setup", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_setup_lvec_records = _sig("exa_model_setup_lvec_records", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_setup_lvec = _sig("exa_model_setup_lvec", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
@@ -170,6 +171,10 @@ exa_driver_nfev_hist_of = _sig("exa_driver_nfev_hist_of", C.c_int, C.c_void_p, C
 exa_driver_get_diagnostics = _sig("exa_driver_get_diagnostics", None, C.c_void_p, C.POINTER(C.c_int64))
 exa_rccl_microbench = _sig("exa_rccl_microbench", C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_bootstrap_env = _sig("exa_bootstrap_env", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
+exa_bootstrap_reply_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+exa_bootstrap_gather_reply = _sig("exa_bootstrap_gather_reply", C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, exa_bootstrap_reply_fn, C.c_void_p,
+                                  C.c_double, C.c_char_p, C.c_int)
+exa_transport_from_identities = _sig("exa_transport_from_identities", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_int)
 exa_bootstrap_bcast = _sig("exa_bootstrap_bcast", C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_char_p, C.c_int)
 exa_bootstrap = _sig("exa_bootstrap", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_char_p, C.c_int)
 exa_driver_get_pcg_reduction = _sig("exa_driver_get_pcg_reduction", None, C.c_void_p, C.POINTER(C.c_double))

@@ -49,6 +49,17 @@ int exa_rccl_microbench(int iters, int n, double* out2, char* err, int errlen);
  * 127.0.0.1:29517); exa_bootstrap = both + device selection (local rank mod visible devices) + the RCCL unique id in uid128. */
 int exa_bootstrap_env(int* rank, int* nranks, int* local_rank);
 int exa_bootstrap_bcast(int rank, int nranks, void* buf, int nbytes, double timeout_s, char* err, int errlen);
+/* The rendez-vous in its general form: every rank contributes nbytes, rank 0 turns the table of all contributions (rank order) into the
+ * reply every rank receives (fn runs on rank 0 only; 0 = ok).  exa_bootstrap uses it to decide the transport from the IDENTITY of the
+ * ranks' devices (host name + PCI bus id): RCCL when every rank has a GPU of its own - on one node or several -, the shared-device
+ * inter-process transport only when ranks of ONE host share a device; ranks that share a device across hosts cannot exist, and the
+ * shared-device transport is refused for a group that spans hosts. */
+typedef int (*exa_bootstrap_reply_fn)(const void* all, int nranks, int nbytes, void* reply, int reply_bytes, void* user);
+int exa_bootstrap_gather_reply(int rank, int nranks, const void* mine, int nbytes, void* reply, int reply_bytes, exa_bootstrap_reply_fn fn, void* user,
+                               double timeout_s, char* err, int errlen);
+/* the decision itself, exposed for the tests: ids = nranks records of 96 bytes (host name[64], PCI bus id[32], zero padded);
+ * returns 1 = RCCL, 2 = shared-device transport, -1 = impossible (reason in err) - EXA_TRANSPORT=rccl|ipc overrides where it can */
+int exa_transport_from_identities(const void* ids, int nranks, char* err, int errlen);
 int exa_bootstrap(int* rank, int* nranks, void* uid128, char* err, int errlen);
 /* Test transport: `nranks` drivers on ONE device, one host thread each, exchanging through an in-process group instead of RCCL
  * (RCCL refuses two ranks on one device).  Pass the 128 bytes as the unique id of every rank; destroy after the drivers. */

@@ -95,6 +95,36 @@ int64_t exa_qf_size(const exa_ctx* ctx, int vdim);
  * (src/mechanics_driver.cpp:1058-1154): fills state0 (28,Q,E) from one quaternion per element. */
 int exa_init_state(exa_ctx* ctx, double* state0_dev, const double* quats_per_elem_dev /*(4,E)*/, exa_stream s);
 
+/* State layout ------------------------------------------------------------------------------------------------- */
+/* The 28 state variables of a quadrature point, all six models (index table of src/mechanics_ecmech.hpp:165-185; numHist + ne + 1,
+ * :136-141).  Slot = offset inside the (28, Q, E) quadrature function:
+ *
+ *    0        shrateEff   effective shear rate of the step, sum_a |gdot_a|            (ecmech::evptn::iHistA_shrateEff, "shrateEff")
+ *    1        shrEff      accumulated effective shear, slot 1 += slot 0 * dt          (iHistA_shrEff, "shrEff")
+ *    2        flowStr     ExaCMech's flow strength; ExaConstit stores the accumulated plastic work there ("pl_work",
+ *                         src/mechanics_ecmech.cpp:154-160) - so does this library
+ *    3        nFEval      residual evaluations the local Newton solve (SNLS trust-region dog-leg) of this point took in this step
+ *                         (iHistA_nFEval); 2 for an elastic point
+ *    4 .. 8   deviatoric elastic strain in the lattice frame, 5-vector              (iHistLbE, "elas_strain")
+ *    9 .. 12  lattice orientation, unit quaternion, scalar first                    (iHistLbQ, "quats")
+ *    13       hardness: slip-system strength g (Voce kinds) or dislocation density rho (Kocks-Mecking kinds)   (iHistLbH, "hardness")
+ *    14 .. 25 the 12 slip rates gdot_a of the converged step                          (iHistLbGdot, "gdot")
+ *    26       relative volume                                                         ("rel_vol")
+ *    27       internal energy per reference volume                                    ("int_eng")
+ *
+ * Two slots carry more than a value:
+ *    slot 0  is an INPUT of the next step: the hardness update takes the begin-of-step effective shear rate from it instead of
+ *            re-reading the 12 slip rates (88 B per point less traffic).  Invariant a caller-supplied state0 must satisfy:
+ *            slot 0 == sum_a |slot 14+a|.  It holds for every state this library wrote and for exa_init_state; a state that
+ *            comes from elsewhere (restart file, another code) is brought into this form by exa_state_normalize.
+ *    slot 3  follows the iteration PATH of the local solve, not only its result.  The library reproduces the reference solver's
+ *            path: against a CPU restatement of that solver the count is equal at >= 99.9 % of the points and never differs by more than one
+ *            (ulp-level ties of the trust-region acceptance tests; asserted by tests/test_gpu_parity.py, test_gpu_point_fixtures.py,
+ *            test_gpu_fullsize.py; measured 99.999 %, profiles/r04_nfev_agreement.txt).  The tail split (exa_set_newton_cap) does not
+ *            change it. */
+/* state[0] = sum_a |state[14+a]| at every point of a state array in the context's layout (see above) */
+int exa_state_normalize(exa_ctx* ctx, double* state_dev, exa_stream s);
+
 /* ExaCMechModel::ModelSetup (src/mechanics_ecmech.cpp:192-258), i.e. StressSetup/StateVarsSetup, grad_calc,
  * kernel_setup, getResponseECM, kernel_postprocessing fused into one launch.  On return (stream order) stress1, state1
  * and the column-major tangent d sigma/d eps hold end-of-step values.  Points whose local solve did not converge are

@@ -19,6 +19,13 @@ import orc  # noqa: E402
 
 CASES = [("fcc_voce", 0, 0, "props_cp_voce.txt", 0), ("bcc_voce", 1, 0, "props_cp_voce.txt", 2), ("fcc_voce_nl", 0, 1, "props_cp_vocenl.txt", 1),
          ("bcc_voce_nl", 1, 1, "props_cp_vocenl.txt", 3), ("fcc_kmdd", 0, 2, "props_cp_mts.txt", 4), ("bcc_kmdd", 1, 2, "props_cp_mts.txt", 5)]
+# Property variants (round 5): every power-law form of the Voce kinetics the device code carries (x^9, x^19, x^99, the rolled loop for another
+# integer exponent, exp(xn log|t|) for a non-integer one), a Voce-NL hardening exponent != 1, and Kocks-Mecking with p, q != 1.
+# (name, xtal, kin, property file, model id, {property index: value})
+M_FORMS = [("m0p1", 0.1), ("m0p05", 0.05), ("m0p01", 0.01), ("m1o31", 1.0 / 31.0), ("m0p03", 0.03)]
+VARIANTS = [(f"{c[0]}_{tag}", c[1], c[2], c[3], c[4], {7: m}) for c in (CASES[0], CASES[3]) for tag, m in M_FORMS]
+VARIANTS += [("fcc_voce_nl_mp0p7", 0, 1, "props_cp_vocenl.txt", 1, {12: 0.7}),
+             ("fcc_kmdd_p0p8_q1p4", 0, 2, "props_cp_mts.txt", 4, {10: 0.8, 11: 1.4}), ("bcc_kmdd_p0p8_q1p4", 1, 2, "props_cp_mts.txt", 5, {10: 0.8, 11: 1.4})]
 DTS = [0.005, 0.195, 0.1, 0.1, 0.2, 0.4]
 RECORD = (0, 2, 5)
 
@@ -26,8 +33,10 @@ if __name__ == "__main__":
     orc.build()
     out_dir = os.path.join(HERE, "point_fixtures")
     os.makedirs(out_dir, exist_ok=True)
-    for name, xtal, kin, pfile, model in CASES:
+    for name, xtal, kin, pfile, model, overrides in [c + ({},) for c in CASES] + VARIANTS:
         props = np.loadtxt(os.path.join(orc.REFDATA, pfile)).ravel()
+        for idx, val in overrides.items():
+            props[idx] = val
         rve = hipref.make_rve(orc, 2, distort=0.2, seed=11)
         P = rve["E"] * rve["Q"]
         quats = hipref.random_quats(rve["E"], seed=2024 + model)

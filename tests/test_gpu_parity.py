@@ -20,8 +20,19 @@ pytestmark = pytest.mark.gpu
 REFDATA_PROPS = {"voce": "props_cp_voce.txt", "vocenl": "props_cp_vocenl.txt", "mts": "props_cp_mts.txt"}
 
 
-def _props(orc, key):
-    return np.loadtxt(orc.REFDATA + "/" + REFDATA_PROPS[key]).ravel()
+def _props(orc, key, overrides=None):
+    props = np.loadtxt(orc.REFDATA + "/" + REFDATA_PROPS[key]).ravel()
+    for idx, val in (overrides or {}).items():
+        props[idx] = val
+    return props
+
+
+def _nfev_check(got, ref, what):
+    """State slot 3 (function evaluations of the local Newton solve) follows the iteration path: equal to the oracle's at >= 99.9 % of the
+    points and never off by more than one (ulp-level ties of the trust-region tests)."""
+    got = np.asarray(got).ravel(); ref = np.asarray(ref).ravel()
+    assert np.abs(got - ref).max() <= 1, (what, np.abs(got - ref).max())
+    assert np.mean(got == ref) >= 0.999, (what, float(np.mean(got == ref)), int((got != ref).sum()), got.size)
 
 
 def _orc_model_setup(orc, xtal, kin, props, rve, dt, J, vel_e, s0, sv0):
@@ -42,16 +53,41 @@ CASES = [
     ("bcc_kmdd", 1, 2, "mts", 5),
 ]
 
+# Property variants: every form of the Voce power law |tau/g|^(1/m - 1) the device code carries (ecm_device.hpp voce_gdot12 / pow_xn:
+# compile-time chains x^9, x^19, x^99 beside the x^49 of the shipped sets, the rolled square-and-multiply loop for any other integer
+# exponent, exp(xn log|t|) for a non-integer one), for Voce and Voce-NL (the latter also with a hardening exponent m' != 1), FCC and BCC;
+# and the Kocks-Mecking thermal-activation law with p, q != 1 (the general instantiation: the host only dispatches the p = q = 1 one
+# when the material says so, model_kernels.hip).  Index 7 of the Voce tables is m; 12 of the Voce-NL table m'; 10 / 11 of the
+# Kocks-Mecking table p / q (exaconstit_amd/csrc/host_tables.cpp exa_fill_mat_params).
+M_FORMS = [("m0p1", 0.1), ("m0p05", 0.05), ("m0p01", 0.01), ("m1o31", 1.0 / 31.0), ("m0p03", 0.03)]
+VARIANT_CASES = [(f"{c[0]}_{tag}", c[1], c[2], c[3], c[4], {7: m}) for c in CASES[:4] for tag, m in M_FORMS]
+VARIANT_CASES += [("fcc_voce_nl_mp0p7", 0, 1, "vocenl", 1, {12: 0.7}), ("bcc_voce_nl_mp0p7_m0p05", 1, 1, "vocenl", 3, {12: 0.7, 7: 0.05}),
+                  ("fcc_kmdd_p0p8_q1p4", 0, 2, "mts", 4, {10: 0.8, 11: 1.4}), ("bcc_kmdd_p0p8_q1p4", 1, 2, "mts", 5, {10: 0.8, 11: 1.4})]
+VARIANT_IDS = [c[0] for c in VARIANT_CASES]
+
 
 @pytest.mark.parametrize("name,xtal,kin,pkey,model", CASES)
 def test_model_setup_matches_oracle(oracle, name, xtal, kin, pkey, model):
     """Drive 8 kinematic steps (elastic -> fully plastic) and compare every output of ModelSetup each step."""
+    _check_model_setup(oracle, name, xtal, kin, _props(oracle, pkey), model)
+
+
+@pytest.mark.parametrize("name,xtal,kin,pkey,model,overrides", VARIANT_CASES, ids=VARIANT_IDS)
+def test_model_setup_property_variants(oracle, name, xtal, kin, pkey, model, overrides):
+    """The same comparison with edited property tables, so that every branch of the slip kinetics runs against the oracle's general pow()."""
+    props = _props(oracle, pkey, overrides)
+    if 7 in overrides:      # the exponent the host derives must select the intended device form
+        xn = 1.0 / props[7] - 1.0
+        assert {"m0p1": xn == 9.0, "m0p05": xn == 19.0, "m0p01": xn == 99.0, "m1o31": xn == 30.0, "m0p03": xn != np.floor(xn)}[
+            [t for t, _ in M_FORMS if name.endswith(t)][0]]
+    _check_model_setup(oracle, name, xtal, kin, props, model)
+
+
+def _check_model_setup(orc, name, xtal, kin, props, model):
     import exaconstit_amd.lib as L
-    orc = oracle
     dev = hipref.Dev()
     N = 6
     rve = hipref.make_rve(orc, N, distort=0.15)
-    props = _props(orc, pkey)
     P = rve["E"] * rve["Q"]
     ctx = L.Context(model, props, 298.0, 1, rve["E"])
     # reference-element table of the library == oracle's
@@ -71,6 +107,7 @@ def test_model_setup_matches_oracle(oracle, name, xtal, kin, pkey, model):
     vel_e = hipref.l_to_e(rve, v_nodes)
     x = rve["X"].copy()
     dts = [0.005, 0.195, 0.1, 0.1, 0.2, 0.4, 0.5, 1.0]
+    nfev_gpu, nfev_ref = [], []
     for step, dt in enumerate(dts):
         x = x + v_nodes * dt                      # end-of-step coordinates
         xe = hipref.l_to_e(rve, x)
@@ -95,6 +132,7 @@ def test_model_setup_matches_oracle(oracle, name, xtal, kin, pkey, model):
         for lo, hi in ((0, 3), (3, 8), (8, 12), (12, 13), (13, 25), (25, 27)):
             assert rel_l2(a[:, lo:hi], b[:, lo:hi]) < 1e-8, (name, step, lo)
         assert rel_l2(g_cm, cm) < 1e-7, (name, step)
+        nfev_gpu.append(g_sv1.reshape(P, 28)[:, 3].copy()); nfev_ref.append(sv1.reshape(P, 28)[:, 3].copy())
         # fused L-vector entry (gathers nodes, computes and writes J): same answers as the E-vector entry, J == exa_jacobians
         if step in (0, len(dts) - 1):
             import torch
@@ -110,7 +148,64 @@ def test_model_setup_matches_oracle(oracle, name, xtal, kin, pkey, model):
         s0, sv0 = s1, sv1                          # both sides continue from the oracle's state
     # the last steps must be plastic for the test to mean anything
     assert np.abs(sv0.reshape(P, 28)[:, 14:26]).sum(axis=1).min() > 0
+    assert np.concatenate(nfev_ref).max() > 4
+    _nfev_check(np.concatenate(nfev_gpu), np.concatenate(nfev_ref), name)
     ctx.close()
+
+
+@pytest.mark.parametrize("name,xtal,kin,pkey,model", [CASES[0], CASES[5]])
+def test_foreign_state_is_normalised(oracle, name, xtal, kin, pkey, model):
+    """A begin-of-step state that was not written by this library (restart file of another code): slip rates present, slot 0 (effective
+    shear rate) not the sum of their magnitudes.  The reference's hardness update sums the 12 rates (ExaCMech updateH through
+    getResponseECM, src/mechanics_ecmech.cpp:176-186); the kernel reads slot 0, so exa_state_normalize must restore the invariant
+    (include/exaconstit_hip.h, "State layout") - after it the update equals the oracle's on the foreign state, in both layouts."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 4, distort=0.15)
+    E, Q, P = rve["E"], rve["Q"], rve["E"] * rve["Q"]
+    props = _props(orc, pkey)
+    quats = hipref.random_quats(E)
+    hist = np.zeros(26); orc.lib().orc_hist_init(xtal, kin, orc._p(props), len(props), orc._p(hist))
+    sv0 = np.tile(np.concatenate([hist, [1.0, 0.0]]), P).reshape(P, 28); sv0[:, 9:13] = np.repeat(quats, Q, axis=0); sv0 = sv0.ravel()
+    s0 = np.zeros(6 * P)
+    v_nodes = hipref.velocity_field(rve); vel_e = hipref.l_to_e(rve, v_nodes)
+    x = rve["X"].copy()
+    for dt in (0.005, 0.195, 0.2, 0.4, 0.5):              # oracle alone: reach plastic flow
+        x = x + v_nodes * dt
+        J = np.zeros(9 * P); orc.lib().orc_jacobians(1, E, orc._p(hipref.l_to_e(rve, x)), orc._p(J))
+        nf, s0, sv0, _, _ = _orc_model_setup(orc, xtal, kin, props, rve, dt, J, vel_e, s0, sv0)
+        assert nf == 0
+    foreign = sv0.reshape(P, 28).copy()
+    assert np.abs(foreign[:, 14:26]).sum(axis=1).min() > 0
+    foreign[:, 0] = 0.0                                    # "shrateEff" absent from the foreign file
+    dt = 0.5
+    x = x + v_nodes * dt
+    J = np.zeros(9 * P); orc.lib().orc_jacobians(1, E, orc._p(hipref.l_to_e(rve, x)), orc._p(J))
+    nf, s1, sv1, cm, _ = _orc_model_setup(orc, xtal, kin, props, rve, dt, J, vel_e, s0, foreign.ravel())
+    assert nf == 0
+    for layout in (L.EXA_QLAYOUT_AOS, L.EXA_QLAYOUT_EB64):
+        ctx = L.Context(model, props, 298.0, 1, E)
+        if layout == L.EXA_QLAYOUT_EB64:
+            ctx.check(L.exa_set_quadrature_layout(ctx.h, layout))
+            up = lambda a, w: dev.up(_aos_to_eb64(a, E, Q, w)); down = lambda t, w: _eb64_to_aos(t, E, Q, w).cpu().numpy()
+        else:
+            up = lambda a, w: dev.up(np.asarray(a).ravel()); down = lambda t, w: t.cpu().numpy().reshape(P, w)
+        sz = lambda w: int(L.exa_qf_size(ctx.h, w))
+        d_sv0 = up(foreign, 28)
+        ctx.check(L.exa_state_normalize(ctx.h, ptr(d_sv0), None))
+        n0 = down(d_sv0, 28)
+        assert np.array_equal(n0[:, 1:], foreign[:, 1:]) and rel_l2(n0[:, 0], np.abs(foreign[:, 14:26]).sum(axis=1)) < 1e-15
+        d_J, d_v, d_s0 = up(J, 9), dev.up(vel_e), up(s0, 6)
+        o = [dev.zeros(sz(6)), dev.zeros(sz(28)), dev.zeros(sz(36))]
+        ctx.check(L.exa_model_setup(ctx.h, dt, ptr(d_J), ptr(d_v), ptr(d_s0), ptr(d_sv0), ptr(o[0]), ptr(o[1]), ptr(o[2]), None))
+        assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+        keep = np.ones(28, bool); keep[3] = False
+        assert rel_l2(down(o[0], 6).ravel(), s1) < 1e-9, (name, layout)
+        assert rel_l2(down(o[1], 28)[:, 13], sv1.reshape(P, 28)[:, 13]) < 1e-10, (name, layout)       # the hardness is what slot 0 feeds
+        assert rel_l2(down(o[1], 28)[:, keep], sv1.reshape(P, 28)[:, keep]) < 1e-8, (name, layout)
+        assert rel_l2(down(o[2], 36).ravel(), cm) < 1e-7, (name, layout)
+        ctx.close()
 
 
 def _spd_tangent(P, seed=3):
@@ -643,20 +738,28 @@ def _aos_to_eb64(a, E, Q, W):
     return np.ascontiguousarray(full.reshape(nb, 64, Q, W).transpose(0, 2, 3, 1)).ravel()
 
 
+@pytest.mark.parametrize("name,xtal,kin,pkey,model,overrides", VARIANT_CASES, ids=VARIANT_IDS)
+def test_default_product_path_property_variants(oracle, name, xtal, kin, pkey, model, overrides):
+    """test_default_product_path_matches_oracle with the edited property tables of VARIANT_CASES (every power-law form, m' != 1, p,q != 1)."""
+    _check_default_product_path(oracle, name, xtal, kin, _props(oracle, pkey, overrides), model)
+
+
 @pytest.mark.parametrize("name,xtal,kin,pkey,model", CASES)
 def test_default_product_path_matches_oracle(oracle, name, xtal, kin, pkey, model):
+    _check_default_product_path(oracle, name, xtal, kin, _props(oracle, pkey), model)
+
+
+def _check_default_product_path(orc, name, xtal, kin, props, model):
     """The path the stand-alone driver and bench.py run by default - element-blocked quadrature functions, the fused L-vector constitutive
     launch (node gather + Jacobians + update), the residual from L-vectors, and the geometry-recomputing action on compact tangent records,
     partial and element assembly - compared DIRECTLY with the oracle point by point, every step from elastic to fully plastic (the other
     layout tests compare this path with the reference-layout path; here there is no intermediate)."""
     import torch
     import exaconstit_amd.lib as L
-    orc = oracle
     dev = hipref.Dev()
     rve = hipref.make_rve(orc, 5, distort=0.15)      # E = 125: a partial last block of 64
     E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
     P = E * Q
-    props = _props(orc, pkey)
     quats = hipref.random_quats(E)
     d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
     v_nodes = hipref.velocity_field(rve)
@@ -677,6 +780,7 @@ def test_default_product_path_matches_oracle(oracle, name, xtal, kin, pkey, mode
     xg = np.random.default_rng(5).standard_normal(3 * NN)
     mask_np = (np.random.default_rng(6).random(3 * NN) < 0.1).astype(np.uint8)
     keep = np.ones(28, bool); keep[3] = False
+    nfev_gpu, nfev_ref = [], []
     for step, dt in enumerate([0.005, 0.195, 0.1, 0.2, 0.4, 0.5, 1.0]):
         x = x + v_nodes * dt
         xe = hipref.l_to_e(rve, x)
@@ -690,10 +794,12 @@ def test_default_product_path_matches_oracle(oracle, name, xtal, kin, pkey, mode
         assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
         assert rel_l2(_eb64_to_aos(d_J, E, Q, 9).cpu().numpy().ravel(), J) < 1e-13
         assert rel_l2(_eb64_to_aos(d_s1, E, Q, 6).cpu().numpy().ravel(), s1) < 1e-9, (name, step)
-        a = _eb64_to_aos(d_sv1, E, Q, 28).cpu().numpy()[:, keep]; b = sv1.reshape(P, 28)[:, keep]
+        g_sv = _eb64_to_aos(d_sv1, E, Q, 28).cpu().numpy()
+        a = g_sv[:, keep]; b = sv1.reshape(P, 28)[:, keep]
         for lo, hi in ((0, 3), (3, 8), (8, 12), (12, 13), (13, 25), (25, 27)):
             assert rel_l2(a[:, lo:hi], b[:, lo:hi]) < 1e-8, (name, step, lo)
         assert rel_l2(_eb64_to_aos(d_cm, E, Q, 36).cpu().numpy().ravel(), cm) < 1e-7, (name, step)
+        nfev_gpu.append(g_sv[:, 3].copy()); nfev_ref.append(sv1.reshape(P, 28)[:, 3].copy())
         # residual F(sigma) from L-vectors against the oracle's AssemblePA + AddMultPA + E->L
         dmat = np.zeros(9 * P); orc.lib().orc_assemble_pa(Q, E, orc._p(rve["W"]), orc._p(J), orc._p(s1), orc._p(dmat))
         ye = np.zeros(3 * n * E); orc.lib().orc_add_mult_pa(Q, E, n, orc._p(rve["G"]), orc._p(dmat), orc._p(ye))
@@ -735,6 +841,7 @@ def test_default_product_path_matches_oracle(oracle, name, xtal, kin, pkey, mode
             assert L.exa_grad_diagonal(c2.h, ptr(dev.zeros(3 * n * E)), None) < 0      # the full-record consumers say so instead of reading stale data
         s0, sv0 = s1, sv1
     assert np.abs(sv0.reshape(P, 28)[:, 14:26]).sum(axis=1).min() > 0      # fully plastic at the end
+    _nfev_check(np.concatenate(nfev_gpu), np.concatenate(nfev_ref), name)
     for c in ctxs.values(): c.close()
 
 

@@ -1,7 +1,7 @@
 """Per-quadrature-point golden fixtures (tests/golden/point_fixtures/*.npz, written by tests/golden/make_point_fixtures.py from the oracle
 after it was pinned to the reference's golden curves) replayed through the C ABI of the HIP library WITHOUT the oracle: inputs are the
 Jacobians, E-vector velocity, begin-of-step stress and state of 64 points per model in the elastic, transition and plastic regime; expected
-outputs are stress (1e-9 rel-L2), state (1e-8 per slot group; the evaluation counter, slot 3, must agree for >= 95 % of the points) and
+outputs are stress (1e-9 rel-L2), state (1e-8 per slot group; the evaluation counter, slot 3, must agree at >= 99.9 % of the points and never differ by more than one) and
 the tangent (1e-7).  Also checks the GPU tangent against central differences of the GPU stress update along isochoric directions."""
 import os
 
@@ -14,6 +14,9 @@ from hipref import rel_l2, ptr
 pytestmark = pytest.mark.gpu
 FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "point_fixtures")
 MODELS = ["fcc_voce", "bcc_voce", "fcc_voce_nl", "bcc_voce_nl", "fcc_kmdd", "bcc_kmdd"]
+# property variants (tests/golden/make_point_fixtures.py VARIANTS): every power-law form of the Voce kinetics, m' != 1, Kocks-Mecking p, q != 1
+MODELS += [f"{b}_{t}" for b in ("fcc_voce", "bcc_voce_nl") for t in ("m0p1", "m0p05", "m0p01", "m1o31", "m0p03")]
+MODELS += ["fcc_voce_nl_mp0p7", "fcc_kmdd_p0p8_q1p4", "bcc_kmdd_p0p8_q1p4"]
 
 
 def _gpu_update(L, ctx, dev, dt, J, vel_e, s0, sv0, P):
@@ -31,15 +34,19 @@ def test_point_fixtures(name):
     E, Q = int(z["E"]), int(z["Q"]); P = E * Q
     dev = hipref.Dev()
     ctx = L.Context(int(z["model"]), z["props"], 298.0, 1, E)
-    keep = np.ones(28, bool); keep[3] = False
+    nf_gpu, nf_ref = [], []
     for step in z["steps"]:
         s1, sv1, cm = _gpu_update(L, ctx, dev, z[f"dt_{step}"], z[f"J_{step}"], z["vel_e"], z[f"s0_{step}"], z[f"sv0_{step}"], P)
         assert rel_l2(s1, z[f"s1_{step}"]) < 1e-9, (name, step)
         a = sv1.reshape(P, 28); b = z[f"sv1_{step}"].reshape(P, 28)
         for lo, hi in ((0, 3), (4, 9), (9, 13), (13, 14), (14, 26), (26, 28)):
             assert rel_l2(a[:, lo:hi], b[:, lo:hi]) < 1e-8, (name, step, lo)
-        assert np.mean(a[:, 3] == b[:, 3]) >= 0.95, (name, step)          # function-evaluation counts of the local solver
+        nf_gpu.append(a[:, 3].copy()); nf_ref.append(b[:, 3].copy())
         assert rel_l2(cm, z[f"cm_{step}"]) < 1e-7, (name, step)
+    # function-evaluation counts of the local solver (state slot 3): the iteration path is part of parity
+    nf_gpu = np.concatenate(nf_gpu); nf_ref = np.concatenate(nf_ref)
+    assert np.abs(nf_gpu - nf_ref).max() <= 1, (name, np.abs(nf_gpu - nf_ref).max())
+    assert np.mean(nf_gpu == nf_ref) >= 0.999, (name, float(np.mean(nf_gpu == nf_ref)))
     ctx.close()
 
 

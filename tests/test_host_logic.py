@@ -229,6 +229,61 @@ def test_launcher_bootstrap_rendezvous(style):
         assert "rank %d of 3 local %d payload_ok 1" % (rank, rank) in out
 
 
+def _ident_table(recs):
+    import ctypes as C
+    t = (C.c_ubyte * (96 * len(recs)))()
+    for i, (h, d) in enumerate(recs):
+        for k, b in enumerate(h.encode()[:63]): t[96 * i + k] = b
+        for k, b in enumerate(d.encode()[:31]): t[96 * i + 64 + k] = b
+    return t
+
+
+def test_transport_decided_from_device_identities(monkeypatch):
+    """exa_bootstrap picks the transport from (host name, PCI bus id) of every rank, not from rank and device COUNTS: 16 ranks on 2 nodes x 8
+    GPUs (more ranks than any rank sees devices) and one visible device per rank (srun --gpus-per-task=1) are RCCL launches; only ranks of one
+    host that share a device get the shared-device transport, and that transport is refused across hosts."""
+    import ctypes as C
+    import exaconstit_amd.lib as L
+    monkeypatch.delenv("EXA_TRANSPORT", raising=False)
+    err = C.create_string_buffer(256)
+    dec = lambda recs: L.exa_transport_from_identities(_ident_table(recs), len(recs), err, 256)
+    gpus = ["0000:%02x:00.0" % b for b in (0x05, 0x15, 0x65, 0x75, 0x85, 0x95, 0xe5, 0xf5)]
+    assert dec([("nodeA", g) for g in gpus]) == 1                                             # one node, 8 GPUs, 8 ranks
+    assert dec([("nodeA", g) for g in gpus] + [("nodeB", g) for g in gpus]) == 1              # 2 x 8: same bus ids on the other host are other GPUs
+    assert dec([("box", gpus[0]), ("box", gpus[0])]) == 2                                     # two ranks on the one GPU of a test box
+    assert dec([("box", gpus[0])] * 8) == 2
+    assert dec([("nodeA", gpus[0]), ("nodeA", gpus[0]), ("nodeB", gpus[0])]) == -1 and b"one host" in err.value      # shared device + several hosts
+    monkeypatch.setenv("EXA_TRANSPORT", "ipc")
+    assert dec([("nodeA", g) for g in gpus]) == 2                                             # forced, one host: allowed (plumbing runs)
+    assert dec([("nodeA", gpus[0]), ("nodeB", gpus[0])]) == -1
+    monkeypatch.setenv("EXA_TRANSPORT", "rccl")
+    assert dec([("box", gpus[0]), ("box", gpus[0])]) == -1 and b"same device" in err.value    # RCCL refuses two ranks on a device: say so early
+    assert dec([("nodeA", gpus[0]), ("nodeB", gpus[0])]) == 1
+
+
+@pytest.mark.parametrize("case", ["two_nodes", "shared_device"])
+def test_bootstrap_gathers_identities(case):
+    """The rendez-vous in its gather-and-reply form (what exa_bootstrap runs): four real processes contribute an identity each, rank 0
+    decides, every rank receives the same decision and table.  Peers start before rank 0 (they retry).  No GPU."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bootstrap_worker.py")
+    ident = {"two_nodes": [("n0", "0000:05:00.0"), ("n0", "0000:15:00.0"), ("n1", "0000:05:00.0"), ("n1", "0000:15:00.0")],
+             "shared_device": [("box", "0000:05:00.0")] * 4}[case]
+    procs = []
+    for rank in (3, 2, 1, 0):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PMI_RANK", "PMI_SIZE", "EXA_RANK", "EXA_NRANKS", "MASTER_PORT", "MASTER_ADDR", "EXA_TRANSPORT")}
+        env.update({"EXA_RANK": str(rank), "EXA_NRANKS": "4", "EXA_MASTER_PORT": str(port), "FAKE_HOST": ident[rank][0], "FAKE_PCI": ident[rank][1]})
+        procs.append((rank, subprocess.Popen([sys.executable, worker, "gather"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    want = "kind %d hosts %s pcis %s" % (1 if case == "two_nodes" else 2, ",".join(h for h, _ in ident), ",".join(d for _, d in ident))
+    for rank, p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, (rank, out, err)
+        assert ("rank %d of 4 " % rank) + want in out, (out, err)
+
+
 def test_bootstrap_without_launcher():
     import ctypes as C
     import exaconstit_amd.lib as L
