@@ -183,8 +183,15 @@ inline void mesh_init(Mesh& m, const RefElem& re, int nx, int ny, int nz, double
    }
 }
 
+// Threads of the element / point loops: 1 = serial like the reference's rtmodel=CPU path (MFEM_FORALL on the cpu device); orc_set_threads(n > 1) is
+// the stand-in for its rtmodel=OPENMP / mpirun -np n runs in bench.py's cpu_baseline leg.  Every parallel loop below writes disjoint outputs per
+// element (the E->L sum stays serial), so the results do not depend on the thread count.
+inline int& model_threads() { static int n = 1; return n; }
+#define ORC_PAR_FOR _Pragma("omp parallel for schedule(static) num_threads(model_threads()) if (model_threads() > 1)")
+
 // L-vector (byNODES) -> E-vector (node, comp, elem)
 inline void restrict_LtoE(const Mesh& m, const double* L, double* Ev) {
+   ORC_PAR_FOR
    for (int e = 0; e < m.E; e++) for (int c = 0; c < 3; c++) for (int a = 0; a < m.n; a++)
       Ev[a + m.n * (c + 3 * e)] = L[m.conn[a + m.n * e] + m.NN * c];
 }
@@ -197,6 +204,7 @@ inline void restrict_EtoL_add(const Mesh& m, const double* Ev, double* L) {
 // J(i,j,q,e) = sum_a x(a,i,e) * G(a,j,q)           (MFEM GeometricFactors + re-layout, mechanics_operator.cpp:350-391)
 inline void jacobians(const RefElem& re, int E, const double* xe /*(n,3,E)*/, double* J /*(3,3,Q,E)*/) {
    const int n = re.n, Q = re.Q;
+   ORC_PAR_FOR
    for (int e = 0; e < E; e++) for (int q = 0; q < Q; q++) for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) {
       double s = 0;
       for (int a = 0; a < n; a++) s += xe[a + n * (i + 3 * e)] * re.G[a + n * (j + 3 * q)];
@@ -220,6 +228,7 @@ inline void adjugate3(const double* J, double* adj) {
 
 // grad_calc: field_grad(q,t,qpt,e) += sum_{r,s} field(r,q,e) G(r,s,qpt) Jinv(s,t)   (output must be pre-zeroed)
 inline void grad_calc(int Q, int E, int n, const double* J, const double* G, const double* field, double* fgrad) {
+   ORC_PAR_FOR
    for (int e = 0; e < E; e++) {
       for (int q = 0; q < Q; q++) {
          const double* Jq = &J[9 * (q + (size_t)Q * e)];
@@ -238,7 +247,6 @@ inline void grad_calc(int Q, int E, int n, const double* J, const double* G, con
 // ExaCMechModel::ModelSetup  (K2..K9)
 // ---------------------------------------------------------------------------------------------
 struct ModelOpts { bool transpose_tangent = true; ecm::PointOpts po; };
-inline int& model_threads() { static int n = 1; return n; }
 
 // returns number of points whose local solve failed
 inline int model_setup(const ecm::Model& mdl, int Q, int E, int n, int nstatev, double dt, double temp_k,
@@ -308,6 +316,7 @@ inline int model_setup(const ecm::Model& mdl, int Q, int E, int n, int nstatev, 
 // AssemblePA: D(j,k,q,e) = W_q * sum_l sigma(k,l) adj(J)(j,l)          mechanics_integrators.cpp:240-312
 inline void assemble_pa(int Q, int E, const double* W, const double* J, const double* stress1, double* dmat) {
    static const int V[3][3] = { { 0, 5, 4 }, { 5, 1, 3 }, { 4, 3, 2 } };
+   ORC_PAR_FOR
    for (int e = 0; e < E; e++) for (int q = 0; q < Q; q++) {
       const size_t ip = q + (size_t)Q * e;
       double adj[9]; adjugate3(&J[9 * ip], adj);
@@ -321,6 +330,7 @@ inline void assemble_pa(int Q, int E, const double* W, const double* J, const do
 
 // AddMultPA: Y(i,k,e) += sum_q sum_j G(i,j,q) D(j,k,q,e)                mechanics_integrators.cpp:545-555
 inline void add_mult_pa(int Q, int E, int n, const double* G, const double* dmat, double* Y) {
+   ORC_PAR_FOR
    for (int e = 0; e < E; e++) for (int q = 0; q < Q; q++) {
       const double* D = &dmat[9 * (q + (size_t)Q * e)];
       for (int k = 0; k < 3; k++) for (int j = 0; j < 3; j++) for (int i = 0; i < n; i++)
@@ -332,6 +342,7 @@ inline int voigt(int i, int j) { static const int V[3][3] = { { 0, 5, 4 }, { 5, 
 
 // TransformMatGradTo4D: C4(i,j,k,l,p) = C(voigt(i,j), voigt(k,l), p)    mechanics_model.cpp:970-1060
 inline void transform_matgrad_4d(size_t P, const double* C /*(6,6,P)*/, double* C4 /*(3,3,3,3,P)*/) {
+   ORC_PAR_FOR
    for (size_t ip = 0; ip < P; ip++)
       for (int l = 0; l < 3; l++) for (int k = 0; k < 3; k++) for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++)
          C4[i + 3 * (j + 3 * (k + 3 * (l + 3 * ip)))] = C[voigt(i, j) + 6 * (voigt(k, l) + 6 * ip)];
@@ -340,6 +351,7 @@ inline void transform_matgrad_4d(size_t P, const double* C /*(6,6,P)*/, double* 
 // AssembleGradPA: D4(e,q,i,k,l,n) = dt W/detJ * sum_{j,m} A(j,i) C4(j,k,l,m) A(m,n), A(r,c)=adj[r+3c] (col-major view)
 //                                                                       mechanics_integrators.cpp:425-511
 inline void assemble_grad_pa(int Q, int E, double dt, const double* W, const double* J, const double* C4, double* D4 /*row-major (E,Q,3,3,3,3)*/) {
+   ORC_PAR_FOR
    for (int e = 0; e < E; e++) for (int q = 0; q < Q; q++) {
       const size_t ip = q + (size_t)Q * e;
       const double* Jq = &J[9 * ip];
@@ -358,6 +370,7 @@ inline void assemble_grad_pa(int Q, int E, double dt, const double* W, const dou
 
 // AddMultGradPA                                                            mechanics_integrators.cpp:592-620
 inline void add_mult_grad_pa(int Q, int E, int n, const double* G, const double* D4, const double* X, double* Y) {
+   ORC_PAR_FOR
    for (int e = 0; e < E; e++) for (int q = 0; q < Q; q++) {
       const double* D = &D4[81 * (q + (size_t)Q * e)];
       double gx[3][3];   // gx[i][j] = sum_k G(k,j,q) X(k,i,e)
@@ -372,6 +385,7 @@ inline void add_mult_grad_pa(int Q, int E, int n, const double* G, const double*
 inline void assemble_grad_diag_pa(int Q, int E, int n, double dt, const double* W, const double* G, const double* J, const double* K /*(6,6,Q,E)*/, double* Y) {
    // Voigt rows hit by a unit displacement gradient of component c: (xx|xy|xz) etc.
    static const int R[3][3] = { { 0, 5, 4 }, { 5, 1, 3 }, { 4, 3, 2 } };
+   ORC_PAR_FOR
    for (int e = 0; e < E; e++) for (int q = 0; q < Q; q++) {
       const size_t ip = q + (size_t)Q * e;
       const double* Jq = &J[9 * ip];

@@ -101,7 +101,6 @@ class ExaModel {
    mfem::QuadratureFunction* GetStress1() { return stress1; }
    mfem::QuadratureFunction* GetMatGrad() { return matGrad; }
    mfem::QuadratureFunction* GetMatVars0() { return matVars0; }
-   mfem::QuadratureFunction* GetMatVars1() { return matVars1; }
 };
 
 class ExaNLFIntegrator : public mfem::NonlinearFormIntegrator {

@@ -37,6 +37,23 @@ def build():
 _lib = None
 
 
+def build_native(out_dir):
+    """The oracle compiled for THIS host (-O3 -march=native -fopenmp) into out_dir: the CPU-baseline leg of bench.py times this build (a
+    -march=native object must not travel between machines, so it is never written into the tree).  Returns the path."""
+    so = os.path.join(out_dir, "liboracle_native.so")
+    subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-fopenmp", "-Wno-unused-variable", "-shared", "-o", so,
+                           os.path.join(ORACLE_DIR, "oracle_capi.cpp")])
+    return so
+
+
+def use_lib(path):
+    """bind this module to another build of the oracle (bench.py: the -march=native one)"""
+    global _lib
+    _lib = C.CDLL(path)
+    _lib.orc_ref_elem.restype = C.c_int
+    return _lib
+
+
 def lib():
     global _lib
     if _lib is None:
