@@ -606,6 +606,13 @@ void NonlinearMechOperator::Setup(const double* k) {
    EXA_HC(hipEventRecord(ev.b, stream_)); ev.pending = true;
    timers.qpt_updates += (int64_t)E_ * npe_; model_calls++;
    model_status_pending_ = true;
+   static const bool log_hist = std::getenv("EXA_NFEV_LOG") != nullptr;      // measurement aid: evaluation-count histogram of every launch on stderr (synchronises)
+   if (log_hist) {
+      int h[64]; abi_check(ctx_, exa_model_nfev_hist(ctx_, matVars1.p, h, stream_), "exa_model_nfev_hist");
+      std::fprintf(stderr, "nfev_hist call %ld dt %.4g cap %d tail %d:", (long)model_calls, dt_, newton_cap_, newton_cap_ > 0 ? exa_model_tail_count(ctx_, stream_) : 0);
+      for (int i = 0; i < 64; i++) if (h[i]) std::fprintf(stderr, " %d:%d", i, h[i]);
+      std::fprintf(stderr, "\n");
+   }
    if (cap_auto_ && (model_calls <= 4 || model_calls % 4 == 0)) {   // tail split: next cap from the evaluation counts of this launch (the distribution drifts slowly)
       int h[64]; abi_check(ctx_, exa_model_nfev_hist(ctx_, matVars1.p, h, stream_), "exa_model_nfev_hist");
       // (one dense launch: measured at 128^3, a second level loses - FCC 5: 18.0 ms, 5+11: 19.0, 4+6: 21.1; BCC 4: 9.7, 3+5: 13.1 - because

@@ -7,10 +7,11 @@ with tempfile.TemporaryDirectory() as d:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-amdgpu-use-amdgpu-trackers=1",
                            "-fno-signed-zeros", "-fno-trapping-math", "-fno-math-errno", "-S", "--cuda-device-only", "-o", s, src] + sys.argv[1:], stderr=subprocess.DEVNULL)
     t = open(s).read()
-names = {"0": "Voce", "1": "VoceNL", "2": "KM-FCC", "3": "KM-BCC", "6": "KM-FCC p=q=1", "7": "KM-BCC p=q=1"}
-for m in re.finditer(r'\.name:\s+(_Z13k_model_setupILi(\d)ELb(\d)ELi(\d+)ELb(\d)ELb(\d)EE\S*)\n((?:.*\n){1,14})', t):
+names = {"0": "Voce", "1": "VoceNL", "2": "KM-FCC", "3": "KM-BCC", "6": "KM-FCC p=q=1", "7": "KM-BCC p=q=1", "8": "Voce x^49", "9": "VoceNL x^49"}
+for m in re.finditer(r'\.name:\s+(_Z13k_model_setupILi(\d+)ELb(\d)ELi(\d+)ELb(\d)ELb(\d)EE\S*)\n((?:.*\n){1,14})', t):
     kin, lvec, nfix, qb, rec, body = m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), m.group(7)
     if not (lvec == "1" and nfix == "8" and qb == "1"):
         continue
     g = lambda k: int(re.search(k + r':\s+(\d+)', body).group(1))
-    print("%-13s rec=%s  vgpr %d  sgpr-spills %d  vgpr-spills %d  scratch %d B" % (names[kin], rec, g(r'\.vgpr_count'), g(r'\.sgpr_spill_count'), g(r'\.vgpr_spill_count'), g(r'\.private_segment_fixed_size')))
+    ag = re.search(r'\.agpr_count:\s+(\d+)', body)
+    print("%-13s rec=%s  vgpr %d  agpr %s  sgpr-spills %d  vgpr-spills %d  scratch %d B" % (names.get(kin, kin), rec, g(r'\.vgpr_count'), ag.group(1) if ag else "?", g(r'\.sgpr_spill_count'), g(r'\.vgpr_spill_count'), g(r'\.private_segment_fixed_size')))
