@@ -146,7 +146,15 @@ __global__ __launch_bounds__(PA_BLK) void k_ea_apply_gen(const int E, const doub
       for (int a = 0; a < N; a++) {
          const int g = conn[a + N * e];
 #pragma unroll
-         for (int c = 0; c < 3; c++) { const int64_t idx = g + (int64_t)nnodes * c; X[a + N * c] = (mask != nullptr && mask[idx]) ? 0.0 : x[idx]; }
+         for (int c = 0; c < 3; c++) X[a + N * c] = x[g + (int64_t)nnodes * c];
+      }
+      if (mask != nullptr) {   // second pass: no x load waits for its mask byte (pa_kernels.hip, k_grad_apply_p1)
+#pragma unroll
+         for (int a = 0; a < N; a++) {
+            const int g = conn[a + N * e];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const uint8_t m = mask[g + (int64_t)nnodes * c]; X[a + N * c] = m ? 0.0 : X[a + N * c]; }
+         }
       }
    } else {
 #pragma unroll
@@ -219,7 +227,11 @@ __global__ __launch_bounds__(PA_BLK) void k_ea_apply_rt(const int n, const int E
    double s = 0;
    for (int i = 0; i < ND; i++) {
       double xi;
-      if (LVEC) { const int64_t idx = conn[(i % n) + (int64_t)n * e] + (int64_t)nnodes * (i / n); xi = (mask != nullptr && mask[idx]) ? 0.0 : x[idx]; }
+      if (LVEC) {      // value and mask byte requested together, selected afterwards (no load waits for its mask byte)
+         const int64_t idx = conn[(i % n) + (int64_t)n * e] + (int64_t)nnodes * (i / n);
+         const double xv = x[idx]; const uint8_t m = mask != nullptr ? mask[idx] : (uint8_t)0;
+         xi = m ? 0.0 : xv;
+      }
       else xi = x[i + (int64_t)ND * e];
       s += col[(int64_t)i * PA_BLK] * xi;
    }

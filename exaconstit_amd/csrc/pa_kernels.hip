@@ -13,6 +13,8 @@
 // and contracts  y_e += G^T adj ( Ct : sym( (G x_e) adj ) )  per point.  The p=1 shape-derivative table is a
 // compile-time constant.  L-vector variants fuse the gather (connectivity table) and the scatter-add (FP64 atomics).
 #include "exa_internal.hpp"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -216,29 +218,40 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
    if (e >= E) return;
    if (gate != nullptr && gate[0] != 0.0) return;   // device-side "solver already converged" flag
    double X[3][8], Y[3][8];
+   double XC[GEO ? 3 : 1][8];
    int g[8];
    if (LVEC) {
 #pragma unroll
       for (int a = 0; a < 8; a++) g[a] = conn[a + 8 * e];
+      if (GEO) {   // (requested with the x values: one round trip for all 72 gathers)
+#pragma unroll
+         for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int a = 0; a < 8; a++) XC[c][a] = coords[g[a] + (int64_t)nnodes * c];
+      }
+      // every value and every mask byte is requested before the first one is looked at (written as `mask[idx] ? 0 : x[idx]` the compiler makes each
+      // x load conditional on its mask byte: 24 dependent round trips in front of the record stream of a wave - measured in round 5)
 #pragma unroll
       for (int c = 0; c < 3; c++)
 #pragma unroll
-         for (int a = 0; a < 8; a++) {
-            const int64_t idx = g[a] + (int64_t)nnodes * c;
-            X[c][a] = (mask != nullptr && mask[idx]) ? 0.0 : x[idx];
-         }
+         for (int a = 0; a < 8; a++) X[c][a] = x[g[a] + (int64_t)nnodes * c];
+      if (mask != nullptr) {
+         uint8_t mk[3][8];
+#pragma unroll
+         for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int a = 0; a < 8; a++) mk[c][a] = mask[g[a] + (int64_t)nnodes * c];
+         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+         for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int a = 0; a < 8; a++) X[c][a] = mk[c][a] ? 0.0 : X[c][a];
+      }
    } else {
 #pragma unroll
       for (int c = 0; c < 3; c++)
 #pragma unroll
          for (int a = 0; a < 8; a++) X[c][a] = x[a + 8 * (c + 3 * e)];
-   }
-   double XC[GEO ? 3 : 1][8];
-   if (GEO) {
-#pragma unroll
-      for (int c = 0; c < 3; c++)
-#pragma unroll
-         for (int a = 0; a < 8; a++) XC[c][a] = coords[g[a] + (int64_t)nnodes * c];
    }
 #pragma unroll
    for (int c = 0; c < 3; c++)
@@ -308,6 +321,8 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
 #pragma unroll
          for (int a = 0; a < 8; a++) y[a + 8 * (c + 3 * e)] += Y[c][a];
    }
+}
+
 }
 
 __global__ __launch_bounds__(PA_BLK) void k_grad_diag_p1(const int E, const double* __restrict__ pa, double* __restrict__ y) {
@@ -481,7 +496,17 @@ __global__ __launch_bounds__(PA_BLK) void k_ea_apply_p1(const int E, const doubl
 #pragma unroll
       for (int c = 0; c < 3; c++)
 #pragma unroll
-         for (int a = 0; a < 8; a++) { const int64_t idx = g[a] + (int64_t)nnodes * c; X[a + 8 * c] = (mask != nullptr && mask[idx]) ? 0.0 : x[idx]; }
+         for (int a = 0; a < 8; a++) X[a + 8 * c] = x[g[a] + (int64_t)nnodes * c];
+      if (mask != nullptr) {   // second pass: no x load waits for its mask byte (see k_grad_apply_p1)
+         uint8_t mk[24];
+#pragma unroll
+         for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int a = 0; a < 8; a++) mk[a + 8 * c] = mask[g[a] + (int64_t)nnodes * c];
+         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+         for (int i = 0; i < 24; i++) X[i] = mk[i] ? 0.0 : X[i];
+      }
    } else {
 #pragma unroll
       for (int i = 0; i < 24; i++) X[i] = x[i + 24 * e];
