@@ -323,8 +323,6 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
    }
 }
 
-}
-
 __global__ __launch_bounds__(PA_BLK) void k_grad_diag_p1(const int E, const double* __restrict__ pa, double* __restrict__ y) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
    if (e >= E) return;
