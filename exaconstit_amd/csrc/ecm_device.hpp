@@ -1380,11 +1380,28 @@ ECM_DI double norm8sq(const double v[8]) { double s = 0; for (int i = 0; i < 8; 
 // cmat then points at the lane's first 16-byte pair of the record ([13 pairs][64 lanes][2]); trd stores D^T (element-assembly contexts).
 // IO: where the point's data lives (model_kernels.hip, PointIO): sv0() / s0() begin-of-step state / stress, sv1() / s1() / cm() outputs, stash()
 // the lane's LDS stash, ipt() the point id, refresh() re-derives all of them from the thread index (see ECM_EPI_NO_LOADS)
+// The begin-of-step values a point reads of its old state and stress (21 of the 34: slip rates and evaluation count are not inputs, see
+// ECM_SHRATE_FROM_STATE).  The caller requests them BEFORE it gathers nodes and forms the velocity gradient, so that the state rows and the node
+// rows travel together: as loads inside point_update they were issued behind the gathers' wait - one more memory round trip at the start of every
+// wave (round 5: the prologue of the fused launch went from five dependent round trips to two).
+struct PointIn { double shrate, shr, flow, e[5], q[4], h, vol, eint, s[6]; };
+template <int QS>
+ECM_DI void load_point_in(const double* __restrict__ sv0, const double* __restrict__ s0, PointIn& p) {
+   p.shrate = ldg(&sv0[(H_SHRATE) * QS]); p.shr = ldg(&sv0[(H_SHR) * QS]); p.flow = ldg(&sv0[(H_FLOW) * QS]);
+#pragma unroll
+   for (int i = 0; i < 5; i++) p.e[i] = ldg(&sv0[(H_E + i) * QS]);
+#pragma unroll
+   for (int i = 0; i < 4; i++) p.q[i] = ldg(&sv0[(H_Q + i) * QS]);
+   p.h = ldg(&sv0[(H_H) * QS]); p.vol = ldg(&sv0[(IND_VOL) * QS]); p.eint = ldg(&sv0[(IND_EINT) * QS]);
+#pragma unroll
+   for (int i = 0; i < 6; i++) p.s[i] = ldg(&s0[i * QS]);
+}
+
 template <int KIN, int QS, bool REC = false, class IO>
-ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io, const int kcap,
+ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io, const int kcap, const PointIn& pin,
                         const double* pq_lds = nullptr, const double tsc = 0.0, const bool trd = false, const TailIO tio = TailIO()) {
    const bool resume = tio.rs_in != nullptr;
-   const double* __restrict__ sv0 = io.sv0(); const double* __restrict__ s0 = io.s0();
+   const double* __restrict__ sv0 = io.sv0();
    double* st = io.stash();
    Prob pb; pb.st = st; pb.gs = QS; pb.pqt = pq_lds;
    pb.dt_ri = 1.0 / dt;
@@ -1398,11 +1415,11 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
                   0.5 * (L[2 + 3 * 1] + L[1 + 3 * 2]), d_sm);
       double dnorm2 = 0; for (int i = 0; i < 5; i++) dnorm2 += d_sm[i] * d_sm[i];
       const double dnorm = sqrt(dnorm2), dEff = SQR2B3 * dnorm;
-      const double vOld = ldg(&sv0[(IND_VOL) * QS]), vNew = vOld * exp(dkk * dt), delv = vNew - vOld;
-      const double pOld = -(1.0 / 3.0) * (ldg(&s0[(0) * QS]) + ldg(&s0[(1) * QS]) + ldg(&s0[(2) * QS]));
-      double s_old[5]; sym_to_vecd(ldg(&s0[(0) * QS]) + pOld, ldg(&s0[(1) * QS]) + pOld, ldg(&s0[(2) * QS]) + pOld, ldg(&s0[(5) * QS]), ldg(&s0[(4) * QS]), ldg(&s0[(3) * QS]), s_old);
+      const double vOld = pin.vol, vNew = vOld * exp(dkk * dt), delv = vNew - vOld;
+      const double pOld = -(1.0 / 3.0) * (pin.s[0] + pin.s[1] + pin.s[2]);
+      double s_old[5]; sym_to_vecd(pin.s[0] + pOld, pin.s[1] + pOld, pin.s[2] + pOld, pin.s[5], pin.s[4], pin.s[3], s_old);
       // ---- EOS ("updateSimple", EosModelConst<false>): p = K (1/v - 1) + Gamma e
-      const double eNew = ldg(&sv0[(IND_EINT) * QS]) - delv * pOld;
+      const double eNew = pin.eint - delv * pOld;
       const double tK = mp.tK0 + eNew * mp.dtde;
       const double bulkNew = mp.bulk * vNew + mp.gamma * pOld * vNew;
       // ---- hardness to end of step with begin-of-step slip rates
@@ -1412,25 +1429,25 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
       // begin-of-step effective shear rate sum_a |gdot_a|: state slot 0 holds exactly this sum (written below from the same 12 values), so one
       // load can replace twelve (88 B of the 208 B a point reads of its old state)
       double shrate_o = 0;
-      if (ECM_SHRATE_FROM_STATE) shrate_o = ldg(&sv0[(H_SHRATE) * QS]);
+      if (ECM_SHRATE_FROM_STATE) shrate_o = pin.shrate;
       else for (int a = 0; a < NSLIP; a++) shrate_o += fabs(ldg(&sv0[(H_GDOT + a) * QS]));
-      const double h_u = kin_update_h<KIN>(mp, ldg(&sv0[(H_H) * QS]), dt, shrate_o);
+      const double h_u = kin_update_h<KIN>(mp, pin.h, dt, shrate_o);
       // ---- point problem set-up
       // (reciprocals of well-scaled positive numbers through frcp / rsqrt: 5 instructions instead of the ~13 of an IEEE division)
       const double detV_ri = frcp(vNew); ECM_ST(st, ST_PB + PB_DETVRI) = detV_ri;
       const double a_V = cbrt(vNew), a_V_ri = frcp(a_V);
       pb.esc = E_SCALE * a_V_ri; ECM_ST(st, ST_PB + PB_ESCI) = a_V * (1.0 / E_SCALE);
-      double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += ldg(&sv0[(H_Q + i) * QS]) * ldg(&sv0[(H_Q + i) * QS]); const double ni = rsqrt(n2); for (int i = 0; i < 4; i++) qn[i] = ldg(&sv0[(H_Q + i) * QS]) * ni; }
+      double qn[4]; { double n2 = 0; for (int i = 0; i < 4; i++) n2 += pin.q[i] * pin.q[i]; const double ni = rsqrt(n2); for (int i = 0; i < 4; i++) qn[i] = pin.q[i] * ni; }
       double Cn[9]; quat_to_mat(qn, Cn);
       double dn[5]; rot_vecd_T(Cn, d_sm, dn);
       double wrk_old = 0.0;
-      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = ldg(&sv0[(H_E + i) * QS]) * a_V_ri; wrk_old += s_old[i] * d_sm[i]; }
+      for (int i = 0; i < 5; i++) { ECM_ST(st, ST_DN + i) = dn[i]; ECM_ST(st, ST_EN + i) = pin.e[i] * a_V_ri; wrk_old += s_old[i] * d_sm[i]; }
       ECM_CD(CD_WRKOLD) = wrk_old;
       for (int i = 0; i < 3; i++) ECM_ST(st, ST_WN + i) = Cn[i] * w_sm[0] + Cn[3 + i] * w_sm[1] + Cn[6 + i] * w_sm[2];
       for (int i = 0; i < 4; i++) ECM_CD(CD_QN + i) = qn[i];
       ECM_CD(CD_VOLD) = vOld; ECM_CD(CD_VNEW) = vNew; ECM_CD(CD_ENEW) = eNew; ECM_CD(CD_DEFF) = dEff; ECM_CD(CD_BULK) = bulkNew; ECM_CD(CD_HU) = h_u;
       if (REC) ECM_CD(CD_TSC) = tsc;
-      if (ECM_EPI_NO_LOADS) { ECM_ST(st, ST_PB + PB_SHR0) = ldg(&sv0[(H_SHR) * QS]); ECM_ST(st, ST_PB + PB_FLOW0) = ldg(&sv0[(H_FLOW) * QS]); }
+      if (ECM_EPI_NO_LOADS) { ECM_ST(st, ST_PB + PB_SHR0) = pin.shr; ECM_ST(st, ST_PB + PB_FLOW0) = pin.flow; }
       double adots_ref;
       if (kin_is_km(KIN)) {
          const double sq = sqrt(h_u);
@@ -1451,7 +1468,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
       double* sv1 = io.sv1(); double* s1 = io.s1(); double* cmat = io.cm();
       double acc = 0.0;
       for (int i = 0; i < NSTATEV; i++) { const double v = ldg(&sv0[i * QS]); acc += v; stg(&sv1[i * QS], v + L[i % 9]); }
-      for (int i = 0; i < 6; i++) stg(&s1[i * QS], ldg(&s0[i * QS]) + acc);
+      for (int i = 0; i < 6; i++) stg(&s1[i * QS], pin.s[i] + acc);
       if (REC) { double2* rc = reinterpret_cast<double2*>(cmat); for (int pr = 0; pr < 13; pr++) rc[pr * 64] = make_double2(acc + pr, tsc); }
       else for (int i = 0; i < 36; i++) stg(&cmat[i * QS], acc + i);
       return 0;

@@ -94,7 +94,10 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
    extern __shared__ double sG[];
    const bool rows_by_wave = QB && !tail_mode;
    const int wpb = (int)(blockDim.x >> 6);
-   const bool g_lds = !P2F && exa_g_in_lds(n, rows_by_wave ? wpb : Q);   // orders above 2: the table stays in global memory (exa_internal.hpp)
+   // fused trilinear launch, element-blocked: q is wave-uniform, so the 24 shape derivatives of the wave's point come through scalar loads
+   // (no LDS staging, no barrier, no round trip in front of everything else); the dense tail launch (lane-varying q) stages the whole table
+   constexpr bool SROW = LVEC && NFIX == 8 && QB;
+   const bool g_lds = !P2F && !(SROW && rows_by_wave) && exa_g_in_lds(n, rows_by_wave ? wpb : Q);   // orders above 2: the table stays in global memory (exa_internal.hpp)
    const int tab = g_lds ? n * 3 * (rows_by_wave ? wpb : Q) : 0;
    // Kocks-Mecking: the slip table (12 rows of 8) behind the stash, for the rows that are read by lane-varying index (ecm_device.hpp, eval_rj)
    const int pqo = tab + ecmdev::ST_SLOTS * ECM_STASH_STRIDE;
@@ -114,6 +117,8 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
    const int q = io.q; const int64_t e = io.e;
    if (!tail_mode && e * Q >= P) return;
    constexpr int QS = QB ? 64 : 1;
+   // the point's begin-of-step state and stress are requested first: they depend on nothing but (e, q) and travel while the nodes are gathered
+   ecmdev::PointIn pin; ecmdev::load_point_in<QS>(io.sv0(), io.s0(), pin);
    const QView vJ = qview<QB>(9, Q, e, q);
    const double* Gq = g_lds ? sG + 3 * n * (rows_by_wave ? (int)(threadIdx.x >> 6) : q) : G + 3 * n * q;
    double J11, J21, J31, J12, J22, J32, J13, J23, J33;
@@ -144,6 +149,58 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
       for (int c = 0; c < 3; c++)
 #pragma unroll
          for (int t = 0; t < 3; t++) L[c + 3 * t] = gx[c][0] * Ji[0][t] + gx[c][1] * Ji[1][t] + gx[c][2] * Ji[2][t];
+   } else if constexpr (LVEC && NFIX == 8) {
+      // Trilinear fused launch: connectivity once, then the 24 coordinates AND the 24 velocities of the element in one round trip, then the
+      // arithmetic.  (Written as two node loops - Jacobian, velocity gradient - the compiler re-read the connectivity for the second one and
+      // issued the velocity gathers behind the Jacobian stores: five dependent memory round trips before the first state value was used.)
+      const int32_t* ce = conn + (int64_t)8 * e;
+      int gi[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) gi[r] = ce[r];
+      double xs[3][8], vs[3][8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+         xs[0][r] = xl[gi[r]]; xs[1][r] = xl[gi[r] + nnodes]; xs[2][r] = xl[gi[r] + 2 * (int64_t)nnodes];
+         vs[0][r] = vel[gi[r]]; vs[1][r] = vel[gi[r] + nnodes]; vs[2][r] = vel[gi[r] + 2 * (int64_t)nnodes];
+      }
+      double Jc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, Lx[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // Jc[i + 3 j] = dx_i/dxi_j, Lx[c + 3 s] = dv_c/dxi_s
+      double wq = 0.0;
+      auto contract = [&](auto&& Gv) {
+#pragma unroll
+         for (int r = 0; r < 8; r++) {
+            const double g0 = Gv(r), g1 = Gv(r + 8), g2 = Gv(r + 16);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+               Jc[c] += xs[c][r] * g0; Jc[c + 3] += xs[c][r] * g1; Jc[c + 6] += xs[c][r] * g2;
+               Lx[c] += vs[c][r] * g0; Lx[c + 3] += vs[c][r] * g1; Lx[c + 6] += vs[c][r] * g2;
+            }
+         }
+      };
+      if (SROW && rows_by_wave) {
+         const int qu = __builtin_amdgcn_readfirstlane(q);
+         const p2::cptr Gc = p2::as_const(G) + 24 * qu;
+         if (REC) wq = p2::as_const(Wq)[qu];
+         contract([&](int i) { return Gc[i]; });
+      } else {
+         if (REC) wq = Wq[q];
+         contract([&](int i) { return Gq[i]; });
+      }
+      J11 = Jc[0]; J21 = Jc[1]; J31 = Jc[2]; J12 = Jc[3]; J22 = Jc[4]; J32 = Jc[5]; J13 = Jc[6]; J23 = Jc[7]; J33 = Jc[8];
+      if (Jio) {   // optional (uniform): the driver's p = 1 record route needs no Jacobian field - its integrator kernels take the geometry from the nodes
+         double* Jo = Jio + vJ.base;
+         ecmdev::stg(Jo, J11); ecmdev::stg(Jo + QS, J21); ecmdev::stg(Jo + 2 * QS, J31); ecmdev::stg(Jo + 3 * QS, J12); ecmdev::stg(Jo + 4 * QS, J22); ecmdev::stg(Jo + 5 * QS, J32);
+         ecmdev::stg(Jo + 6 * QS, J13); ecmdev::stg(Jo + 7 * QS, J23); ecmdev::stg(Jo + 8 * QS, J33);
+      }
+      const double detJ = J11 * (J22 * J33 - J32 * J23) - J21 * (J12 * J33 - J32 * J13) + J31 * (J12 * J23 - J22 * J13);
+      const double di = 1.0 / detJ;
+      if (REC) tsc = dt * wq * di;
+      const double Ji[3][3] = { { di * (J22 * J33 - J23 * J32), di * (J32 * J13 - J12 * J33), di * (J12 * J23 - J22 * J13) },
+                                { di * (J31 * J23 - J21 * J33), di * (J11 * J33 - J13 * J31), di * (J21 * J13 - J11 * J23) },
+                                { di * (J21 * J32 - J31 * J22), di * (J31 * J12 - J11 * J32), di * (J11 * J22 - J12 * J21) } };
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+         for (int tt = 0; tt < 3; tt++) L[c + 3 * tt] = Lx[c] * Ji[0][tt] + Lx[c + 3] * Ji[1][tt] + Lx[c + 6] * Ji[2][tt];
    } else {
    if (LVEC) {
       // J(i,j) = sum_r x_r,i dN_r/dxi_j   (column-major 3x3 per point, like MFEM's geometric factors after the re-layout)
@@ -196,7 +253,7 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
       for (int tt = 0; tt < 3; tt++) L[c + 3 * tt] = Lx[c] * Ji[0][tt] + Lx[c + 3] * Ji[1][tt] + Lx[c + 6] * Ji[2][tt];
    }
    // per-thread stash behind the shape table in LDS: slot s of this thread at stash[s * ECM_STASH_STRIDE + threadIdx.x] (PointIO::stash)
-   const int rc = point_update<KIN, QS, REC>(mp, dt, L, io, kcap, sG + pqo, tsc, trd != 0,
+   const int rc = point_update<KIN, QS, REC>(mp, dt, L, io, kcap, pin, sG + pqo, tsc, trd != 0,
                                              TailIO{ tail_out, rs_out, tail_mode ? rs_in : nullptr, P, !tail_mode && rs_out != nullptr });
    if (rc == 1) atomicAdd(fail, 1);
 }
@@ -296,9 +353,10 @@ int exa_launch_nfev_hist(exa_ctx* ctx, const double* state, int* hist_dev, hipSt
 // in global memory): with the stash and the slip table it must fit the 64 KB a launch gets without an attribute change.
 static_assert(64 * 3 * 64 > EXA_G_LDS_MAX_DOUBLES, "order-3 shape tables must not be staged in LDS by the constitutive launch");
 static_assert(sizeof(double) * ((size_t)27 * 3 * 27 + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE + 8 * ecmdev::NSLIP) <= 65536, "dynamic LDS of k_model_setup exceeds 64 KB");
-static size_t model_lds_bytes(const exa_ctx* ctx, bool km, bool p2f, bool qb, int tail_mode) {
+static size_t model_lds_bytes(const exa_ctx* ctx, bool km, bool p2f, bool qb, int tail_mode, bool lvec8) {
    const int nrow = (qb && !tail_mode) ? EXA_MODEL_BS / 64 : ctx->Q;
-   const size_t rows = (p2f || !exa_g_in_lds(ctx->n, nrow)) ? 0 : (size_t)ctx->n * 3 * nrow;
+   const bool srow = lvec8 && qb && !tail_mode;      // k_model_setup, SROW: the wave's shape row comes through scalar loads
+   const size_t rows = (p2f || srow || !exa_g_in_lds(ctx->n, nrow)) ? 0 : (size_t)ctx->n * 3 * nrow;
    return sizeof(double) * (rows + (size_t)ecmdev::ST_SLOTS * ECM_STASH_STRIDE + (km ? (size_t)8 * ecmdev::NSLIP : (size_t)0));
 }
 
@@ -322,7 +380,7 @@ static void launch_model_q(exa_ctx* ctx, double dt, double* J, const double* vel
    const int64_t nb = QB ? (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64) : (ctx->P + bs - 1) / bs;
    const double* G = NFIX == 27 ? ctx->T1_dev : ctx->G_dev;
    launch_levels(ctx, nb, [&](int64_t blocks, int kcap, int* list, int mode, int* list_out, const double* rs_in, double* rs_out) {
-      hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)blocks), dim3(bs), model_lds_bytes(ctx, ecmdev::kin_is_km(KIN), NFIX == 27, QB, mode), s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
+      hipLaunchKernelGGL((k_model_setup<KIN, LVEC, NFIX, QB>), dim3((unsigned)blocks), dim3(bs), model_lds_bytes(ctx, ecmdev::kin_is_km(KIN), NFIX == 27, QB, mode, LVEC && NFIX == 8), s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, G, vel, xl, ctx->conn,
                          ctx->nnodes, stress0, state0, stress1, state1, cmat, ctx->fail_count_dev, kcap, list, mode, (const double*)nullptr, 0, list_out, rs_in, rs_out);
    });
 }
@@ -335,7 +393,7 @@ static void launch_model_rec(exa_ctx* ctx, double dt, double* J, const double* v
    const int64_t nb = (((int64_t)((ctx->E + 63) / 64) * ctx->Q) + (bs / 64) - 1) / (bs / 64);
    const int trd = ctx->cfg.assembly == EXA_ASSEMBLY_EA;
    launch_levels(ctx, nb, [&](int64_t blocks, int kcap, int* list, int mode, int* list_out, const double* rs_in, double* rs_out) {
-      hipLaunchKernelGGL((k_model_setup<KIN, true, 8, true, true>), dim3((unsigned)blocks), dim3(bs), model_lds_bytes(ctx, ecmdev::kin_is_km(KIN), false, true, mode), s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
+      hipLaunchKernelGGL((k_model_setup<KIN, true, 8, true, true>), dim3((unsigned)blocks), dim3(bs), model_lds_bytes(ctx, ecmdev::kin_is_km(KIN), false, true, mode, true), s, ctx->mp, ctx->Q, ctx->n, ctx->P, dt, J, ctx->G_dev, vel, xl, ctx->conn,
                          ctx->nnodes, stress0, state0, stress1, state1, ctx->pa_c, ctx->fail_count_dev, kcap, list, mode, ctx->W_dev, trd, list_out, rs_in, rs_out);
    });
 }
