@@ -42,6 +42,8 @@ MODEL_NAMES = {"fcc_voce": "FCC Voce power-law", "bcc_voce": "BCC Voce power-law
                "fcc_kmdd": "FCC Kocks-Mecking dislocation density", "bcc_kmdd": "BCC Kocks-Mecking dislocation density"}
 SETTLE_PASSES = 60                # untimed constitutive passes before the timed region (>= --warmup): reported as `warmup`, see main()
 SOLVE_STEPS_DEFAULT = 14          # real Newton/PCG steps of the reference schedule before the timed passes (plastic regime: steps >= 10)
+SOLVE_STEPS_TOTAL_DEFAULT = 25    # ... and the solve goes on to this step after the timed regions: per-step in-solve kernel rates up to the plateau of the
+                                  # dt = 0.1 segment (steps 3..21 of test/data/custom_dt.txt) and into the dt = 0.2 segment (22..27)
 PREP_DTS = [0.005, 0.195, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1]   # first 10 steps of the reference schedule: 0.1 % strain, plastic
 
 
@@ -199,6 +201,8 @@ def main():
     ap.add_argument("--jacobi", action="store_true", help="true Jacobi preconditioner (refreshed every Newton iteration) instead of the reference's effective identity (SURVEY fact 9)")
     ap.add_argument("--solve-steps", type=int, default=int(os.environ.get("EXA_BENCH_SOLVE_STEPS", str(SOLVE_STEPS_DEFAULT))),
                     help="real Newton/PCG time steps of the reference schedule that bring the RVE to the benchmark state (0: kinematically driven state only)")
+    ap.add_argument("--solve-steps-total", type=int, default=int(os.environ.get("EXA_BENCH_SOLVE_STEPS_TOTAL", str(SOLVE_STEPS_TOTAL_DEFAULT))),
+                    help="after the timed regions the solve continues (committing --solve-steps) up to this step of the schedule, for the in-solve rates")
     args = ap.parse_args()
 
     import torch
@@ -295,25 +299,31 @@ def main():
         drv.close()
         rng = np.random.default_rng(20240928)
         quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
-        sched = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "custom_dt.txt")).ravel()[:args.solve_steps]
+        sched = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "custom_dt.txt")).ravel()[:max(args.solve_steps, args.solve_steps_total)]
         drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=asm, rank=rank, nranks=world, uid=uid, jacobi=args.jacobi, **mk)
         del quats
         barrier(); t0 = time.perf_counter()
         rows = []; hist_pl = np.zeros(64, dtype=np.int64); ms_pl = 0.0; calls_pl = 0; kms_tot = 0.0; kit_tot = 0; model_ms_tot = 0.0; calls_tot = 0
-        for ti in range(1, args.solve_steps + 1):
+
+        def solve_step(ti, commit):
+            """one step of the schedule; returns the row of in-solve figures (kernel time = HIP events around every constitutive launch of the step,
+            the reference's ecmech_kernel region, src/mechanics_ecmech.cpp:237-257; max over ranks)"""
             drv.reset_timers()
-            last = ti == args.solve_steps     # the last step is solved but not committed: the timed passes repeat its converged launch
-            assert drv.step(ti, commit=not last), f"Newton failed at step {ti}"
+            assert drv.step(ti, commit=commit), f"Newton failed at step {ti}"
             tm = drv.timers(); nw, kr, mc = drv.stats()
             mms = max_over_ranks(tm["model_ms"]); calls = int(mc[-1])
-            rows.append({"step": ti, "dt": float(sched[ti - 1]), "newton_iters": int(nw[-1]), "krylov_iters": int(kr[-1]), "model_calls": calls,
-                         "kernel_ms_per_call": mms / max(calls, 1), "qpt_updates_per_s_in_kernel": P_global * calls / (mms * 1e-3)})
-            kms_tot += max_over_ranks(tm["krylov_ms"]); kit_tot += tm["krylov_iters"]; model_ms_tot += mms; calls_tot += calls
+            return {"step": ti, "dt": float(sched[ti - 1]), "newton_iters": int(nw[-1]), "krylov_iters": int(kr[-1]), "model_calls": calls,
+                    "kernel_ms_per_call": mms / max(calls, 1), "qpt_updates_per_s_in_kernel": P_global * calls / (mms * 1e-3),
+                    "_model_ms": mms, "_krylov_ms": max_over_ranks(tm["krylov_ms"]), "_krylov_iters": tm["krylov_iters"]}
+        for ti in range(1, args.solve_steps + 1):
+            last = ti == args.solve_steps     # the last step is solved but not committed: the timed passes repeat its converged launch
+            row = solve_step(ti, commit=not last); rows.append(row)
+            kms_tot += row["_krylov_ms"]; kit_tot += row["_krylov_iters"]; model_ms_tot += row["_model_ms"]; calls_tot += row["model_calls"]
             if ti >= 10:     # steady plastic regime (SURVEY 8(d): "steps >= 5 of the schedule"; the transition has passed by step 10)
-                ms_pl += mms; calls_pl += calls; hist_pl += drv.nfev_hist(which=1 if last else 0)
+                ms_pl += row["_model_ms"]; calls_pl += row["model_calls"]; hist_pl += drv.nfev_hist(which=1 if last else 0)
         barrier(); wall = max_over_ranks(time.perf_counter() - t0)
         dg = drv.diagnostics()
-        solve = {"steps": args.solve_steps, "wall_s": wall, "per_step": rows,
+        solve = {"steps": args.solve_steps, "wall_s": wall, "per_step": [{k: v for k, v in r.items() if not k.startswith("_")} for r in rows],
                  "qpt_updates_per_s_in_kernel": P_global * calls_tot / (model_ms_tot * 1e-3),
                  "pcg_iters_per_s": kit_tot / (kms_tot * 1e-3),
                  "steady_plastic": ({"steps": f"10..{args.solve_steps}", "qpt_updates_per_s_in_kernel": P_global * calls_pl / (ms_pl * 1e-3),
@@ -349,6 +359,41 @@ def main():
     pcg_ms = max_over_ranks(pc["pcg_ms"]); apply_ms = max_over_ranks(pc["apply_ms"]) / args.pcg_iters
     pcg_it_s = pc["iters"] / (pcg_ms * 1e-3)
     comm_ranks, comm_transport = drv.comm_info()
+    comm_details = drv.comm_details()
+    per_rank = None
+    if world > 1:      # every rank's share: elements, neighbours, bytes per halo exchange, overlap setting
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, dict(rank=rank, **comm_details))
+    # ---- the solve goes on: in-solve kernel rates up to the plateau (qpt updates/s = sum of P over ModelSetup calls / kernel time) ----------
+    in_solve = None
+    if solve is not None and args.solve_steps_total > args.solve_steps:
+        total = len(sched)
+        barrier(); t0 = time.perf_counter()
+        drv.commit_step()                         # end-of-step update of the step whose converged launch was timed
+        for ti in range(args.solve_steps + 1, total + 1):
+            rows.append(solve_step(ti, commit=True))
+        barrier(); wall2 = max_over_ranks(time.perf_counter() - t0)
+
+        def seg(lo, hi):
+            rr = [r for r in rows if lo <= r["step"] <= hi]
+            if not rr:
+                return None
+            ms = sum(r["_model_ms"] for r in rr); calls = sum(r["model_calls"] for r in rr)
+            return {"steps": f"{lo}..{min(hi, rows[-1]['step'])}", "model_calls": calls, "kernel_ms_per_call": ms / calls,
+                    "qpt_updates_per_s_in_kernel": P_global * calls / (ms * 1e-3), "frac": MODEL_BYTES_PER_QPT * P_local / (ms / calls * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        seg01_end = 21      # last step of the dt = 0.1 segment of test/data/custom_dt.txt
+        in_solve = {"whole_solve": seg(1, total), "steps_ge_5": seg(5, total), "steps_ge_10": seg(10, total),
+                    "plateau": seg(max(10, min(seg01_end, total) - 2), min(seg01_end, total)),
+                    "dt_0p2_segment": seg(seg01_end + 1, total) if total > seg01_end else None,
+                    "solved_to_step": total, "wall_s_of_the_continuation": wall2,
+                    "per_step": [{k: v for k, v in r.items() if not k.startswith("_")} for r in rows[args.solve_steps:]],
+                    "definition": "SURVEY 8(d): (sum over ModelSetup calls of P) / (time inside the fused constitutive launch), every launch of every Newton iterate of "
+                                  "the steps named, HIP events around each launch; frac = 928 B x qpts / kernel time / 8 TB/s.  plateau = the last three steps of "
+                                  "the schedule's dt = 0.1 segment (the evaluation counts left by the elastic-plastic transition have decayed); the dt = 0.2 segment "
+                                  "that follows starts a new, shorter transition",
+                    "claim_40pct_rests_on": "plateau (in-solve) and the timed passes of `value` (the converged launch of step "
+                                            f"{args.solve_steps}); steps_ge_5 / whole_solve include the transition launches, whose evaluation counts (mean up to 10, "
+                                            "wave maximum 15) set their time - see profiles/r05_transition_study.txt"}
     if rank == 0:
         ndof_local = L.exa_driver_local_dofs(drv.h)
         # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench): bytes/qpt x local qpts.  The counter
@@ -407,7 +452,8 @@ def main():
                        "state": (f"real Newton/PCG solve of the reference schedule, {args.solve_steps} steps; timed passes = the converged (last) residual evaluation of step {args.solve_steps}"
                                  if args.solve_steps > 0 else "kinematically driven (10 prescribed-velocity passes)"),
                        "qpts": P_global, "decomposition": f"{world} block(s)"},
-            "comm": {"transport": comm_transport, "ranks_reported_by_transport": comm_ranks,
+            "library": {"path": L.LIB_PATH, "build_id": L.exa_build_id().decode(), "kernel_build_id": L.exa_kernel_build_id().decode()},
+            "comm": {"transport": comm_transport, "ranks_reported_by_transport": comm_ranks, "rank0": comm_details, "per_rank": per_rank,
                      "note": "rccl: ncclCommCount of the library's communicator; ipc: shared-device inter-process transport (more ranks than devices)"},
             "pcg_iters_per_s": pcg_it_s, "pcg_iters": pc["iters"], "pcg_ms_per_iter": pcg_ms / max(pc["iters"], 1),
             "pcg_wall_s": t_pcg_wall, "nonconverged_points": m["failed"],
@@ -449,6 +495,8 @@ def main():
         }
         if solve is not None:
             out["newton_pcg_solve"] = solve
+        if in_solve is not None:
+            out["roofline"]["in_solve"] = in_solve
         if world == 1 and not args.no_cpu_baseline:
             try:
                 voce = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "props_cp_voce.txt")).ravel()

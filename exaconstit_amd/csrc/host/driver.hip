@@ -84,7 +84,11 @@ struct LoopbackGroup {
    std::vector<std::vector<double>> red;                 // per-rank contribution of the current reduction
    std::vector<std::vector<const double*>> sendbuf;      // [rank][neighbour slot] device send buffers of the current halo exchange
    std::vector<std::vector<int>> nbr_rank;               // [rank][slot] neighbour rank
-   explicit LoopbackGroup(int n_) : n(n_), red(n_), sendbuf(n_), nbr_rank(n_) {}
+   // stream-asynchronous exchange (Comm::exchange): "my send buffer is packed" / "I have read my neighbours' send buffers", recorded by every rank
+   // on its own stream and waited for by its peers' streams - the host threads only meet to know that the events have been recorded
+   std::vector<hipEvent_t> ev_packed, ev_read; std::vector<char> ev_read_valid;
+   explicit LoopbackGroup(int n_) : n(n_), red(n_), sendbuf(n_), nbr_rank(n_), ev_packed(n_, nullptr), ev_read(n_, nullptr), ev_read_valid(n_, 0) {}
+   ~LoopbackGroup() { for (hipEvent_t e : ev_packed) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : ev_read) if (e) (void)hipEventDestroy(e); }
    void barrier() {
       std::unique_lock<std::mutex> lk(m);
       const uint64_t g = gen;
@@ -202,7 +206,7 @@ void Comm::init(int rank_, int nranks_, const void* uid, bool force_rccl) {
    if (uid && std::memcmp(uid, kLoopMagic, 8) == 0) {
       LoopbackGroup* g; std::memcpy(&g, (const char*)uid + 8, sizeof(g));
       if (g->n != nranks) throw std::runtime_error("Comm::init: loopback group size mismatch");
-      loop_ = g;
+      loop_ = g; loop_async_ = std::getenv("EXA_LOOPBACK_SYNC") == nullptr;
    } else if (uid && std::memcmp(uid, kIpcMagic, 8) == 0 && nranks > 1) {
       ipc_ = ipc_attach(uid, rank, nranks);
    } else if (nranks > 1 || force_) {
@@ -359,17 +363,34 @@ void Comm::exchange(const Partition& part, hipStream_t s) {
       LoopbackGroup* g = (LoopbackGroup*)loop_;
       g->sendbuf[rank].resize(nb); g->nbr_rank[rank].resize(nb);
       for (size_t i = 0; i < nb; i++) { g->sendbuf[rank][i] = sb(i); g->nbr_rank[rank][i] = part.nbrs[i].rank; }
+      auto peer_src = [&](size_t i) {   // my slot i talks to rank r; r's slot that talks to me holds what I receive (same dof order on both sides)
+         const int r = part.nbrs[i].rank;
+         for (size_t k = 0; k < g->nbr_rank[r].size(); k++) if (g->nbr_rank[r][k] == rank) return g->sendbuf[r][k];   // one neighbour entry per pair of ranks
+         throw std::runtime_error("loopback halo: asymmetric neighbour lists");
+      };
+      if (loop_async_) {
+         // Stream-asynchronous form (default; EXA_LOOPBACK_SYNC=1 keeps the host-synchronous one): NO stream is drained.  Every rank records
+         // "packed" on its stream, its peers' streams wait for that event before they copy, every rank records "read" behind its copies and a
+         // rank's NEXT pack waits for its neighbours' "read" (issued by the pack's caller through wait_peers_read).  The host threads meet twice
+         // per exchange only so that an event is recorded before somebody waits for it - the device work of all ranks stays in flight, which is
+         // how the overlapped halo (halo_begin / halo_end: cs_, ev_ready_, ev_done_) runs over RCCL.
+         if (!g->ev_packed[rank]) { EXA_HC(hipEventCreateWithFlags(&g->ev_packed[rank], hipEventDisableTiming)); EXA_HC(hipEventCreateWithFlags(&g->ev_read[rank], hipEventDisableTiming)); }
+         EXA_HC(hipEventRecord(g->ev_packed[rank], s));
+         g->barrier();                                            // every rank's "packed" is recorded (host side only)
+         for (size_t i = 0; i < nb; i++) {
+            EXA_HC(hipStreamWaitEvent(s, g->ev_packed[part.nbrs[i].rank], 0));
+            EXA_HC(hipMemcpyAsync(rb(i), peer_src(i), sizeof(double) * cnt(i), hipMemcpyDeviceToDevice, s));
+         }
+         EXA_HC(hipEventRecord(g->ev_read[rank], s)); g->ev_read_valid[rank] = 1;
+         g->barrier();                                            // every rank's "read" is recorded
+         // nobody repacks its send buffer before its readers are done: the stream that packs next is the stream of this exchange or a later one of
+         // this rank - ordered behind these waits either way (halo_sum packs on s, halo_begin on cs_, and cs_ waits for ev_ready_ recorded on s)
+         for (size_t i = 0; i < nb; i++) EXA_HC(hipStreamWaitEvent(s, g->ev_read[part.nbrs[i].rank], 0));
+         return;
+      }
       EXA_HC(hipStreamSynchronize(s));
       g->barrier();
-      for (size_t i = 0; i < nb; i++) {   // my slot i talks to rank r; r's slot that talks to me holds what I receive (same dof order on both sides)
-         const int r = part.nbrs[i].rank; const double* src = nullptr;
-         for (size_t k = 0; k < g->nbr_rank[r].size(); k++) if (g->nbr_rank[r][k] == rank) {
-            // a pair of ranks is connected by exactly one neighbour entry on each side
-            src = g->sendbuf[r][k]; break;
-         }
-         if (!src) throw std::runtime_error("loopback halo: asymmetric neighbour lists");
-         EXA_HC(hipMemcpyAsync(rb(i), src, sizeof(double) * cnt(i), hipMemcpyDeviceToDevice, s));
-      }
+      for (size_t i = 0; i < nb; i++) EXA_HC(hipMemcpyAsync(rb(i), peer_src(i), sizeof(double) * cnt(i), hipMemcpyDeviceToDevice, s));
       EXA_HC(hipStreamSynchronize(s));
       g->barrier();
       return;
@@ -498,6 +519,9 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
       const char* ho = std::getenv("EXA_HALO_OVERLAP");
       const bool want = ho ? std::string(ho) != "off" && std::string(ho) != "0" : std::string(comm.transport()) != "rccl";
       overlap_ = fast_p1_ && lvec_grad_ && !det && part.E_bdr > 0 && !part.nbrs.empty() && (opt.assembly == Assembly::PA || ea_rec) && want;
+      // decided collectively: every rank runs the same form (a partition in which one rank has no boundary block would otherwise put its
+      // exchange on another stream than its peers')
+      if (comm.nranks > 1) overlap_ = comm.max_over_ranks(overlap_ ? 0.0 : 1.0) == 0.0;
       nblk_bdr_ = (part.E_bdr + 63) / 64;
    }
 }
@@ -716,7 +740,8 @@ void NonlinearMechOperator::GradMult(const double* x, double* y, bool constraine
       const uint8_t* m = constrained ? ess_mask.p : nullptr;
       const int nball = (E_ + 63) / 64;
       const int rc0 = exa_grad_apply_lvec_blocks(ctx_, x, y, m, done_flag, 0, nblk_bdr_, stream_);
-      if (rc0 == EXA_ERR_UNSUPPORTED) overlap_ = false;   // the context cannot run block ranges (nothing has been added to y): whole action + halo_sum from now on
+      // (the context cannot run block ranges - a property of the configuration, the same on every rank; nothing has been added to y: whole action + halo_sum from now on)
+      if (rc0 == EXA_ERR_UNSUPPORTED) overlap_ = false;
       else {
          abi_check(ctx_, rc0, "exa_grad_apply_lvec_blocks");
          comm_.halo_begin(part_, y, stream_);
@@ -1180,10 +1205,15 @@ bool SystemDriver::Step(int ti, bool commit) {
    step_wall_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count());
    if (!ok) return false;
    if (!commit) return true;   // the converged state stays the END-of-step state: the next constitutive pass repeats this step's last residual evaluation
-   UpdateModel();
-   op.SwapCoords();
-   steps_done++;
+   CommitStep();
    return true;
+}
+// end-of-step update of a solved step (also called later for a step solved with commit = false, as long as only residual evaluations at the
+// converged velocity - bench passes - have run in between: they rewrite the same end-of-step state)
+void SystemDriver::CommitStep() {
+   UpdateModel();
+   oper_->SwapCoords();
+   steps_done++;
 }
 
 int SystemDriver::RunAll() {

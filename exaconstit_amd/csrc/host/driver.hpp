@@ -48,11 +48,13 @@ class Comm {
    // us per call of the fused 16-byte all-reduce and of a grouped send/recv of `n` doubles to the own rank (one-rank communicator: latency floor of the RCCL calls)
    void microbench(int iters, int n, double* us_allreduce, double* us_sendrecv);
    bool deterministic = false;               // halo contributions added segment by segment (fixed order) instead of one atomic pass
+   size_t halo_dofs() const { return seg_off_.back(); }   // doubles this rank sends (= receives) per exchange, all neighbours
    bool forced() const { return force_; }   // EXA_FORCE_RCCL=1: the one-rank communicator runs the multi-rank code paths and every RCCL call
  private:
    void unpack(double* y, hipStream_t s);
    void loopback_reduce(double* dev, int n, int op, hipStream_t s);
    void* comm_ = nullptr; void* loop_ = nullptr; void* ipc_ = nullptr; bool force_ = false;
+   bool loop_async_ = false;   // loopback: exchanges ordered by events only, no stream is drained (driver.hip, Comm::exchange)
    DevBuf<int32_t> idx_all_; DevBuf<double> sbuf_all_, rbuf_all_; std::vector<size_t> seg_off_{ 0 };   // concatenated neighbour segments
    DevBuf<double> tmp_;
    hipStream_t cs_ = nullptr; hipEvent_t ev_ready_ = nullptr, ev_done_ = nullptr;   // communication stream of halo_begin / halo_end
@@ -121,6 +123,7 @@ class NonlinearMechOperator {
    hipStream_t stream() const { return stream_; }
    const Partition& part() const { return part_; }
    Comm& comm() { return comm_; }
+   bool halo_overlap() const { return overlap_; }      // the gradient action overlaps the halo exchange with its interior blocks
    // data (device)
    DevBuf<double> x_ref, x_beg, x_cur, el_x, el_v, el_jac, diag, dinv, weight;
    DevBuf<double> stress0, stress1, matVars0, matVars1, matGrad;
@@ -171,6 +174,7 @@ class SystemDriver {
    // one time step of the reference's loop (src/mechanics_driver.cpp:837-907); returns false if Newton failed
    // commit = false (bench): solve the step but leave begin-of-step state, coordinates and outputs untouched
    bool Step(int ti, bool commit = true);
+   void CommitStep();                      // end-of-step update of a step solved with commit = false
    int RunAll();
    bool NewtonSolve(double* x, SolverStats& st);
    int CGSolve(const double* b, double* x);   // device PCG, returns iterations

@@ -122,6 +122,18 @@ int exa_driver_comm_info(exa_driver* d, int* out2) {
    } catch (const std::exception& e) { std::fprintf(stderr, "exa_driver_comm_info: %s\n", e.what()); return -1; }
 }
 
+// out8 = { local elements, elements in blocks that touch shared nodes, neighbours, doubles sent (= received) per halo exchange, halo exchange
+//          overlapped with the interior blocks (0 / 1), transport kind (exa_driver_comm_info), ranks the transport reports, 0 }
+int exa_driver_comm_details(exa_driver* d, int64_t* out8) {
+   try {
+      const SystemDriver& sd = *d->sd; int info[2] = { 1, 0 };
+      (void)exa_driver_comm_info(d, info);
+      out8[0] = sd.part.E; out8[1] = sd.part.E_bdr; out8[2] = (int64_t)sd.part.nbrs.size(); out8[3] = (int64_t)sd.comm.halo_dofs();
+      out8[4] = d->sd->oper().halo_overlap() ? 1 : 0; out8[5] = info[1]; out8[6] = info[0]; out8[7] = 0;
+      return 0;
+   } catch (const std::exception& e) { std::fprintf(stderr, "exa_driver_comm_details: %s\n", e.what()); return -1; }
+}
+
 int exa_loopback_group_create(int nranks, void* out128) { try { Comm::loopback_create(nranks, out128); return 0; } catch (...) { return -1; } }
 void exa_loopback_group_destroy(const void* id128) { Comm::loopback_destroy(id128); }
 
@@ -182,6 +194,11 @@ int exa_driver_step(exa_driver* d, int ti, char* err, int errlen) {
 // the step's Newton/PCG solve without the end-of-step update (bench: the timed constitutive passes that follow repeat the step's converged launch)
 int exa_driver_step_nocommit(exa_driver* d, int ti, char* err, int errlen) {
    try { return d->sd->Step(ti, false) ? 1 : 0; } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
+// ... and its end-of-step update afterwards (bench: the solve goes on from the step whose converged launch was timed)
+int exa_driver_commit_step(exa_driver* d, char* err, int errlen) {
+   try { d->sd->CommitStep(); return 0; } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }
 
 int exa_driver_run(exa_driver* d, char* err, int errlen) {

@@ -152,6 +152,7 @@ exa_device_identity = _sig("exa_device_identity", C.c_int, C.c_char_p, C.c_int)
 exa_driver_comm_info = _sig("exa_driver_comm_info", C.c_int, C.c_void_p, C.POINTER(C.c_int))
 exa_loopback_group_create = _sig("exa_loopback_group_create", C.c_int, C.c_int, C.c_void_p)
 exa_loopback_group_destroy = _sig("exa_loopback_group_destroy", None, C.c_void_p)
+exa_driver_comm_details = _sig("exa_driver_comm_details", C.c_int, C.c_void_p, C.POINTER(C.c_int64))
 exa_driver_create = _sig("exa_driver_create", C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int)
 exa_driver_create_synthetic = _sig("exa_driver_create_synthetic", C.c_void_p, C.POINTER(ExaSynthConfig), C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int)
 exa_driver_destroy = _sig("exa_driver_destroy", None, C.c_void_p)
@@ -160,6 +161,7 @@ exa_driver_local_qpts = _sig("exa_driver_local_qpts", C.c_int64, C.c_void_p)
 exa_driver_local_dofs = _sig("exa_driver_local_dofs", C.c_int64, C.c_void_p)
 exa_driver_step = _sig("exa_driver_step", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_int)
 exa_driver_step_nocommit = _sig("exa_driver_step_nocommit", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_int)
+exa_driver_commit_step = _sig("exa_driver_commit_step", C.c_int, C.c_void_p, C.c_char_p, C.c_int)
 exa_driver_run = _sig("exa_driver_run", C.c_int, C.c_void_p, C.c_char_p, C.c_int)
 exa_driver_get_avgs = _sig("exa_driver_get_avgs", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int)
 exa_driver_get_stats = _sig("exa_driver_get_stats", C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
@@ -231,6 +233,9 @@ class Driver:
             raise RuntimeError(self._err.value.decode())
         return rc == 1
 
+    def commit_step(self):
+        self._chk(exa_driver_commit_step(self.h, self._err, 512))
+
     def run(self):
         rc = exa_driver_run(self.h, self._err, 512)
         if rc == -1000000:
@@ -284,6 +289,12 @@ class Driver:
         o = (C.c_int * 2)()
         assert exa_driver_comm_info(self.h, o) == 0
         return int(o[0]), ("none", "rccl", "ipc", "loopback")[o[1]]
+
+    def comm_details(self):
+        out = (C.c_int64 * 8)()
+        assert exa_driver_comm_details(self.h, out) == 0
+        return {"elements": int(out[0]), "boundary_block_elements": int(out[1]), "neighbours": int(out[2]), "halo_bytes_per_exchange": 8 * int(out[3]),
+                "halo_overlap": bool(out[4])}
 
     def reset_timers(self):
         exa_driver_reset_timers(self.h)

@@ -39,6 +39,10 @@ int exa_comm_unique_id(void* out128, int nranks);
 int exa_device_identity(char* out, int len);
 /* out2 = { rank count the transport itself reports (ncclCommCount for RCCL), kind: 0 none, 1 rccl, 2 ipc, 3 in-process loopback } */
 int exa_driver_comm_info(exa_driver* d, int* out2);
+/* out8 = { local elements, elements in 64-blocks that touch shared nodes, neighbour ranks, doubles sent (= received) per halo exchange,
+ *          halo exchange overlapped with the interior blocks (0 / 1; over RCCL opt-in with EXA_HALO_OVERLAP=on), transport kind, ranks the
+ *          transport reports, 0 } - what bench.py prints per rank of a multi-rank run */
+int exa_driver_comm_details(exa_driver* d, int64_t* out8);
 /* latency floor of the RCCL calls of one PCG iteration on this device (one-rank communicator): out2 = { us per 16-byte all-reduce,
  * us per grouped send/recv of n doubles to the own rank } */
 int exa_rccl_microbench(int iters, int n, double* out2, char* err, int errlen);
@@ -74,6 +78,9 @@ int64_t exa_driver_local_dofs(exa_driver* d);
 int exa_driver_step(exa_driver* d, int ti, char* err, int errlen);
 /* solve step ti but do not commit it (no begin/end swap, no coordinate update, no output row): the state bench.py times its passes on */
 int exa_driver_step_nocommit(exa_driver* d, int ti, char* err, int errlen);
+/* end-of-step update of a step solved by exa_driver_step_nocommit, valid while only residual evaluations at the converged velocity
+ * (exa_driver_bench_model / exa_driver_bench_pcg) have run since */
+int exa_driver_commit_step(exa_driver* d, char* err, int errlen);
 int exa_driver_run(exa_driver* d, char* err, int errlen);
 int exa_driver_get_avgs(exa_driver* d, int which, double* out, int maxrows);
 int exa_driver_get_stats(exa_driver* d, int* newton, int* krylov, int* model_calls, int maxrows);

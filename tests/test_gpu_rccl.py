@@ -61,19 +61,25 @@ def test_two_ranks_two_processes(oracle, tmp_path):
     assert one["newton"] == two["newton"]
 
 
-def test_bench_two_ranks_under_torchrun(tmp_path):
-    """The driver's scaling launch line, `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`, with N = 2: torch's process
-    group and the library's own communicator side by side, max-over-ranks timing, one JSON line from rank 0 that names the transport and the
-    rank count the transport itself reports (ncclCommCount over RCCL; the shared-device transport on a one-GPU box)."""
+@pytest.mark.parametrize("nproc", [2, 8])
+def test_bench_ranks_under_torchrun(tmp_path, nproc):
+    """The driver's scaling launch line, `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`, with N = 2 and N = 8 (the first
+    SCALE run of the driver is N = 8: a 2 x 2 x 2 decomposition, 7 neighbours per rank): torch's process group and the library's own communicator
+    side by side, max-over-ranks timing, one JSON line from rank 0 that names the transport, the rank count the transport itself reports
+    (ncclCommCount over RCCL; the shared-device transport on a one-GPU box) and every rank's share of the partition."""
     import torch
     root = os.path.dirname(HERE)
-    env = dict(os.environ, EXA_BENCH_N="32", EXA_BENCH_SOLVE_STEPS="3"); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the driver's line carries no size flags)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29573",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
-    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, EXA_BENCH_N="32", EXA_BENCH_SOLVE_STEPS="3", EXA_BENCH_SOLVE_STEPS_TOTAL="4"); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the driver's line carries no size flags)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(29573 + nproc),
+           os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["comm"]["ranks_reported_by_transport"] == 2
-    assert d["comm"]["transport"] == ("rccl" if torch.cuda.device_count() >= 2 else "ipc")
+    assert d["n_gpus"] == nproc and d["comm"]["ranks_reported_by_transport"] == nproc
+    assert d["comm"]["transport"] == ("rccl" if torch.cuda.device_count() >= nproc else "ipc")
     assert d["nonconverged_points"] == 0 and d["value"] > 0 and d["newton_pcg_solve"]["steps"] == 3
+    pr = d["comm"]["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(nproc)) and sum(p["elements"] for p in pr) == 32 ** 3
+    assert all(p["neighbours"] == (1 if nproc == 2 else 7) and p["halo_bytes_per_exchange"] > 0 for p in pr)
+    assert d["roofline"]["in_solve"]["solved_to_step"] == 4 and os.path.basename(d["library"]["path"]).startswith("libexaconstit_hip")
