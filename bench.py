@@ -464,6 +464,10 @@ def main():
                          "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS,
                          "traffic": traffic["k_model_setup"] * P_local if "k_model_setup" in traffic else None, "traffic_source": traffic.get("_file"), "kernel_build_id": kid,
                          "bytes_per_qpt": MODEL_BYTES_PER_QPT, "avg_kernel_ms": kern_ms,
+                         # the same launch priced at what it moves by construction on the record route (648 B/qpt): the figure to compare with PMC traffic
+                         "frac_on_bytes_moved": (648.0 * P_local / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (records and args.model in ("fcc_voce", "bcc_voce", "fcc_voce_nl")) else None,
+                         "state_key": "value / roofline: converged launch of the last --solve-steps step of a real Newton/PCG solve (since round 4); `kinematic_state` "
+                                      "(prescribed-velocity passes, the benchmark state of rounds 1-3) is reported under its own key every round: compare rounds on like keys",
                          "bytes_written_per_qpt_note": ("this launch writes the 26-number gradient record instead of the 36 tangent entries (AssembleGradPA fused in)") if records else None,
                          "fp64_flop_per_qpt": flops, "fp64_tflops": (flops * P_local / (kern_ms * 1e-3) / 1e12) if flops else None,
                          "fp64_vector_frac": (flops * P_local / (kern_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TFLOPS) if flops else None,
