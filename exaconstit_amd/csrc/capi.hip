@@ -173,6 +173,13 @@ int exa_model_status(exa_ctx* ctx, exa_stream s) {
    return h;
 }
 
+// the return convention SURVEY 8(b) specifies for the model seam in one call: < 0 error, 0 ok, > 0 quadrature points whose local solve failed
+int exa_model_setup_checked(exa_ctx* ctx, double dt, const double* J, const double* vel, const double* stress0, const double* state0,
+                            double* stress1, double* state1, double* ddsdde, exa_stream s) {
+   const int rc = exa_model_setup(ctx, dt, J, vel, stress0, state0, stress1, state1, ddsdde, s);
+   return rc != EXA_OK ? rc : exa_model_status(ctx, s);
+}
+
 int exa_set_newton_cap(exa_ctx* ctx, int max_evals) {
    if (!ctx || (max_evals != 0 && max_evals < 2)) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_cap: 0 (off) or >= 2");
    if (max_evals && ctx->P >= (int64_t)INT32_MAX) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_cap: the deferred-point list holds 32-bit point ids (P < 2^31)");

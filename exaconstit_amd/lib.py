@@ -57,9 +57,11 @@ exa_set_quadrature_layout = _sig("exa_set_quadrature_layout", C.c_int, C.c_void_
 exa_get_quadrature_layout = _sig("exa_get_quadrature_layout", C.c_int, C.c_void_p)
 exa_qf_size = _sig("exa_qf_size", C.c_int64, C.c_void_p, C.c_int)
 EXA_QLAYOUT_AOS, EXA_QLAYOUT_EB64 = 0, 1
+EXA_OK, EXA_ERR_ARG, EXA_ERR_HIP, EXA_ERR_STATE, EXA_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 exa_init_state = _sig("exa_init_state", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)
 exa_state_normalize = _sig("exa_state_normalize", C.c_int, C.c_void_p, dptr, C.c_void_p)
 exa_model_setup = _sig("exa_model_setup", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
+exa_model_setup_checked = _sig("exa_model_setup_checked", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_setup_lvec_records = _sig("exa_model_setup_lvec_records", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_model_setup_lvec = _sig("exa_model_setup_lvec", C.c_int, C.c_void_p, C.c_double, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_void_p)
 exa_set_newton_cap = _sig("exa_set_newton_cap", C.c_int, C.c_void_p, C.c_int)

@@ -132,6 +132,12 @@ int exa_state_normalize(exa_ctx* ctx, double* state_dev, exa_stream s);
 int exa_model_setup(exa_ctx* ctx, double dt, const double* jacobian_dev /*(3,3,Q,E)*/, const double* vel_evec_dev /*(n,3,E)*/,
                     const double* stress0_dev, const double* state0_dev,
                     double* stress1_dev, double* state1_dev, double* ddsdde_dev, exa_stream s);
+/* exa_model_setup + exa_model_status in one call, with the return value the model seam is specified with: < 0 error, 0 every local
+ * solve converged, > 0 the number of quadrature points whose ExaCMech solve failed (the reference aborts the run on one: ECMECH_FAIL behind
+ * getResponseECM, src/mechanics_ecmech.cpp:176-186).  Synchronises the stream (one 4-byte read-back); the MFEM adapter's ModelSetup uses it. */
+int exa_model_setup_checked(exa_ctx* ctx, double dt, const double* jacobian_dev, const double* vel_evec_dev,
+                            const double* stress0_dev, const double* state0_dev,
+                            double* stress1_dev, double* state1_dev, double* ddsdde_dev, exa_stream s);
 /* Same update driven from L-vectors (needs exa_set_connectivity): gathers nodal coordinates / velocities itself and also
  * WRITES the Jacobians (3,3,Q,E) the integrator calls need, i.e. NonlinearMechOperator::Setup's two L->E restrictions and
  * SetupJacobianTerms (src/mechanics_operator.cpp:310-391) fused into the constitutive launch. */

@@ -69,14 +69,13 @@ class HipExaModel : public ExaModel {
                    const mfem::Vector& /*loc_grad*/, const mfem::Vector& vel) override {
       EXA_ADAPTER_VERIFY(nqpts == exa_qpts_per_elem(ctx_) && nnodes == exa_nodes_per_elem(ctx_), "element order does not match the context");
       (void)nelems;
-      const int rc = exa_model_setup(ctx_, dt, jacobian.Read(), vel.Read(), stress0->Read(), matVars0->Read(), stress1->Write(), matVars1->Write(),
-                                     matGrad->Write(), nullptr);
-      EXA_ADAPTER_VERIFY(rc == EXA_OK, exa_last_error(ctx_));
-      // ExaCMech fails the run when a local solve does not converge (ECMECH_FAIL); the count needs one 4-byte read-back
-      if (check_local_solves_) {
-         const int nfail = exa_model_status(ctx_, nullptr);
-         EXA_ADAPTER_VERIFY(nfail == 0, "the constitutive update did not converge at " + std::to_string(nfail) + " quadrature point(s)");
-      }
+      // ExaCMech fails the run when a local solve does not converge (ECMECH_FAIL): exa_model_setup_checked returns that count (> 0) at the price
+      // of one 4-byte read-back; check_local_solves = false keeps the launch asynchronous (exa_model_status can be asked later)
+      const int rc = check_local_solves_
+         ? exa_model_setup_checked(ctx_, dt, jacobian.Read(), vel.Read(), stress0->Read(), matVars0->Read(), stress1->Write(), matVars1->Write(), matGrad->Write(), nullptr)
+         : exa_model_setup(ctx_, dt, jacobian.Read(), vel.Read(), stress0->Read(), matVars0->Read(), stress1->Write(), matVars1->Write(), matGrad->Write(), nullptr);
+      EXA_ADAPTER_VERIFY(rc >= EXA_OK, exa_last_error(ctx_));
+      EXA_ADAPTER_VERIFY(rc == 0, "the constitutive update did not converge at " + std::to_string(rc) + " quadrature point(s)");
    }
    void UpdateModelVars() override {}
    void calcDpMat(mfem::QuadratureFunction& DpMat) const override {            // src/mechanics_model.hpp:233, src/mechanics_ecmech.hpp:302-363

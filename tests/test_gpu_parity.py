@@ -208,6 +208,30 @@ def test_foreign_state_is_normalised(oracle, name, xtal, kin, pkey, model):
         ctx.close()
 
 
+def test_model_setup_checked_returns_the_failed_point_count(oracle):
+    """exa_model_setup_checked: the return convention SURVEY 8(b) gives the model seam - 0 when every local solve converged, the number of failed
+    quadrature points (> 0) otherwise, < 0 on an argument error - in one call (the reference aborts on ECMECH_FAIL, src/mechanics_ecmech.cpp:176-186)."""
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 4, distort=0.1)
+    E, Q, P = rve["E"], rve["Q"], rve["E"] * rve["Q"]
+    props = _props(orc, "mts")
+    ctx = L.Context(L.EXA_FCC_KMDD, props, 298.0, 1, E)
+    d_quats = dev.up(hipref.random_quats(E).ravel()); d_sv0 = dev.zeros(28 * P)
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_sv0), ptr(d_quats), None))
+    xe = hipref.l_to_e(rve, rve["X"]); d_xe = dev.up(xe); d_J = dev.zeros(9 * P)
+    ctx.check(L.exa_jacobians(ctx.h, ptr(d_xe), ptr(d_J), None))
+    d_s0 = dev.zeros(6 * P); o = [dev.zeros(6 * P), dev.zeros(28 * P), dev.zeros(36 * P)]
+    v = hipref.l_to_e(rve, hipref.velocity_field(rve))
+    args = lambda d_v, dt: (ctx.h, dt, ptr(d_J), ptr(d_v), ptr(d_s0), ptr(d_sv0), ptr(o[0]), ptr(o[1]), ptr(o[2]), None)
+    assert L.exa_model_setup_checked(*args(dev.up(v), 0.1)) == 0
+    nfail = L.exa_model_setup_checked(*args(dev.up(4.0e4 * v), 1.0))          # 4000 % strain in one step: local solves run into the evaluation limit
+    assert 0 < nfail <= P and nfail == L.exa_model_status(ctx.h, None)
+    assert L.exa_model_setup_checked(ctx.h, -1.0, ptr(d_J), ptr(dev.up(v)), ptr(d_s0), ptr(d_sv0), ptr(o[0]), ptr(o[1]), ptr(o[2]), None) == L.EXA_ERR_ARG
+    ctx.close()
+
+
 def _spd_tangent(P, seed=3):
     rng = np.random.default_rng(seed)
     A = rng.standard_normal((P, 6, 6))
