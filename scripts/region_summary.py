@@ -65,14 +65,29 @@ def main():
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["region", "kernel", "dispatches", "mean_us", "min_us", "max_us", "total_ms", "VGPR", "AGPR", "SGPR", "scratch_B_per_lane", "LDS_B_per_block",
-                    "workgroup", "grid"])
+                    "workgroup", "grid", "dynamic_LDS_B_per_block"])
         for (reg, k), v in sorted(rows.items(), key=lambda kv: (kv[0][0], -sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in kv[1]))):
             du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in v]
             r0 = v[-1]
             w.writerow([reg, k, len(v), "%.2f" % (sum(du) / len(du)), "%.2f" % min(du), "%.2f" % max(du), "%.3f" % (sum(du) * 1e-3), r0.get("VGPR_Count", ""),
                         r0.get("Accum_VGPR_Count", ""), r0.get("SGPR_Count", ""), r0.get("Scratch_Size", ""), r0.get("LDS_Block_Size", ""), r0.get("Workgroup_Size_X", ""),
-                        r0.get("Grid_Size_X", "")])
+                        r0.get("Grid_Size_X", ""), dynamic_lds(k, r0)])
     print("wrote", out, "(%d regions x kernels, marker trace: %s)" % (len(rows), "yes" if regions else "no"))
+
+
+def dynamic_lds(kernel, row):
+    """rocprofv3's LDS_Block_Size is the STATIC group segment; the constitutive launch asks for its LDS dynamically (model_kernels.hip, model_lds_bytes):
+    per-lane stash of ST_SLOTS = 38 doubles x block size (+ 8 x 12 doubles of slip table for the Kocks-Mecking kinds 2, 3, 6, 7; + the shape table in the
+    dense tail launch / reference layout, not counted here).  Other kernels: unknown to this script (empty)."""
+    import re
+    m = re.match(r"k_model_setup<(\d+),", kernel)
+    if not m:
+        return ""
+    try:
+        bs = int(row.get("Workgroup_Size_X", 128))
+    except ValueError:
+        bs = 128
+    return 38 * bs * 8 + (8 * 12 * 8 if int(m.group(1)) in (2, 3, 6, 7) else 0)
 
 
 if __name__ == "__main__":
