@@ -204,7 +204,8 @@ struct Partition {
       bdr_nodes.assign(maxattr, std::vector<uint8_t>(NN, 0));
       for (auto& q : bdr) for (int a = 0; a < 4; a++) bdr_nodes[q[0] - 1][q[1 + a]] = 1;
       if (order == 2) elevate_to_p2(bdr);
-      else if (order != 1) throw std::runtime_error("mesh: file meshes run at p_refinement = 1 or 2");
+      else if (order >= 3 && order <= 6) elevate_to_order(order, bdr);
+      else if (order != 1) throw std::runtime_error("mesh: file meshes run at p_refinement = 1 ... 6");
       weight.assign(NN, 1.0); nbrs.clear();
       if (nranks > 1) localize(rcb_owner(nranks));
    }
@@ -243,6 +244,84 @@ struct Partition {
          auto it = face_node.find(key); if (it != face_node.end()) bdr_nodes[q[0] - 1][it->second] = 1;
       }
       conn.swap(c2); X.swap(X2); NN = NN2; p = 2; n = 27;
+   }
+
+   // p_refinement = 3 ... 6 on a file mesh: (p - 1) nodes per edge, (p - 1)^2 per face and (p - 1)^3 per element of the trilinear mesh, at the images
+   // of the Gauss-Lobatto points under the element's trilinear map (src/mechanics_driver.cpp:300-306 raises the order of the nodal space the same
+   // way; straight-sided hexahedra).  Two elements that share an edge or a face traverse it in their own local directions, so a shared node is
+   // identified by a key that does not depend on the element: an edge node by (smaller vertex id, larger vertex id, index counted from the smaller
+   // one), a face node by the four sorted vertex ids and its (u, w) index in the frame whose origin is the face's smallest vertex id and whose
+   // first axis points to the smaller of that corner's two neighbours on the face.  The Gauss-Lobatto points are symmetric, so both elements
+   // compute the same position.  Local numbering = native_order(p).
+   void elevate_to_order(const int order, const std::vector<std::array<int, 5>>& bdr) {
+      const int pp = order, np = pp + 1, n2 = np * np * np, nv = NN;
+      const std::vector<int> nat = native_order(pp);
+      std::vector<double> gll; exa_gll_nodes_01(np, gll);
+      static const int V[8][3] = { { 0, 0, 0 }, { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 0, 0, 1 }, { 1, 0, 1 }, { 1, 1, 1 }, { 0, 1, 1 } };
+      int corner_of[2][2][2];      // lexicographic corner (a, b, c) -> native vertex index
+      for (int v = 0; v < 8; v++) corner_of[V[v][0]][V[v][1]][V[v][2]] = v;
+      std::map<std::array<int64_t, 7>, int> shared_node;      // (kind, ids..., indices) -> global node
+      std::vector<std::array<double, 3>> xnew;
+      std::vector<int32_t> c2((size_t)n2 * E);
+      auto edge_key = [&](int a, int b, int t) { return a < b ? std::array<int64_t, 7>{ 1, a, b, t, 0, 0, 0 } : std::array<int64_t, 7>{ 1, b, a, pp - t, 0, 0, 0 }; };
+      // face with corner ids c[al][be] (al along the first free axis s, be along the second t), node at (s, t)
+      auto face_key = [&](const int c[2][2], int s_, int t_) {
+         int a0 = 0, b0 = 0;
+         for (int al = 0; al < 2; al++) for (int be = 0; be < 2; be++) if (c[al][be] < c[a0][b0]) { a0 = al; b0 = be; }
+         const int sp = a0 ? pp - s_ : s_, tp = b0 ? pp - t_ : t_;
+         const bool s_first = c[1 - a0][b0] < c[a0][1 - b0];
+         std::array<int64_t, 4> ids{ c[0][0], c[0][1], c[1][0], c[1][1] }; std::sort(ids.begin(), ids.end());
+         return std::array<int64_t, 7>{ 2, ids[0], ids[1], ids[2], ids[3], s_first ? sp : tp, s_first ? tp : sp };
+      };
+      for (int e = 0; e < E; e++) {
+         const int32_t* v = &conn[(size_t)8 * e];
+         auto position = [&](int i, int j, int k) {
+            std::array<double, 3> x{ 0, 0, 0 };
+            const double w[3][2] = { { 1.0 - gll[i], gll[i] }, { 1.0 - gll[j], gll[j] }, { 1.0 - gll[k], gll[k] } };
+            for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int c = 0; c < 2; c++) {
+               const int g = v[corner_of[a][b][c]]; const double ww = w[0][a] * w[1][b] * w[2][c];
+               for (int d = 0; d < 3; d++) x[d] += ww * X[g + (size_t)nv * d];
+            }
+            return x;
+         };
+         for (int k = 0; k < np; k++) for (int j = 0; j < np; j++) for (int i = 0; i < np; i++) {
+            const int idx[3] = { i, j, k };
+            int fixed[3], nfix = 0, freeax[3], nfree = 0;
+            for (int d = 0; d < 3; d++) { if (idx[d] == 0 || idx[d] == pp) fixed[nfix++] = d; else freeax[nfree++] = d; }
+            int g;
+            if (nfix == 3) g = v[corner_of[i / pp][j / pp][k / pp]];
+            else if (nfix == 0) { xnew.push_back(position(i, j, k)); g = nv + (int)xnew.size() - 1; }
+            else {
+               std::array<int64_t, 7> key;
+               if (nfix == 2) {      // edge along freeax[0]
+                  int ca[3] = { i / pp, j / pp, k / pp }, cb[3] = { i / pp, j / pp, k / pp };
+                  ca[freeax[0]] = 0; cb[freeax[0]] = 1;
+                  key = edge_key(v[corner_of[ca[0]][ca[1]][ca[2]]], v[corner_of[cb[0]][cb[1]][cb[2]]], idx[freeax[0]]);
+               } else {              // face: fixed[0] constant, free axes freeax[0] (s) and freeax[1] (t)
+                  int c[2][2];
+                  for (int al = 0; al < 2; al++) for (int be = 0; be < 2; be++) {
+                     int cc[3]; cc[fixed[0]] = idx[fixed[0]] / pp; cc[freeax[0]] = al; cc[freeax[1]] = be;
+                     c[al][be] = v[corner_of[cc[0]][cc[1]][cc[2]]];
+                  }
+                  key = face_key(c, idx[freeax[0]], idx[freeax[1]]);
+               }
+               auto it = shared_node.find(key);
+               if (it != shared_node.end()) g = it->second;
+               else { xnew.push_back(position(i, j, k)); g = nv + (int)xnew.size() - 1; shared_node.emplace(key, g); }
+            }
+            c2[nat[i + np * (j + np * k)] + (size_t)n2 * e] = g;
+         }
+      }
+      const int NN2 = nv + (int)xnew.size();
+      std::vector<double> X2((size_t)3 * NN2);
+      for (int g = 0; g < NN2; g++) for (int d = 0; d < 3; d++) X2[g + (size_t)NN2 * d] = g < nv ? X[g + (size_t)nv * d] : xnew[g - nv][d];
+      for (auto& b : bdr_nodes) b.resize(NN2, 0);
+      for (auto& q : bdr) {      // a boundary quadrilateral constrains the nodes on its edges and in its interior too
+         for (int a = 0; a < 4; a++) for (int t = 1; t < pp; t++) { auto it = shared_node.find(edge_key(q[1 + a], q[1 + (a + 1) % 4], t)); if (it != shared_node.end()) bdr_nodes[q[0] - 1][it->second] = 1; }
+         const int c[2][2] = { { q[1], q[4] }, { q[2], q[3] } };      // corners in cyclic order q1 q2 q3 q4: s from q1 to q2, t from q1 to q4
+         for (int s_ = 1; s_ < pp; s_++) for (int t_ = 1; t_ < pp; t_++) { auto it = shared_node.find(face_key(c, s_, t_)); if (it != shared_node.end()) bdr_nodes[q[0] - 1][it->second] = 1; }
+      }
+      conn.swap(c2); X.swap(X2); NN = NN2; p = pp; n = n2;
    }
 
    // element -> rank by recursive coordinate bisection: split the longest extent of the centroid cloud at the element count that

@@ -207,7 +207,7 @@ struct ExaOptions {
       if (mesh_type == "other" || mesh_type == "cubit") {   // file mesh (reference src/mechanics_driver.cpp:239-241); MFEM mesh v1.0 hexahedra only
          if (mesh_file.empty()) throw std::runtime_error("Mesh.floc is required for Mesh.type = \"other\"");
          if (ref_ser != 0) throw std::runtime_error("Mesh.ref_ser > 0 is only built for auto-generated meshes");
-         if (order != 1 && order != 2) throw std::runtime_error("File meshes run at p_refinement = 1 or 2");
+         if (order < 1 || order > 6) throw std::runtime_error("File meshes run at p_refinement = 1 ... 6");
       } else if (mesh_type == "auto") {
          const TomlValue* nc = d.get("Mesh.Auto.ncuts"); const TomlValue* ln = d.get("Mesh.Auto.length");
          if (!nc || !ln || nc->arr.size() != 3 || ln->arr.size() != 3) throw std::runtime_error("Must input mesh geometry/discretization for hex_mesh_gen");

@@ -106,7 +106,7 @@ def test_partitioned_order3_matches_single_rank(oracle, tmp_path):
             assert list(st[0]) == list(ref[1][0])
 
 
-@pytest.mark.parametrize("mesh,nranks,p", [("cube5_shuffled.mesh", 2, 1), ("cube5_shuffled.mesh", 3, 1), ("cube5_nodes.mesh", 5, 1), ("cube5_shuffled.mesh", 3, 2)])
+@pytest.mark.parametrize("mesh,nranks,p", [("cube5_shuffled.mesh", 2, 1), ("cube5_shuffled.mesh", 3, 1), ("cube5_nodes.mesh", 5, 1), ("cube5_shuffled.mesh", 3, 2), ("cube5_shuffled.mesh", 2, 3)])
 def test_file_mesh_partitioned_matches_single_rank(oracle, tmp_path, mesh, nranks, p):
     """Mesh.type = "other" on several ranks: recursive-coordinate-bisection partition of the file's elements (unstructured neighbour
     lists, nodes shared by up to 8 ranks) gives the one-rank run."""

@@ -407,6 +407,46 @@ def test_file_mesh_at_order_two_equals_the_generated_mesh():
                 assert np.array_equal(p["X"][:, dofs[:m] % p["NN"]], parts[r2]["X"][:, other[:m] % parts[r2]["NN"]])
 
 
+@pytest.mark.parametrize("order", [3, 4])
+def test_file_mesh_at_higher_order_equals_the_generated_mesh(order):
+    """p_refinement = 3, 4 on an MFEM mesh file (host/mesh.hpp, elevate_to_order): (p-1) nodes per edge, (p-1)^2 per face, (p-1)^3 per element at the
+    Gauss-Lobatto points, shared nodes identified independently of the elements' local directions - checked on the file whose elements AND local
+    vertex orders are shuffled: every element carries the node coordinates of the generated mesh's element of the same global index, the node
+    count is the conforming one ((5p+1)^3: no duplicated edge / face node), and a partition keeps the invariants of the p = 1 partition."""
+    p = order
+    for name in ("cube5_nodes.mesh", "cube5_shuffled.mesh"):
+        path = os.path.join(REF, name).encode()
+        f1 = _mesh_query(path, 0, 1, 1); fp = _mesh_query(path, 0, 1, p)
+        assert fp["n"] == (p + 1) ** 3 and fp["E"] == 125 and fp["NN"] == (5 * p + 1) ** 3
+        g = _generated(5, p)
+        scale = f1["X"].max()
+        # element correspondence by centroid (the shuffled file permutes elements and rotates their local vertex order)
+        cen_g = {tuple(np.round(scale * g["X"][:, g["conn"][e]].mean(axis=1), 9)): e for e in range(125)}
+        for e in range(125):
+            xe = fp["X"][:, fp["conn"][e]]
+            eg = cen_g[tuple(np.round(xe.mean(axis=1), 9))]
+            xg = scale * g["X"][:, g["conn"][eg]]
+            if name == "cube5_nodes.mesh":      # same local orientation: node by node
+                assert np.allclose(xe, xg, atol=1e-13 * scale)
+            a = {tuple(r) for r in np.round(xe.T, 9)}; b = {tuple(r) for r in np.round(xg.T, 9)}
+            assert a == b                          # the same (p+1)^3 points in either orientation
+        assert np.array_equal(fp["conn"][:, :8], f1["conn"])
+    path = os.path.join(REF, "cube5_shuffled.mesh").encode()
+    for nranks in (2, 3):
+        parts = [_mesh_query(path, r, nranks, p) for r in range(nranks)]
+        assert sorted(np.concatenate([q["gid"] for q in parts]).tolist()) == list(range(125))
+        wsum = {}
+        for q in parts:
+            for i in range(q["NN"]):
+                k = tuple(np.round(q["X"][:, i], 9)); wsum[k] = wsum.get(k, 0.0) + q["w"][i]
+        assert len(wsum) == (5 * p + 1) ** 3 and all(abs(v - 1.0) < 1e-12 for v in wsum.values())
+        for r, q in enumerate(parts):
+            for r2, dofs in q["nb"].items():
+                other = parts[r2]["nb"][r]; m = len(dofs) // 3
+                assert len(dofs) == len(other)
+                assert np.array_equal(q["X"][:, dofs[:m] % q["NN"]], parts[r2]["X"][:, other[:m] % parts[r2]["NN"]])
+
+
 def test_generated_mesh_nodes_sit_at_gauss_lobatto_points():
     """Orders above 2: the nodes of a generated mesh are the Gauss-Lobatto-Legendre points of each element (MFEM's H1 basis), not equispaced."""
     g = _generated(2, 4)
