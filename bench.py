@@ -262,7 +262,7 @@ def main():
                              krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=uid, jacobi=args.jacobi, **mk)
     del quats
     P_global = 8 * N ** 3
-    settle = max(args.warmup, SETTLE_PASSES)
+    settle = max(args.warmup, int(os.environ.get("EXA_BENCH_SETTLE", str(SETTLE_PASSES))))      # EXA_BENCH_SETTLE: A/B aid (does a short --warmup read slow?)
 
     def hist_dict(h):
         return {"mean": float((h * np.arange(64)).sum() / max(h.sum(), 1)), "max": int(np.nonzero(h)[0].max()) if h.any() else 0,
