@@ -214,7 +214,7 @@ def main():
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)          # (a launcher that shows every rank one device numbers it 0)
     torch.cuda.set_device(local)
-    uid = None; shared = False
+    shared = False
     if world > 1:
         # torch's group only carries the barrier, the max-over-ranks of the wall time and the 128-byte id: host-side data, so it runs on gloo
         # and cannot interfere with the library's own RCCL communicator (which carries every collective of the solve).  The ranks compare
@@ -230,12 +230,18 @@ def main():
         dist.all_gather_object(ids, ident)
         shared = len(set(ids)) < world or bool(os.environ.get("EXA_BENCH_SAME_DEVICE"))
         os.environ["EXA_TRANSPORT"] = "ipc" if shared else "rccl"
+
+    def fresh_uid():
+        """A NEW 128-byte id from rank 0 for every communicator: a RCCL unique id serves exactly one ncclCommInitRank per rank (its bootstrap root
+        answers one clique and goes away), and this run creates two drivers one after the other."""
+        if world == 1:
+            return None
         buf = (C.c_ubyte * 128)()
         if rank == 0:
             assert L.exa_comm_unique_id(buf, world) == 0
         t = torch.tensor(list(buf), dtype=torch.uint8)
         dist.broadcast(t, 0)
-        uid = (C.c_ubyte * 128)(*t.tolist())
+        return (C.c_ubyte * 128)(*t.tolist())
 
     def barrier():
         torch.cuda.synchronize()
@@ -259,7 +265,7 @@ def main():
     quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
     asm = 0 if args.assembly.upper() == "PA" else 1
     drv = L.Driver.synthetic(N, props, quats.ravel(), np.array(PREP_DTS), assembly=asm,
-                             krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=uid, jacobi=args.jacobi, **mk)
+                             krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=fresh_uid(), jacobi=args.jacobi, **mk)
     del quats
     P_global = 8 * N ** 3
     settle = max(args.warmup, int(os.environ.get("EXA_BENCH_SETTLE", str(SETTLE_PASSES))))      # EXA_BENCH_SETTLE: A/B aid (does a short --warmup read slow?)
@@ -300,7 +306,7 @@ def main():
         rng = np.random.default_rng(20240928)
         quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
         sched = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "custom_dt.txt")).ravel()[:max(args.solve_steps, args.solve_steps_total)]
-        drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=asm, rank=rank, nranks=world, uid=uid, jacobi=args.jacobi, **mk)
+        drv = L.Driver.synthetic(N, props, quats.ravel(), sched, assembly=asm, rank=rank, nranks=world, uid=fresh_uid(), jacobi=args.jacobi, **mk)
         del quats
         barrier(); t0 = time.perf_counter()
         rows = []; hist_pl = np.zeros(64, dtype=np.int64); ms_pl = 0.0; calls_pl = 0; kms_tot = 0.0; kit_tot = 0; model_ms_tot = 0.0; calls_tot = 0

@@ -6,11 +6,15 @@
 // every collective afterwards is RCCL over xGMI.  Rank 0 prints and writes the avg_* files, every rank writes time/time_solve.<rank>.txt.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include "../../../include/exaconstit_driver.h"
 
 int main(int argc, char** argv) {
+   // Hosts whose kernel driver offers dmabuf IPC only (this pool's): without this setting RCCL and hipIpcGetMemHandle fail between processes.  Set before
+   // the HIP runtime comes up (first HIP call: exa_bootstrap), never overriding what the user exported.
+   ::setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
    std::string opt = "options.toml";
    for (int i = 1; i < argc; i++) if ((!std::strcmp(argv[i], "-opt") || !std::strcmp(argv[i], "--option")) && i + 1 < argc) opt = argv[++i];
    char err[512] = { 0 };
