@@ -60,19 +60,22 @@ def test_executable_under_mpirun_one_rank(tmp_path):
     _check_against_golden(tmp_path, "mtsdd_bcc")
 
 
-def test_executable_two_ranks(tmp_path):
-    """The reference's regression command line, `mpirun -np 2 mechanics -opt voce_pa.toml` (test/test_mechanics.py:38).  Two GPUs: RCCL; one
-    GPU: both ranks map to device 0 and exa_bootstrap hands out the id of the shared-device inter-process transport instead of a RCCL id."""
+@pytest.mark.parametrize("np_", [2, 8])
+def test_executable_ranks(tmp_path, np_):
+    """The reference's regression command line, `mpirun -np N mechanics -opt voce_pa.toml` (test/test_mechanics.py:38), N = 2 and N = 8 (the 10^3
+    mesh on 2 x 2 x 2 blocks).  One GPU per rank: RCCL; a one-GPU box: the ranks hand the identity of their device to rank 0 in the rendez-vous,
+    which finds them on one device and answers with the id of the shared-device inter-process transport instead of a RCCL id (stderr says so)."""
     mpirun = _mpirun()
     toml = _stage(tmp_path, "voce_pa")
-    env = dict(os.environ, EXA_MASTER_PORT="29533")
+    env = dict(os.environ, EXA_MASTER_PORT=str(29533 + np_))
     if mpirun:
-        cmd = [mpirun, "-np", "2", EXE, "-opt", toml]
-        r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+        cmd = [mpirun, "-np", str(np_), EXE, "-opt", toml]
+        r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, (r.stdout, r.stderr)
+        assert "exa_bootstrap: %d ranks, transport" % np_ in r.stderr and ("ranks %d" % np_) in r.stdout
     else:
-        ps = [subprocess.Popen([EXE, "-opt", toml], cwd=str(tmp_path), env=dict(env, EXA_RANK=str(k), EXA_NRANKS="2")) for k in range(2)]
-        assert all(p.wait(timeout=900) == 0 for p in ps)
+        ps = [subprocess.Popen([EXE, "-opt", toml], cwd=str(tmp_path), env=dict(env, EXA_RANK=str(k), EXA_NRANKS=str(np_))) for k in range(np_)]
+        assert all(p.wait(timeout=1500) == 0 for p in ps)
     _check_against_golden(tmp_path, "voce_pa")
-    for k in range(2):
+    for k in range(np_):
         assert os.path.exists(os.path.join(str(tmp_path), "time", "time_solve.%d.txt" % k))
