@@ -40,7 +40,7 @@ APPLY_MOVED_BYTES_COMPACT = 248.0 # ... with the tangent in its deviatoric-block
 PCG_VEC_BYTES_PER_DOF = 128.0
 MODEL_NAMES = {"fcc_voce": "FCC Voce power-law", "bcc_voce": "BCC Voce power-law", "fcc_voce_nl": "FCC non-linear Voce",
                "fcc_kmdd": "FCC Kocks-Mecking dislocation density", "bcc_kmdd": "BCC Kocks-Mecking dislocation density"}
-SETTLE_PASSES = 60                # untimed constitutive passes before the timed region (>= --warmup): reported as `warmup`, see main()
+SETTLE_PASSES = 60                # untimed constitutive passes in front of a timed region that follows a COLD prepare phase (kinematic state, --solve-steps 0), see main()
 SOLVE_STEPS_DEFAULT = 14          # real Newton/PCG steps of the reference schedule before the timed passes (plastic regime: steps >= 10)
 SOLVE_STEPS_TOTAL_DEFAULT = 25    # ... and the solve goes on to this step after the timed regions: per-step in-solve kernel rates up to the plateau of the
                                   # dt = 0.1 segment (steps 3..21 of test/data/custom_dt.txt) and into the dt = 0.2 segment (22..27)
@@ -268,16 +268,20 @@ def main():
                              krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=fresh_uid(), jacobi=args.jacobi, **mk)
     del quats
     P_global = 8 * N ** 3
-    settle = max(args.warmup, int(os.environ.get("EXA_BENCH_SETTLE", str(SETTLE_PASSES))))      # EXA_BENCH_SETTLE: A/B aid (does a short --warmup read slow?)
+    # Untimed passes in front of a timed region.  The kinematic state is timed right after a cold prepare phase, where the first dozens of launches read
+    # ~4 % slow: SETTLE_PASSES there.  The headline region follows a 14-step real solve (24 s of GPU work): measured in round 5, --warmup 5 and 60 settle
+    # passes give the same value (3.771e9 | 3.759e9 qpt/s in one call), so it runs exactly the --warmup passes the contract names.
+    settle_cold = max(args.warmup, int(os.environ.get("EXA_BENCH_SETTLE", str(SETTLE_PASSES))))
+    settle = settle_cold if args.solve_steps <= 0 else max(args.warmup, int(os.environ.get("EXA_BENCH_SETTLE", "0")))
 
     def hist_dict(h):
         return {"mean": float((h * np.arange(64)).sum() / max(h.sum(), 1)), "max": int(np.nonzero(h)[0].max()) if h.any() else 0,
                 "hist": {str(i): int(c) for i, c in enumerate(h) if c}}
 
-    def timed_passes(d, steps):
+    def timed_passes(d, steps, nsettle):
         """untimed settle passes, then `steps` timed passes bracketed by barrier + synchronize; wall s (max over ranks), kernel ms per pass, failed points, histogram"""
-        if settle > 0:
-            d.bench_model(settle)
+        if nsettle > 0:
+            d.bench_model(nsettle)
         barrier(); t0 = time.perf_counter()
         mm = d.bench_model(steps)
         barrier(); tw = max_over_ranks(time.perf_counter() - t0)
@@ -295,7 +299,7 @@ def main():
     t0 = time.perf_counter(); drv.bench_prepare(PREP_DTS); barrier(); prep_s = time.perf_counter() - t0
     P_local = L.exa_driver_local_qpts(drv.h)
     kin_steps = args.steps if args.solve_steps <= 0 else max(5, args.steps // 2)
-    t_kin, kin_kern_ms, kin_failed, kin_hist = timed_passes(drv, kin_steps)
+    t_kin, kin_kern_ms, kin_failed, kin_hist = timed_passes(drv, kin_steps, settle_cold)
     kinematic = {"value": P_global * kin_steps / t_kin, "unit": "qpt-updates/s", "avg_kernel_ms": kin_kern_ms, "passes": kin_steps, "nonconverged_points": kin_failed,
                  "local_solver_evals": hist_dict(kin_hist), "prepare_wall_s": prep_s,
                  "state": "10 prescribed-velocity passes (v = L0 x + seeded perturbation) through the elastic-plastic transition, no equilibrium solve"}
@@ -347,10 +351,10 @@ def main():
                          "size the linear solves stop at the iteration cap: pcg_worst_residual_reduction_at_cap = |r|/|r0| they reached (Newton converges regardless)"}
         P_local = L.exa_driver_local_qpts(drv.h)
     # ---- timed region 1: constitutive passes at the benchmark state --------------------------------------------------------------------
-    # untimed passes before the timed region: the --warmup passes of the contract, and at least SETTLE_PASSES in total so that a short
-    # timed region (the driver runs --steps 20) starts at the clock a long one runs at; the line's `warmup` is the number that ran
+    # untimed passes before the timed region: exactly the --warmup passes of the contract (after the real solve; see `settle` above); the line's
+    # `warmup` is the number that ran
     if args.solve_steps > 0:
-        t_model, kern_ms, failed, nfev = timed_passes(drv, args.steps)
+        t_model, kern_ms, failed, nfev = timed_passes(drv, args.steps, settle)
     else:
         t_model, kern_ms, failed, nfev = t_kin, kin_kern_ms, kin_failed, kin_hist
     m = {"failed": failed}
