@@ -72,7 +72,7 @@ def test_executable_ranks(tmp_path, np_):
     mesh on 2 x 2 x 2 blocks).  One GPU per rank: RCCL; a one-GPU box: the ranks hand the identity of their device to rank 0 in the rendez-vous,
     which finds them on one device and answers with the id of the shared-device inter-process transport instead of a RCCL id (stderr says so)."""
     mpirun = _mpirun()
-    nsteps = 40 if np_ == 2 else 8      # (eight processes share one GPU through the host-synchronous transport: the first 8 of the 40 steps there)
+    nsteps = 40 if np_ == 2 else 4      # (eight processes share one GPU through the host-synchronous transport: the first 4 of the 40 steps there)
     toml = _stage(tmp_path, "voce_pa", nsteps=None if nsteps == 40 else nsteps)
     env = dict(os.environ, EXA_MASTER_PORT=str(29533 + np_))
     if mpirun:

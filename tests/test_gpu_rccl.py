@@ -69,7 +69,8 @@ def test_bench_ranks_under_torchrun(tmp_path, nproc):
     (ncclCommCount over RCCL; the shared-device transport on a one-GPU box) and every rank's share of the partition."""
     import torch
     root = os.path.dirname(HERE)
-    env = dict(os.environ, EXA_BENCH_N="32", EXA_BENCH_SOLVE_STEPS="3", EXA_BENCH_SOLVE_STEPS_TOTAL="4"); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the driver's line carries no size flags)
+    ss = 3 if nproc == 2 else 2      # (eight processes on one GPU through the host-synchronous transport: one step fewer)
+    env = dict(os.environ, EXA_BENCH_N="32", EXA_BENCH_SOLVE_STEPS=str(ss), EXA_BENCH_SOLVE_STEPS_TOTAL=str(ss + 1)); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the driver's line carries no size flags)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(29573 + nproc),
            os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1500)
@@ -78,8 +79,8 @@ def test_bench_ranks_under_torchrun(tmp_path, nproc):
     d = json.loads(line)
     assert d["n_gpus"] == nproc and d["comm"]["ranks_reported_by_transport"] == nproc
     assert d["comm"]["transport"] == ("rccl" if torch.cuda.device_count() >= nproc else "ipc")
-    assert d["nonconverged_points"] == 0 and d["value"] > 0 and d["newton_pcg_solve"]["steps"] == 3
+    assert d["nonconverged_points"] == 0 and d["value"] > 0 and d["newton_pcg_solve"]["steps"] == ss
     pr = d["comm"]["per_rank"]
     assert [p["rank"] for p in pr] == list(range(nproc)) and sum(p["elements"] for p in pr) == 32 ** 3
     assert all(p["neighbours"] == (1 if nproc == 2 else 7) and p["halo_bytes_per_exchange"] > 0 for p in pr)
-    assert d["roofline"]["in_solve"]["solved_to_step"] == 4 and os.path.basename(d["library"]["path"]).startswith("libexaconstit_hip")
+    assert d["roofline"]["in_solve"]["solved_to_step"] == ss + 1 and os.path.basename(d["library"]["path"]).startswith("libexaconstit_hip")
