@@ -29,23 +29,44 @@ constexpr double SQR2I = 0.70710678118654752, SQR6I = 0.40824829046386302, SQR2B
 constexpr double TINY_SQRT = 1.0e-90, EPS_SQRT = 1.0e-8;
 constexpr double GAM_RATIO_OVF = 1.0e45, LN_GAM_RATIO_MIN = -138.15510557964274;
 constexpr double E_SCALE = 5.0e-4, R_SCALE = 0.01;
-// Streaming accesses of the per-point records (read once / written once per launch) can carry the non-temporal hint (ECM_NT=1), the idea
-// being that they then do not displace the wave-slot scratch lines (spills) from L2.
+// Streaming accesses of the per-point records (read once / written once per launch) carry the non-temporal hint: the state / stress / record rows a
+// launch writes are next read by ANOTHER launch after gigabytes of other traffic (3.5 GB of records, 3.8 GB of state at 128^3), so keeping them out
+// of L2 leaves it to the node rows the gathers of neighbouring waves share.  History: round 2 measured the hint as a loss (plastic pass 7.28 -> 7.56 ms)
+// when the kernel still spilled - its scratch lines are what the hint displaced; round 5 (no scratch): stores 4.21 -> 4.18 ms, loads alone +-0, both
+// 4.21 / 4.23 -> 4.17 / 4.13 ms, elastic pass 2.76 -> 2.70 ms (profiles/r05_kernel_experiments.txt).  ECM_NT=0 restores plain accesses (A/B switch).
 #ifndef ECM_NT
-#define ECM_NT 0   // measured at 128^3 (profiles/r02_nt_ab.txt): L2-boundary traffic 1534 -> 1446 B/qpt, elastic pass 5.43 -> 5.24 ms, plastic pass 7.28 -> 7.56 ms: not kept as the default
+#define ECM_NT 1
+#endif
+#ifndef ECM_NT_LD
+#define ECM_NT_LD ECM_NT
+#endif
+#ifndef ECM_NT_ST
+#define ECM_NT_ST ECM_NT
+#endif
+#ifndef ECM_NT_REC
+#define ECM_NT_REC ECM_NT_ST   // the 13 16-byte pairs of the compact gradient record (read by the NEXT kernel, 3.5 GB at 128^3: never from cache)
 #endif
 __device__ __forceinline__ double ldg(const double* p) {
-#if ECM_NT
+#if ECM_NT_LD
    return __builtin_nontemporal_load(p);
 #else
    return *p;
 #endif
 }
 __device__ __forceinline__ void stg(double* p, double v) {
-#if ECM_NT
+#if ECM_NT_ST
    __builtin_nontemporal_store(v, p);
 #else
    *p = v;
+#endif
+}
+__device__ __forceinline__ void stg2(double2* p, double a, double b) {
+#if ECM_NT_REC
+   typedef double vd2 __attribute__((ext_vector_type(2)));
+   vd2 v; v.x = a; v.y = b;
+   __builtin_nontemporal_store(v, reinterpret_cast<vd2*>(p));
+#else
+   *p = make_double2(a, b);
 #endif
 }
 
@@ -1840,7 +1861,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
          { double a = 0.0, b = 0.0; for (int pr = 0; pr < 13; pr++) { a += Dm[2 * pr]; b += Dm[2 * pr + 1]; } rc[0] = make_double2(a, b); }
 #else
 #pragma unroll
-         for (int pr = 0; pr < 13; pr++) rc[pr * 64] = make_double2(Dm[2 * pr], Dm[2 * pr + 1]);
+         for (int pr = 0; pr < 13; pr++) stg2(&rc[pr * 64], Dm[2 * pr], Dm[2 * pr + 1]);
 #endif
       } else {
       const double dti = pb.dt_ri * (okT ? 1.0 : 0.0);
@@ -1978,7 +1999,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
          { double a = 0.0, b = 0.0; for (int pr = 0; pr < 13; pr++) { a += Dm[2 * pr]; b += Dm[2 * pr + 1]; } rc[0] = make_double2(a, b); }
 #else
 #pragma unroll
-         for (int pr = 0; pr < 13; pr++) rc[pr * 64] = make_double2(Dm[2 * pr], Dm[2 * pr + 1]);
+         for (int pr = 0; pr < 13; pr++) stg2(&rc[pr * 64], Dm[2 * pr], Dm[2 * pr + 1]);
 #endif
       } else {
       const double dti = pb.dt_ri * (okT ? 1.0 : 0.0);
