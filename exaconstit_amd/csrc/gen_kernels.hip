@@ -100,7 +100,7 @@ __global__ __launch_bounds__(PA_BLK) void k_assemble_ea_gen(const int E, const d
       const double2* rec = reinterpret_cast<const double2*>(pa + pa_off(blk, Q, q, 0)) + lane;
       double v[PA_SLOTS];
 #pragma unroll
-      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = rec[pr * PA_BLK]; v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
+      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = ld_rec(&rec[pr * PA_BLK]); v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
       const double* Ct = v; const double* adj = v + 36;
       const double detJ = v[45] / W[q];
       const double* Gq = sG + 3 * N * q;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(PA_BLK) void k_assemble_ea_rt(const int n, const in
       const double2* rec = reinterpret_cast<const double2*>(pa + pa_off(blk, Q, q, 0)) + lane;
       double v[PA_SLOTS];
 #pragma unroll
-      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = rec[pr * PA_BLK]; v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
+      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = ld_rec(&rec[pr * PA_BLK]); v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
       const double* Ct = v; const double* adj = v + 36;
       const double detJ = v[45] / W[q];
       const double* Gq = G + (int64_t)3 * n * q;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const doubl
    auto load = [&](int q) {
       const double2* r = reinterpret_cast<const double2*>(pa + (CMP ? pac_off<PAC_PAIRS_GEO>(blk, P2N, q, 0) : pa_off(blk, P2N, q, 0))) + lane;
 #pragma unroll
-      for (int pr = 0; pr < NPR; pr++) rec[pr] = r[pr * PA_BLK];
+      for (int pr = 0; pr < NPR; pr++) rec[pr] = ld_rec(&r[pr * PA_BLK]);
    };
    load(0);
    int gidx[P2N];

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
       const double2* rec = reinterpret_cast<const double2*>(pa + (CMP ? pac_off<PAC_PAIRS>(blk, 8, q, 0) : pa_off(blk, 8, q, 0))) + lane;
       double v[PA_SLOTS];
 #pragma unroll
-      for (int pr = 0; pr < (CMP ? PAC_PAIRS : (GEO ? 18 : PA_PAIRS)); pr++) { const double2 t = rec[pr * PA_BLK]; v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
+      for (int pr = 0; pr < (CMP ? PAC_PAIRS : (GEO ? 18 : PA_PAIRS)); pr++) { const double2 t = ld_rec(&rec[pr * PA_BLK]); v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
       if (GEO) {   // J(i,j) = sum_a x_a,i dN_a/dxi_j, then adj(J) exactly as grad_setup stored it
          double Jl[9];
 #pragma unroll
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_diag_p1(const int E, const doub
       const double2* rec = reinterpret_cast<const double2*>(pa + pa_off(blk, 8, q, 0)) + lane;
       double v[PA_SLOTS];
 #pragma unroll
-      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = rec[pr * PA_BLK]; v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
+      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = ld_rec(&rec[pr * PA_BLK]); v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
       const double* Ct = v; const double* adj = v + 36;
 #pragma unroll
       for (int a = 0; a < 8; a++) {
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(PA_BLK) void k_assemble_ea_p1(const int E, const do
       const double2* rec = reinterpret_cast<const double2*>(pa + pa_off(blk, 8, q, 0)) + lane;
       double v[PA_SLOTS];
 #pragma unroll
-      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = rec[pr * PA_BLK]; v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
+      for (int pr = 0; pr < PA_PAIRS; pr++) { const double2 t = ld_rec(&rec[pr * PA_BLK]); v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
       const double* Ct = v; const double* adj = v + 36;
       // b vectors (detJ * dN/dx) for every node; Ct already carries dt W / detJ
       double b[8][3];
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(PA_BLK) void k_ea_apply_p1(const int E, const doubl
       const double2* col = reinterpret_cast<const double2*>(emat + ea_off(blk, j, 0)) + lane;
       double s = 0;
 #pragma unroll
-      for (int ipair = 0; ipair < 12; ipair++) { const double2 t = col[ipair * PA_BLK]; s += t.x * X[2 * ipair] + t.y * X[2 * ipair + 1]; }
+      for (int ipair = 0; ipair < 12; ipair++) { const double2 t = ld_rec(&col[ipair * PA_BLK]); s += t.x * X[2 * ipair] + t.y * X[2 * ipair + 1]; }
       if (LVEC) atomicAdd(&y[g[j & 7] + (int64_t)nnodes * (j >> 3)], s);
       else y[j + 24 * e] += s;
    }
