@@ -113,6 +113,9 @@ __global__ void k_reduce_cg(int nb, const double* __restrict__ partial, double* 
 // x += alpha d; r -= alpha z; z = dinv r; partial of (r, z)_w
 // IDENT: the preconditioner is the identity (the reference's Jacobi smoother with its never-refreshed dinv = 1): z == r, so dinv is
 // not read and z is not written (k_cg_step2z<true> takes r instead)
+#ifndef EXA_CG_X_NT
+#define EXA_CG_X_NT 1
+#endif
 template <bool IDENT>
 __global__ void k_cg_step1(int64_t n, int64_t nn, const double* __restrict__ S, const double* __restrict__ w, const double* __restrict__ dinv,
                            const double* __restrict__ d, double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial) {
@@ -121,7 +124,11 @@ __global__ void k_cg_step1(int64_t n, int64_t nn, const double* __restrict__ S, 
    const double alpha = S[4];
    double acc = 0;
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#if EXA_CG_X_NT
+      __builtin_nontemporal_store(__builtin_nontemporal_load(&x[i]) + alpha * d[i], &x[i]);      // x is touched once per iteration: it need not displace d, r, z from the caches
+#else
       x[i] += alpha * d[i];
+#endif
       const double ri = r[i] - alpha * z[i];
       r[i] = ri;
       const double zi = IDENT ? ri : dinv[i] * ri;
