@@ -489,9 +489,9 @@ def main():
                                                       "26 record doubles: no Jacobian field, effective shear rate from state slot 0); frac stays priced at SURVEY 8(d)'s 928 B/qpt",
                          "note": "the contract's HBM fraction of the ALGORITHMIC bytes (928 B/qpt) is reported in frac; the launch is bound by FP64 VALU issue at the clock "
                                  "the chip sustains at its 1 400 W package limit (~1.93 GHz, not the nominal 2.4 GHz the fp64_issue figures are priced at): SQ counters "
-                                 + ("(profiles/r04_sq_fcc_voce.txt) show the VALU busy 86 % of the wave cycles, 6 845 VALU instructions per wave of which 5 947 FP64 arithmetic, "
-                                    "no scratch (7 660 instructions / 100 B at the end of round 3, profiles/r04_kernel_experiments.txt); " if args.model == "fcc_voce" else
-                                    f"of the Kocks-Mecking launches (main + tail) in profiles/r04_sq_{args.model}.txt; fp64_* figures are quoted for the Voce kernel only; ")
+                                 + ("(profiles/r05_sq_fcc_voce.txt) show the VALU busy 89 % of the wave cycles and waiting 12 % of them, 6 820 VALU instructions per wave of which 5 947 FP64 "
+                                    "arithmetic, no scratch (round 4: 86 % / 19.5 % / 6 845; profiles/r05_kernel_experiments.txt); " if args.model == "fcc_voce" else
+                                    f"of the Kocks-Mecking launches (main + tail) in profiles/r05_sq_{args.model}.txt; fp64_* figures are quoted for the Voce kernel only; ")
                                  + "traffic = L2-boundary bytes from the PMC "
                                  "passes of THIS kernel build and instantiation (profiles/*_pmc_traffic.json with the library's kernel_build_id; null otherwise); "
                                  "roofline_pcg_apply is the HBM-bound half of the metric"},
