@@ -184,7 +184,12 @@ __global__ void k_cg2_update(int64_t n, const double* __restrict__ S, const doub
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
       const double ui = IDENT ? r[i] : u[i];
       const double pi = ui + beta * p[i], qi = sv[i] + beta * q[i];
-      p[i] = pi; q[i] = qi; x[i] += alpha * pi;
+      p[i] = pi; q[i] = qi;
+#if EXA_CG_X_NT
+      __builtin_nontemporal_store(__builtin_nontemporal_load(&x[i]) + alpha * pi, &x[i]);      // (x and q are touched once per iteration: see k_cg_step1)
+#else
+      x[i] += alpha * pi;
+#endif
       const double ri = r[i] - alpha * qi;
       r[i] = ri;
       if (!IDENT) u[i] = dinv[i] * ri;
