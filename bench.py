@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--model", default="fcc_voce", choices=["fcc_voce", "bcc_voce", "fcc_voce_nl", "fcc_kmdd", "bcc_kmdd"],
                     help="crystal model of the RVE; the headline metric is quoted on fcc_voce (BASELINE config 4 also names bcc_kmdd)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adapter-route", action="store_true", help="skip the `adapter_route` block (the calls the MFEM adapters make, timed at the same state)")
     ap.add_argument("--jacobi", action="store_true", help="true Jacobi preconditioner (refreshed every Newton iteration) instead of the reference's effective identity (SURVEY fact 9)")
     ap.add_argument("--solve-steps", type=int, default=int(os.environ.get("EXA_BENCH_SOLVE_STEPS", str(SOLVE_STEPS_DEFAULT))),
                     help="real Newton/PCG time steps of the reference schedule that bring the RVE to the benchmark state (0: kinematically driven state only)")
@@ -374,6 +375,43 @@ def main():
     if world > 1:      # every rank's share: elements, neighbours, bytes per halo exchange, overlap setting
         per_rank = [None] * world
         dist.all_gather_object(per_rank, dict(rank=rank, **comm_details))
+    # ---- the drop-in route at the same state: what include/exaconstit_mfem_adapters.hpp calls (never `value`) --------------------------------------------
+    adapter = None
+    if world == 1 and not args.no_adapter_route and args.assembly.upper() == "PA" and N <= 160:
+        try:
+            ar = drv.bench_adapter_route(max(5, min(args.steps, 40)), max(5, min(args.pcg_iters, 40)))
+            Pq = float(P_local)
+            adapter = {
+                "what": "the SAME state through exactly the calls HipExaModel::ModelSetup and HipExaNLFIntegrator::{AssembleGradPA, AddMultGradPA} make "
+                        "(include/exaconstit_mfem_adapters.hpp): exa_model_setup on the reference's (vdim, Q, E) quadrature functions with a Jacobian field and a velocity "
+                        "E-vector, exa_grad_setup, exa_grad_apply on E-vectors between exa_restrict and exa_restrict_transpose_add; a second context in the AOS layout "
+                        "that is given the driver's begin-of-step state (de-blocked on the device), coordinates and velocity",
+                "aos_staging_through_lds": ar["aos_staging"],
+                "model_setup": {"avg_kernel_ms": ar["model_ms"], "qpt_updates_per_s": Pq / (ar["model_ms"] * 1e-3), "bytes_per_qpt": MODEL_BYTES_PER_QPT,
+                                "frac": MODEL_BYTES_PER_QPT * Pq / (ar["model_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "pass_ms_with_velocity_restriction": ar["pass_ms"], "nonconverged_points": ar["failed"],
+                                "driver_route_same_loop_ms": ar["driver_route_model_ms"], "ratio_to_driver_route": ar["model_ms"] / ar["driver_route_model_ms"],
+                                "note": "frac = 928 B x qpts / kernel time / 8 TB/s (SURVEY 8(d)); this launch moves all of them (Jacobian field in, 36 tangent entries out); "
+                                        "driver_route = exa_model_setup_lvec_records on the element-blocked layout (`value`)"},
+                "geometry_ms": ar["geometry_ms"],
+                "grad_setup": {"avg_kernel_ms": ar["grad_setup_ms"], "bytes_per_qpt": 8.0 * (36 + 9 + 46),
+                               "frac": 8.0 * (36 + 9 + 46) * Pq / (ar["grad_setup_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "AssembleGradPA: reads tangent 36 + Jacobian 9, writes the 46-double record (the reference writes 81; the record route has no such pass)"},
+                "grad_apply": {"avg_kernel_ms": ar["grad_apply_ms"], "bytes_per_qpt": APPLY_BYTES_PER_QPT,
+                               "frac": APPLY_BYTES_PER_QPT * Pq / (ar["grad_apply_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "bytes_moved_per_qpt": 8.0 * (46 + 3 + 6), "frac_on_bytes_moved": 8.0 * 55 * Pq / (ar["grad_apply_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "action_ms_with_restriction_and_transpose": ar["action_ms"],
+                               "driver_route_action_ms": ar["driver_route_apply_ms"], "ratio_to_driver_route": ar["action_ms"] / ar["driver_route_apply_ms"],
+                               "note": "AddMultGradPA on E-vectors: 46-double record + x (24 / element) + y read and written; frac priced at SURVEY 8(d)'s 408 B/qpt; "
+                                       "action = L->E + kernel + E->L, what an MFEM caller pays per PCG iteration"},
+                "parity_with_driver_route": {"stress_max_rel_diff": ar["stress_rel_diff"], "state_max_rel_diff": ar["state_rel_diff"], "action_max_rel_diff": ar["action_rel_diff"],
+                                             "points_with_another_evaluation_count": ar["nfev_differing"],
+                                             "note": "max |a - b| / max |a| over all points of the RVE: end-of-step stress and state (slot 3, the local solver's evaluation "
+                                                     "count, counted separately) of the AOS launch against the record route's, K x through the E-vector action against the "
+                                                     "L-vector action"},
+            }
+        except Exception as e:      # a reported block, never a dependency of the headline
+            adapter = {"failed": str(e)}
     # ---- the solve goes on: in-solve kernel rates up to the plateau (qpt updates/s = sum of P over ModelSetup calls / kernel time) ----------
     in_solve = None
     if solve is not None and args.solve_steps_total > args.solve_steps:
@@ -511,6 +549,8 @@ def main():
             out["newton_pcg_solve"] = solve
         if in_solve is not None:
             out["roofline"]["in_solve"] = in_solve
+        if adapter is not None:
+            out["adapter_route"] = adapter
         if world == 1 and not args.no_cpu_baseline:
             try:
                 voce = np.loadtxt(os.path.join(ROOT, "tests", "golden", "refdata", "props_cp_voce.txt")).ravel()

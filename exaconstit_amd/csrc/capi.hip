@@ -113,6 +113,8 @@ int exa_set_quadrature_layout(exa_ctx* ctx, int layout) {
    ctx->qblk = (layout == EXA_QLAYOUT_EB64); ctx->have_resid = false; ctx->have_grad = false;
    return EXA_OK;
 }
+int exa_set_aos_staging(exa_ctx* ctx, int on) { if (!ctx) return EXA_ERR_ARG; ctx->aos_stage = on != 0; return EXA_OK; }
+int exa_get_aos_staging(const exa_ctx* ctx) { return (ctx && ctx->aos_stage) ? 1 : 0; }
 int exa_get_quadrature_layout(const exa_ctx* ctx) { return (ctx && ctx->qblk) ? EXA_QLAYOUT_EB64 : EXA_QLAYOUT_AOS; }
 int64_t exa_qf_size(const exa_ctx* ctx, int vdim) { return (ctx && vdim > 0) ? (int64_t)exa_qf_doubles(ctx, vdim) : -1; }
 

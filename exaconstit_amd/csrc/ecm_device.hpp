@@ -60,6 +60,10 @@ __device__ __forceinline__ void stg(double* p, double v) {
    *p = v;
 #endif
 }
+// output store of the point update: global memory (non-temporal), or - LO, the staged AOS launch (model_kernel.hpp, PointIO<.., STG>) - the lane's row of
+// the wave's LDS stage, from where the wave stores whole rows of 64 points coalesced
+template <bool LO>
+__device__ __forceinline__ void ost(double* p, double v) { if constexpr (LO) *p = v; else stg(p, v); }
 __device__ __forceinline__ void stg2(double2* p, double a, double b) {
 #if ECM_NT_REC
    typedef double vd2 __attribute__((ext_vector_type(2)));
@@ -683,9 +687,12 @@ ECM_DI double kin_update_h(const MatParams& mp, double hs_o, double dt, double s
 #define ECM_SWEEP_UNROLL 0   // block Gauss-Seidel sweeps of the Newton step rolled (1: unrolled; A/B on MI355X)
 #endif
 #ifndef ECM_STASH_STRIDE
-#define ECM_STASH_STRIDE 128   // = threads per block of the constitutive launch.  128 (4 blocks of 2 waves per CU) instead of 256: every stash slot is then within
-                               // the 64 KB reach of a ds_read / ds_write immediate offset from ONE address register (with 256 the slots from 32 up
-                               // needed their own address registers, which the allocator spilled), and a block waits for 2 waves instead of 4
+#define ECM_STASH_STRIDE 64    // lanes per stash region: every WAVE owns ST_SLOTS x 64 contiguous doubles (slot s of lane l at region[s * 64 + l]), the regions of a
+                               // block's waves one behind the other (model_kernel.hpp, PointIO::stash).  All slots are within the reach of a ds_read / ds_write
+                               // immediate offset from ONE address register (rounds 3-5: stride = block size 128, slots interleaved across the two waves; with
+                               // 256 the slots from 32 up needed their own address registers, which the allocator spilled).  Per-wave regions are what lets the
+                               // staged AOS launch use the wave's region as a transposition buffer for its 64 contiguous point rows (round 6); 128 = the
+                               // interleaved form of rounds 3-5 (A/B switch; no staged launch then)
 #endif
 #ifndef ECM_EPI_NO_LOADS
 #define ECM_EPI_NO_LOADS 1   // no global or scratch load behind the first output store: on gfx9 loads and stores share the in-order vmcnt counter, so a load
@@ -699,6 +706,12 @@ constexpr int PB_SCI = 0, PB_ESCI = 1, PB_DETVRI = 2;   // 1/sc, 1/esc, 1/detV: 
 constexpr int PB_SHR0 = 3, PB_FLOW0 = 4;               // begin-of-step accumulated shear / plastic work: only the outputs need them (see ECM_EPI_NO_LOADS)
 static_assert(ST_PB + PB_FLOW0 < ST_SLOTS, "stash slots");
 constexpr int ST_NCD = ST_PB - ST_CD;
+// Staged AOS launch (point_update<.., STG>): its tangent rows only cover slots 0 .. 17 of the wave's region, so what the state / stress outputs need after the
+// tangent waits in slots that are dead by then - the tail of the restore copy of x, the begin-of-step quaternion (read), the record scale (REC only), 1/sc
+// (Newton loop only), the bulk modulus (read) - instead of in registers across the tangent arithmetic (the allocator spilled 13 of them to scratch, and a
+// scratch reload behind the row stores waits for the store queue of the wave)
+constexpr int ST_EPI_E = ST_XS + 5, ST_EPI_Q0 = ST_EPI_E + 5, ST_EPI_Q2 = 31, ST_EPI_Q3 = 33, ST_EPI_WRK = 29;
+static_assert(ST_EPI_E == 18 && ST_EPI_Q0 + 1 == ST_CD + 3 && ST_EPI_E + 4 < ST_EPI_Q0, "epilogue parking slots: rows of the tangent halves end at slot 17; e_f in 18..22 (x tail, q_n[0..1])");
 // (the deviatoric stress work of the step needs D' and the old stress only through  sum (s_old + s_new) . D' = s_old . D' + s_lat . d_lat:
 //  the first scalar is parked, the second uses the lattice-frame D' of the converged evaluation - 10 slots fewer than parking both vectors)
 constexpr int CD_QN = 0, CD_VOLD = 4, CD_VNEW = 5, CD_ENEW = 6, CD_DEFF = 7, CD_BULK = 8, CD_HU = 9, CD_TSC = 10, CD_WRKOLD = 11;
@@ -1094,8 +1107,9 @@ ECM_DI bool eval_rj(const MatParams& mp, const Prob& pb, const double x[8], doub
 }
 
 // slip rates at the converged point (Voce family): written once, instead of one global store per system and evaluation
-template <int XNCT>
-ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out, double& dis_rate, double& shrate) {
+// LO: gdot_out is the lane's row in the LDS stage (see ost); the stash may then no longer be read, 1/detV comes in through detv_lo
+template <int XNCT, bool LO = false>
+ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out, double& dis_rate, double& shrate, const double detv_lo = 0.0) {
    const double ks[5] = { mp.pk0 * e_f[0], mp.pk1 * e_f[1], mp.pk2 * e_f[2], mp.pk2 * e_f[3], mp.pk2 * e_f[4] };
    double tau[NSLIP], gd[NSLIP];
    if (ECM_SLIP_FORMS_CSE) slip_tau12(ks, tau);
@@ -1111,13 +1125,13 @@ ECM_DI void voce_slip_rates(const MatParams& mp, const Prob& pb, const double e_
    voce_gdot12<false, true, XNCT>(mp, pb.g_i, tau, gd, nullptr);
    double dis = 0.0, shr = 0.0;
 #pragma unroll
-   for (int a = 0; a < NSLIP; a++) { stg(&gdot_out[a * pb.gs], gd[a]); dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
-   if (ECM_DEFER_DIS) { dis_rate = dis * ECM_ST(pb.st, ST_PB + PB_DETVRI); shrate = shr; }   // (rates below t_min = (1e-60)^m count as 0 here: below 1e-60 of the reference rate)
+   for (int a = 0; a < NSLIP; a++) { ost<LO>(&gdot_out[a * pb.gs], gd[a]); dis += tau[a] * gd[a]; shr += fabs(gd[a]); }
+   if (ECM_DEFER_DIS) { dis_rate = dis * (LO ? detv_lo : ECM_ST(pb.st, ST_PB + PB_DETVRI)); shrate = shr; }   // (rates below t_min = (1e-60)^m count as 0 here: below 1e-60 of the reference rate)
 }
 
 // slip rates at the converged point (Kocks-Mecking family, ECM_KM_GDOT_AT_END): one more pass through the kinetics (no derivatives) instead
 // of 12 global stores per evaluation - on gfx9 every scratch reload of the Newton loop otherwise waits for those stores (vmcnt)
-template <bool PQ1, bool SC>
+template <bool PQ1, bool SC, bool LO = false>
 ECM_DI void km_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out) {
    const double k[5] = { mp.kd0 * e_f[0], mp.kd0 * e_f[1], mp.kd2 * e_f[2], mp.kd2 * e_f[3], mp.kd2 * e_f[4] };
 #pragma unroll 1
@@ -1127,7 +1141,7 @@ ECM_DI void km_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[
       for (int a = 0; a < KW; a++) tau[a] = PQ_TAB[a0 + a][0] * k[0] + PQ_TAB[a0 + a][1] * k[1] + PQ_TAB[a0 + a][2] * k[2] + PQ_TAB[a0 + a][3] * k[3] + PQ_TAB[a0 + a][4] * k[4];
       kmbald_gdot4<false, ECM_KW, PQ1, SC>(mp, pb.kv, tau, gd, nullptr);
 #pragma unroll
-      for (int a = 0; a < KW; a++) stg(&gdot_out[(a0 + a) * pb.gs], gd[a]);
+      for (int a = 0; a < KW; a++) ost<LO>(&gdot_out[(a0 + a) * pb.gs], gd[a]);
    }
 }
 
@@ -1137,7 +1151,7 @@ ECM_DI void km_slip_rates(const MatParams& mp, const Prob& pb, const double e_f[
 #ifndef ECM_KM_GDOT_GA
 #define ECM_KM_GDOT_GA 1
 #endif
-template <bool PQ1, bool SC>
+template <bool PQ1, bool SC, bool LO = false>
 ECM_DI void km_slip_rates_ga(const MatParams& mp, const Prob& pb, const double e_f[5], double* __restrict__ gdot_out) {
    const double ks[5] = { mp.pk0 * e_f[0], mp.pk1 * e_f[1], mp.pk2 * e_f[2], mp.pk2 * e_f[3], mp.pk2 * e_f[4] };
    const double g_ia = 1.0 / mp.tau_a, gAth = pb.kv.g, wi = 1.0 / mp.wrD;
@@ -1178,7 +1192,7 @@ ECM_DI void km_slip_rates_ga(const MatParams& mp, const Prob& pb, const double e
       }
    }
 #pragma unroll
-   for (int a = 0; a < NSLIP; a++) stg(&gdot_out[a * pb.gs], gd[a]);
+   for (int a = 0; a < NSLIP; a++) ost<LO>(&gdot_out[a * pb.gs], gd[a]);
 }
 
 // ---- pieces of the Jacobian action (rotation data from the stash) ---------------------------------------------------
@@ -1406,21 +1420,28 @@ ECM_DI double norm8sq(const double v[8]) { double s = 0; for (int i = 0; i < 8; 
 // rows travel together: as loads inside point_update they were issued behind the gathers' wait - one more memory round trip at the start of every
 // wave (round 5: the prologue of the fused launch went from five dependent round trips to two).
 struct PointIn { double shrate, shr, flow, e[5], q[4], h, vol, eint, s[6]; };
-template <int QS>
+// LI: the rows are in the wave's LDS stage (staged AOS launch): plain reads
+template <int QS, bool LI = false>
 ECM_DI void load_point_in(const double* __restrict__ sv0, const double* __restrict__ s0, PointIn& p) {
-   p.shrate = ldg(&sv0[(H_SHRATE) * QS]); p.shr = ldg(&sv0[(H_SHR) * QS]); p.flow = ldg(&sv0[(H_FLOW) * QS]);
+   auto ld = [](const double* a) { if constexpr (LI) return *a; else return ldg(a); };
+   p.shrate = ld(&sv0[(H_SHRATE) * QS]); p.shr = ld(&sv0[(H_SHR) * QS]); p.flow = ld(&sv0[(H_FLOW) * QS]);
 #pragma unroll
-   for (int i = 0; i < 5; i++) p.e[i] = ldg(&sv0[(H_E + i) * QS]);
+   for (int i = 0; i < 5; i++) p.e[i] = ld(&sv0[(H_E + i) * QS]);
 #pragma unroll
-   for (int i = 0; i < 4; i++) p.q[i] = ldg(&sv0[(H_Q + i) * QS]);
-   p.h = ldg(&sv0[(H_H) * QS]); p.vol = ldg(&sv0[(IND_VOL) * QS]); p.eint = ldg(&sv0[(IND_EINT) * QS]);
+   for (int i = 0; i < 4; i++) p.q[i] = ld(&sv0[(H_Q + i) * QS]);
+   p.h = ld(&sv0[(H_H) * QS]); p.vol = ld(&sv0[(IND_VOL) * QS]); p.eint = ld(&sv0[(IND_EINT) * QS]);
 #pragma unroll
-   for (int i = 0; i < 6; i++) p.s[i] = ldg(&s0[i * QS]);
+   for (int i = 0; i < 6; i++) p.s[i] = ld(&s0[i * QS]);
 }
 
-template <int KIN, int QS, bool REC = false, class IO>
+// STG (staged AOS launch): the outputs go to the lane's rows of the wave's LDS stage - which is the wave's stash region - and the wave stores them
+// coalesced in three rounds (io.flush_tangent(0 | 1), io.flush_state()): every lane must stay in the wave until the last round (a point that is cut off by the
+// tail split only marks itself), and nothing may be read from the stash once the first row of a round has been written.
+template <int KIN, int QS, bool REC = false, bool STG = false, class IO>
 ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io, const int kcap, const PointIn& pin,
                         const double* pq_lds = nullptr, const double tsc = 0.0, const bool trd = false, const TailIO tio = TailIO()) {
+   static_assert(!STG || (QS == 1 && !REC && ECM_STASH_STRIDE == 64 && ECM_EPI_NO_LOADS && ECM_TANGENT_FIRST && ECM_KM_GDOT_AT_END), "staged outputs: AOS rows, per-wave stash regions, tangent first");
+   bool cut = false;   // STG: handed over to the dense launch (the lane stays for the wave's stores; what it writes the dense launch overwrites)
    const bool resume = tio.rs_in != nullptr;
    const double* __restrict__ sv0 = io.sv0();
    double* st = io.stash();
@@ -1561,7 +1582,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
                for (int i = 0; i < 8; i++) stg(&o[i * tio.stride], x[i]);
                stg(&o[8 * tio.stride], delta); stg(&o[9 * tio.stride], (double)nfev);
             }
-            return 2;
+            if constexpr (STG) { cut = true; break; } else return 2;
          }
          // Newton step first; the steepest-descent data (grad = Js^T r, Jg = Js grad) only when the step leaves the trust region
          if (!KEEP || !reject_prev) {
@@ -1670,9 +1691,16 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
    // before the state / stress outputs are computed instead of being carried (and spilled) through them; and no scratch reload of the
    // tangent arithmetic has to wait behind the 34 output stores (on gfx9 a reload waits for every earlier store of the wave).  The two
    // parked values the outputs need from the slot the tangent overwrites are read before.
-   const double hu_keep = ECM_CD(CD_HU), deff_keep = ECM_CD(CD_DEFF);
+   const double hu_keep = ECM_CD(CD_HU), deff_keep = ECM_CD(CD_DEFF);      // (STG: read again in write_state_staged, not carried)
    double wrk_new = 0.0;   // s_new . D' in the lattice frame of the converged evaluation (the inner product of the 5-vectors is frame-invariant)
    for (int k = 0; k < 5; k++) wrk_new += s_lat[k] * J.dl[k];
+   if constexpr (STG) {   // see ST_EPI_*
+      static_assert(ST_EPI_Q2 == ST_CD + CD_TSC && ST_EPI_Q3 == ST_PB + PB_SCI && ST_EPI_WRK == ST_CD + CD_BULK && !REC, "dead slots");
+      for (int i = 0; i < 5; i++) ECM_ST(st, ST_EPI_E + i) = e_f[i];
+      ECM_ST(st, ST_EPI_Q0) = qout[0]; ECM_ST(st, ST_EPI_Q0 + 1) = qout[1]; ECM_ST(st, ST_EPI_Q2) = qout[2]; ECM_ST(st, ST_EPI_Q3) = qout[3];
+      ECM_ST(st, ST_EPI_WRK) = wrk_new;
+      ECM_PARK_BARRIER();
+   }
    auto write_state = [&]() {
       for (int i = 0; i < 4; i++) stg(&sv1[(H_Q + i) * QS], qout[i]);
       double s_sm[5]; rot_vecd(Cf, s_lat, s_sm);
@@ -1696,6 +1724,41 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
       const double t1 = SQR2I * s_sm[0], t2 = SQR6I * s_sm[1];
       stg(&s1[(0) * QS], t1 - t2 - pNew); stg(&s1[(1) * QS], -t1 - t2 - pNew); stg(&s1[(2) * QS], SQR2B3 * s_sm[1] - pNew);
       stg(&s1[(3) * QS], SQR2I * s_sm[4]); stg(&s1[(4) * QS], SQR2I * s_sm[3]); stg(&s1[(5) * QS], SQR2I * s_sm[2]);
+   };
+   // the same with every stash value read BEFORE the first row store (the rows of the wave's 64 points cover the stash slots of all its lanes)
+   auto write_state_staged = [&]() {
+      const double vNew = ECM_CD(CD_VNEW), vOld = ECM_CD(CD_VOLD), wrkOld = ECM_CD(CD_WRKOLD), shr0 = ECM_ST(st, ST_PB + PB_SHR0), flow0 = ECM_ST(st, ST_PB + PB_FLOW0);
+      const double a_V = E_SCALE * ECM_ST(st, ST_PB + PB_ESCI), hu = ECM_CD(CD_HU), deff = ECM_CD(CD_DEFF), wrkn = ECM_ST(st, ST_EPI_WRK);
+      double eNew = ECM_CD(CD_ENEW);
+      double ef[5], qo[4];
+      for (int i = 0; i < 5; i++) ef[i] = ECM_ST(st, ST_EPI_E + i);
+      qo[0] = ECM_ST(st, ST_EPI_Q0); qo[1] = ECM_ST(st, ST_EPI_Q0 + 1); qo[2] = ECM_ST(st, ST_EPI_Q2); qo[3] = ECM_ST(st, ST_EPI_Q3);
+      ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();
+      for (int i = 0; i < 4; i++) ost<true>(&sv1[(H_Q + i) * QS], qo[i]);
+      double Cq[9]; quat_to_mat(qo, Cq);      // = Cf: the rotation matrix is even in the quaternion
+      // (the products are pinned to registers: as single-use values they would be contracted into the rotation's multiply-adds, which the per-lane form -
+      //  where s_lat also feeds the tangent - does not do, and the staged form is held to the per-lane form's bits)
+      double sl[5]; for (int i = 0; i < 5; i++) { sl[i] = kdj[i] * ef[i]; asm volatile("" : "+v"(sl[i])); }
+      double s_sm[5]; rot_vecd(Cq, sl, s_sm);
+      eNew += 0.25 * (vOld + vNew) * dt * (wrkOld + wrkn);
+      if constexpr (!kin_is_km(KIN)) voce_slip_rates<kin_xn_ct(KIN), true>(mp, pb, ef, sv1 + H_GDOT * QS, dis_rate, shrate, detV_ri);
+      else {
+         if (ECM_KM_GDOT_GA && kin_base(KIN) == KIN_KMBALD_GA && kin_pq1(KIN) && mp.with_g_athermal) km_slip_rates_ga<kin_pq1(KIN), kin_sc_exp(KIN), true>(mp, pb, ef, sv1 + H_GDOT * QS);
+         else km_slip_rates<kin_pq1(KIN), kin_sc_exp(KIN), true>(mp, pb, ef, sv1 + H_GDOT * QS);
+      }
+      ost<true>(&sv1[(H_SHRATE) * QS], shrate);
+      ost<true>(&sv1[(H_SHR) * QS], shr0 + shrate * dt);
+      ost<true>(&sv1[(H_FLOW) * QS], ((deff > TINY_SQRT) ? dis_rate * dt : 0.0) + flow0);
+      ost<true>(&sv1[(H_NFEV) * QS], (double)nfev);
+      for (int i = 0; i < 5; i++) ost<true>(&sv1[(H_E + i) * QS], ef[i] * a_V);
+      ost<true>(&sv1[(H_H) * QS], hu);
+      ost<true>(&sv1[(IND_VOL) * QS], vNew); ost<true>(&sv1[(IND_EINT) * QS], eNew);
+      const double pNew = mp.bulk * (1.0 / vNew - 1.0) + mp.gamma * eNew;
+      const double t1 = SQR2I * s_sm[0], t2 = SQR6I * s_sm[1];
+      ost<true>(&s1[(0) * QS], t1 - t2 - pNew); ost<true>(&s1[(1) * QS], -t1 - t2 - pNew); ost<true>(&s1[(2) * QS], SQR2B3 * s_sm[1] - pNew);
+      ost<true>(&s1[(3) * QS], SQR2I * s_sm[4]); ost<true>(&s1[(4) * QS], SQR2I * s_sm[3]); ost<true>(&s1[(5) * QS], SQR2I * s_sm[2]);
+      ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();
+      io.flush_state();
    };
    if (!ECM_TANGENT_FIRST) write_state();
 #ifdef ECM_EXP_TAN_FAKE   // timing experiment: the 13 record stores without the tangent arithmetic
@@ -1884,8 +1947,15 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
          const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
          const double bk = (j < 3) ? bulkNew : 0.0;
          // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[(i + 6 j) * QS]
+         if constexpr (STG) {   // columns 0-2, then 3-5, through the lane's 18-double row of the stage (cmat = that row)
+            const int jj = j % 3;
+            cmat[0 + 6 * jj] = t1 - t2 + bk; cmat[1 + 6 * jj] = -t1 - t2 + bk; cmat[2 + 6 * jj] = SQR2B3 * T2[1] + bk;
+            cmat[3 + 6 * jj] = SQR2I * T2[4]; cmat[4 + 6 * jj] = SQR2I * T2[3]; cmat[5 + 6 * jj] = SQR2I * T2[2];
+            if (jj == 2) { ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier(); io.flush_tangent(j / 3); ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier(); }
+         } else {
          stg(&cmat[(0 + 6 * j) * QS], t1 - t2 + bk); stg(&cmat[(1 + 6 * j) * QS], -t1 - t2 + bk); stg(&cmat[(2 + 6 * j) * QS], SQR2B3 * T2[1] + bk);
          stg(&cmat[(3 + 6 * j) * QS], SQR2I * T2[4]); stg(&cmat[(4 + 6 * j) * QS], SQR2I * T2[3]); stg(&cmat[(5 + 6 * j) * QS], SQR2I * T2[2]);
+         }
       }
       }
    }
@@ -2024,12 +2094,20 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
          const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
          const double bk = (j < 3) ? bulkNew : 0.0;
          // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[(i + 6 j) * QS]
+         if constexpr (STG) {   // columns 0-2, then 3-5, through the lane's 18-double row of the stage (cmat = that row)
+            const int jj = j % 3;
+            cmat[0 + 6 * jj] = t1 - t2 + bk; cmat[1 + 6 * jj] = -t1 - t2 + bk; cmat[2 + 6 * jj] = SQR2B3 * T2[1] + bk;
+            cmat[3 + 6 * jj] = SQR2I * T2[4]; cmat[4 + 6 * jj] = SQR2I * T2[3]; cmat[5 + 6 * jj] = SQR2I * T2[2];
+            if (jj == 2) { ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier(); io.flush_tangent(j / 3); ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier(); }
+         } else {
          stg(&cmat[(0 + 6 * j) * QS], t1 - t2 + bk); stg(&cmat[(1 + 6 * j) * QS], -t1 - t2 + bk); stg(&cmat[(2 + 6 * j) * QS], SQR2B3 * T2[1] + bk);
          stg(&cmat[(3 + 6 * j) * QS], SQR2I * T2[4]); stg(&cmat[(4 + 6 * j) * QS], SQR2I * T2[3]); stg(&cmat[(5 + 6 * j) * QS], SQR2I * T2[2]);
+         }
       }
       }
    }
 #endif
+   if constexpr (STG) { write_state_staged(); return cut ? 2 : ((conv && ok) ? 0 : 1); }
    if (ECM_TANGENT_FIRST) write_state();
    return (conv && ok) ? 0 : 1;
 }

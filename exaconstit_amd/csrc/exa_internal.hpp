@@ -44,6 +44,7 @@ struct exa_ctx {
    bool ea_generic = false;
    bool ea_matfree = false, emat_valid = false;   // EA, p = 2: L-vector action computed from the point records, matrices assembled on demand
    bool qblk = false;                       // quadrature functions in the element-blocked layout (see QView below)
+   bool aos_stage = true;                   // AOS layout: constitutive launches move a wave's contiguous point rows coalesced and transpose them through LDS (exa_set_aos_staging)
    bool have_resid = false, have_grad = false;
    bool grad_records_only = false;          // gradient data = compact records written by the constitutive launch: no 46-double records, no element matrices
    // L-vector support

@@ -64,6 +64,8 @@ void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const
                  double* fuse_den_S = nullptr);
 void vk_min3(int64_t nn, const double* x, double* partial /*>= DOT_BLOCKS*/, double* out3, hipStream_t s);
 void vk_vgrad_velocity(int64_t nn, const uint8_t* m, const double* x, const double* org3_dev, const double* L9_host, double* v, hipStream_t s);
+void vk_qf_eb64_to_aos(int W, int Q, int64_t E, const double* src_eb64, double* dst_aos, hipStream_t s);   // (W, Q, E) <- [block][q][W][lane]
+void vk_max_abs_diff(int64_t n, const double* a, const double* b, double* out3_dev /* max |a-b|, max |a|, (u64) differing entries of the skipped component */, hipStream_t s, int W = 0, int skip = -1);
 void vk_pack(int64_t n, const int32_t* idx, const double* y, double* buf, hipStream_t s);
 void vk_unpack_add(int64_t n, const int32_t* idx, const double* buf, double* y, hipStream_t s);
 

@@ -449,6 +449,7 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    cfg.nelems = part.E; cfg.assembly = opt.assembly == Assembly::PA ? EXA_ASSEMBLY_PA : EXA_ASSEMBLY_EA; cfg.integ = bbar ? EXA_INTEG_BBAR : EXA_INTEG_FULL; cfg.device = -1;
    int err = 0; ctx_ = exa_create(&cfg, &err);
    if (!ctx_) throw std::runtime_error("exa_create failed (" + std::to_string(err) + ")");
+   this->props = props; cfg_used = cfg; cfg_used.props = nullptr;
    nn_ = part.NN; nd_ = 3 * nn_; E_ = part.E; npe_ = part.n;
    fast_p1_ = (part.p == 1 && !bbar);          // fused L-vector kernels exist for p = 1 full integration
    lvec_grad_ = fast_p1_ || opt.assembly == Assembly::EA || part.p == 2;   // p = 2: matrix-free action from the point records (PA and EA)

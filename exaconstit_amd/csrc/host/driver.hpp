@@ -132,6 +132,9 @@ class NonlinearMechOperator {
    Precond precond = Precond::IDENTITY;
    Timers timers;
    int model_calls = 0;
+   std::vector<double> props;     // material parameters the context was created with (the adapter-route bench creates a second, AOS context from them)
+   exa_config cfg_used;           // ... and its configuration (props pointer not valid after construction)
+   double dt() const { return dt_; }
    // quadrature points whose local (ExaCMech) solve did not converge in the last constitutive launch.  The library fails the run
    // in that case (ECMECH_FAIL in getResponseSngl); here a non-zero count poisons the next residual norm on every rank, so that
    // Newton reports non-convergence: Time.Auto then cuts dt, otherwise the run stops.

@@ -347,6 +347,108 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out, char* err, int e
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }
 
+// The drop-in route at the driver's current state: exactly the calls the MFEM adapters of include/exaconstit_mfem_adapters.hpp make
+// (HipExaModel::ModelSetup -> exa_model_setup on the reference's (vdim, Q, E) quadrature functions with a Jacobian field and a velocity
+// E-vector; HipExaNLFIntegrator::AssembleGradPA -> exa_grad_setup; AddMultGradPA -> exa_grad_apply on E-vectors between the element
+// restriction and its transpose, which MFEM's nonlinear form performs around it: spec reference src/mechanics_operator_ext.cpp:149-157),
+// on a second context in the AOS layout that is given this driver's begin-of-step state, coordinates and velocity.  `steps` timed
+// constitutive launches, `iters` timed gradient actions; results compared with what the driver's own route produced from the same state.
+//   out[0]  ms per exa_model_setup launch                     out[1]  ms per pass = velocity L->E + exa_model_setup
+//   out[2]  ms of coordinates L->E + exa_jacobians            out[3]  ms per exa_grad_setup
+//   out[4]  ms per exa_grad_apply (E-vector kernel alone)     out[5]  ms per action = L->E + exa_grad_apply + E->L
+//   out[6]  max |stress1 - driver's| / max |stress1|          out[7]  max |state1 - driver's| / max |state1|
+//   out[8]  max |K x - driver's K x| / max |K x|              out[9]  non-converged points
+//   out[10] ms per launch of the driver's own route at this state (same loop)      out[11] ms of the driver's own gradient action
+//   out[12] AOS staging through LDS in effect (1 / 0)         out[13] points whose evaluation count (state slot 3, left out of out[7]) differs
+int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* out, char* err, int errlen) {
+   try {
+      SystemDriver& sd = *d->sd; NonlinearMechOperator& op = sd.oper();
+      if (sd.part.p != 1 || sd.comm.nranks != 1) throw std::runtime_error("exa_driver_bench_adapter_route: one rank, p = 1");
+      hipStream_t s = op.stream(); const int nd = op.Height(); const int nn = nd / 3;
+      const int64_t E = sd.part.E; const int Q = 8; const int64_t P = E * Q;
+      for (int i = 0; i < 16; i++) out[i] = 0.0;
+      // the driver's own residual evaluation + gradient data at this state: the outputs the adapter route is compared with
+      DevBuf<double> r(nd), yC(nd), yA(nd);
+      op.Mult(sd.v_sol.p, r.p);
+      op.GetGradient();
+      exa_ctx* ctxC = op.GetModel()->ctx();
+      const bool blocked = exa_get_quadrature_layout(ctxC) == EXA_QLAYOUT_EB64;
+      auto timed = [&](int n, auto&& body) {
+         hipEvent_t e0, e1; EXA_HC(hipEventCreate(&e0)); EXA_HC(hipEventCreate(&e1));
+         EXA_HC(hipEventRecord(e0, s));
+         for (int i = 0; i < n; i++) body();
+         EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));
+         float ms = 0; EXA_HC(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+         return (double)ms / (n > 0 ? n : 1);
+      };
+      {  ProfRegion prof("adapter_route_reference_launches");
+         op.Setup<true>(sd.v_sol.p);
+         out[10] = timed(steps, [&] { op.Setup<true>(sd.v_sol.p); });
+         op.FlushModelTimers();
+         EXA_HC(hipMemsetAsync(yC.p, 0, sizeof(double) * nd, s));
+         out[11] = timed(iters, [&] { if (exa_grad_apply_lvec(ctxC, r.p, yC.p, nullptr, s) != EXA_OK) throw std::runtime_error(exa_last_error(ctxC)); });
+         EXA_HC(hipMemsetAsync(yC.p, 0, sizeof(double) * nd, s));
+         if (exa_grad_apply_lvec(ctxC, r.p, yC.p, nullptr, s) != EXA_OK) throw std::runtime_error(exa_last_error(ctxC));
+      }
+      // second context: the reference's quadrature-function layout, E-vector entry points
+      exa_config cfg = op.cfg_used; cfg.props = op.props.data(); cfg.nprops = (int)op.props.size(); cfg.assembly = EXA_ASSEMBLY_PA; cfg.integ = EXA_INTEG_FULL;
+      int ec = 0; exa_ctx* ctxA = exa_create(&cfg, &ec);
+      if (!ctxA) throw std::runtime_error("exa_driver_bench_adapter_route: exa_create failed");
+      struct Guard { exa_ctx* c; ~Guard() { exa_destroy(c); } } guard{ ctxA };
+      auto chk = [&](int rc, const char* what) { if (rc < 0) throw std::runtime_error(std::string(what) + ": " + exa_last_error(ctxA)); };
+      chk(exa_set_connectivity(ctxA, op.conn.p, nn), "exa_set_connectivity");
+      DevBuf<double> sv0((size_t)28 * P), s0((size_t)6 * P), sv1((size_t)28 * P), s1((size_t)6 * P), cm((size_t)36 * P), J((size_t)9 * P), tmp((size_t)28 * P);
+      DevBuf<double> elx((size_t)24 * E), elv((size_t)24 * E), ely((size_t)24 * E), sc(3);
+      auto to_aos = [&](int W, const DevBuf<double>& src, DevBuf<double>& dst) {
+         if (blocked) vk_qf_eb64_to_aos(W, Q, E, src.p, dst.p, s);
+         else EXA_HC(hipMemcpyAsync(dst.p, src.p, sizeof(double) * W * P, hipMemcpyDeviceToDevice, s));
+      };
+      to_aos(28, op.matVars0, sv0); to_aos(6, op.stress0, s0);
+      const double dt = op.dt();
+      // geometric factors of the end-of-step configuration (MFEM: GetGeometricFactors + the re-layout of exa_jacobians_from_geom)
+      out[2] = timed(2, [&] { chk(exa_restrict(ctxA, op.x_cur.p, elx.p, s), "exa_restrict"); chk(exa_jacobians(ctxA, elx.p, J.p, s), "exa_jacobians"); });
+      chk(exa_restrict(ctxA, sd.v_sol.p, elv.p, s), "exa_restrict");
+      auto model = [&] { chk(exa_model_setup(ctxA, dt, J.p, elv.p, s0.p, sv0.p, s1.p, sv1.p, cm.p, s), "exa_model_setup"); };
+      model(); model();
+      {  ProfRegion prof(("adapter_route_model[passes=" + std::to_string(steps) + "]").c_str());
+         out[0] = timed(steps, model); }
+      out[1] = timed(steps, [&] { chk(exa_restrict(ctxA, sd.v_sol.p, elv.p, s), "exa_restrict"); model(); });
+      out[9] = (double)exa_model_status(ctxA, s);
+      out[12] = (double)exa_get_aos_staging(ctxA);
+      unsigned long long differing = 0;
+      auto rel_diff = [&](int64_t n, const double* a, const double* b, int W = 0, int skip = -1) {
+         vk_max_abs_diff(n, a, b, sc.p, s, W, skip);
+         double h[3]; EXA_HC(hipMemcpyAsync(h, sc.p, sizeof(h), hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+         std::memcpy(&differing, &h[2], sizeof(differing));
+         return h[1] > 0.0 ? h[0] / h[1] : h[0];
+      };
+      to_aos(6, op.stress1, tmp); out[6] = rel_diff(6 * P, s1.p, tmp.p);
+      to_aos(28, op.matVars1, tmp); out[7] = rel_diff(28 * P, sv1.p, tmp.p, 28, 3); out[13] = (double)differing;   // slot 3 = the local solver's evaluation count
+      // AssembleGradPA
+      chk(exa_grad_setup(ctxA, dt, J.p, cm.p, s), "exa_grad_setup");
+      {  ProfRegion prof("adapter_route_grad_setup");
+         out[3] = timed(3, [&] { chk(exa_grad_setup(ctxA, dt, J.p, cm.p, s), "exa_grad_setup"); }); }
+      // AddMultGradPA between the element restriction and its transpose
+      chk(exa_restrict(ctxA, r.p, elx.p, s), "exa_restrict");
+      ely.zero(s);
+      chk(exa_grad_apply(ctxA, elx.p, ely.p, s), "exa_grad_apply");
+      {  ProfRegion prof(("adapter_route_grad_apply[iters=" + std::to_string(iters) + "]").c_str());
+         out[4] = timed(iters, [&] { chk(exa_grad_apply(ctxA, elx.p, ely.p, s), "exa_grad_apply"); }); }
+      auto action = [&] {
+         chk(exa_restrict(ctxA, r.p, elx.p, s), "exa_restrict");
+         ely.zero(s);
+         chk(exa_grad_apply(ctxA, elx.p, ely.p, s), "exa_grad_apply");
+         chk(exa_restrict_transpose_add(ctxA, ely.p, yA.p, s), "exa_restrict_transpose_add");
+      };
+      {  ProfRegion prof(("adapter_route_action[iters=" + std::to_string(iters) + "]").c_str());
+         out[5] = timed(iters, action); }
+      EXA_HC(hipMemsetAsync(yA.p, 0, sizeof(double) * nd, s));
+      action();
+      out[8] = rel_diff(nd, yA.p, yC.p);
+      return 0;
+   } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
+}
+
 int exa_choose_newton_cap(const int* hist64, double tail_cost) { return choose_newton_cap(hist64, tail_cost); }
 int exa_choose_newton_caps(const int* hist64, double tail_cost, int* k1, int* k2) { if (!hist64 || !k1 || !k2) return -1; choose_newton_caps_resume(hist64, tail_cost, *k1, *k2); return 0; }
 

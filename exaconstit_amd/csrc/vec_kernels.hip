@@ -307,6 +307,28 @@ __global__ void k_vgrad_velocity(int64_t nn, const uint8_t* __restrict__ m, cons
    for (int i = 0; i < 3; i++) if (m[g + nn * i]) v[g + nn * i] = L.a[3 * i] * d0 + L.a[3 * i + 1] * d1 + L.a[3 * i + 2] * d2;
 }
 
+// quadrature function in the element-blocked layout [block of 64 elements][q][W][lane] -> the reference's (W, Q, E) layout (bench / parity tooling of
+// the adapter route: host/driver_capi.hip, exa_driver_bench_adapter_route)
+__global__ void k_qf_eb64_to_aos(const int W, const int Q, const int64_t n, const double* __restrict__ src, double* __restrict__ dst) {
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const int c = (int)(i % W); const int64_t pt = i / W; const int q = (int)(pt % Q); const int64_t e = pt / Q;
+      dst[i] = src[((((e >> 6) * Q + q) * (int64_t)W + c) << 6) + (e & 63)];
+   }
+}
+// out[0] = max |a - b|, out[1] = max |a| (bit patterns of non-negative doubles order like the numbers; out zeroed by the launcher); a NaN on either side -> out[0] = +inf.
+// W > 0: the arrays hold W-vectors and component `skip` is left out of the two maxima; out[2] counts its entries that differ (the evaluation counter of a state array)
+__global__ void k_max_abs_diff(const int64_t n, const double* __restrict__ a, const double* __restrict__ b, unsigned long long* __restrict__ out, const int W, const int skip) {
+   double d = 0.0, m = 0.0; unsigned long long cnt = 0;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const double x = a[i], y = b[i]; const double t = fabs(x - y);
+      if (W > 0 && (int)(i % W) == skip) { cnt += (x != y) ? 1ull : 0ull; continue; }
+      d = (t == t) ? fmax(d, t) : __longlong_as_double(0x7ff0000000000000ll); m = fmax(m, fabs(x));
+   }
+   for (int o = 32; o > 0; o >>= 1) { d = fmax(d, __shfl_xor(d, o)); m = fmax(m, __shfl_xor(m, o)); }
+   if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], (unsigned long long)__double_as_longlong(d)); atomicMax(&out[1], (unsigned long long)__double_as_longlong(m)); }
+   if (cnt) atomicAdd(&out[2], cnt);
+}
+
 inline unsigned gblk(int64_t n) { const int64_t b = (n + RBLK - 1) / RBLK; return (unsigned)(b < exa_host::DOT_BLOCKS ? (b > 0 ? b : 1) : exa_host::DOT_BLOCKS); }
 
 }  // namespace
@@ -381,6 +403,14 @@ void vk_cg2_dots(int64_t n, int64_t nn, const double* w, const uint8_t* m, const
    hipLaunchKernelGGL(k_reduce2, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out2);
 }
 void vk_cg_step2(int64_t n, const double* S, const double* z, double* d, hipStream_t s) { hipLaunchKernelGGL(k_cg_step2, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, d); }
+void vk_qf_eb64_to_aos(int W, int Q, int64_t E, const double* src, double* dst, hipStream_t s) {
+   const int64_t n = (int64_t)W * Q * E;
+   hipLaunchKernelGGL(k_qf_eb64_to_aos, dim3(gblk(n) * 8), dim3(RBLK), 0, s, W, Q, n, src, dst);
+}
+void vk_max_abs_diff(int64_t n, const double* a, const double* b, double* out3_dev, hipStream_t s, int W, int skip) {
+   (void)hipMemsetAsync(out3_dev, 0, 3 * sizeof(double), s);
+   hipLaunchKernelGGL(k_max_abs_diff, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, a, b, reinterpret_cast<unsigned long long*>(out3_dev), W, skip);
+}
 void vk_pack(int64_t n, const int32_t* idx, const double* y, double* buf, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_pack, dim3(nblk(n)), dim3(256), 0, s, n, idx, y, buf); }
 void vk_unpack_add(int64_t n, const int32_t* idx, const double* buf, double* y, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_unpack_add, dim3(nblk(n)), dim3(256), 0, s, n, idx, buf, y); }
 

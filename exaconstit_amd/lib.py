@@ -55,6 +55,8 @@ exa_qpts_per_elem = _sig("exa_qpts_per_elem", C.c_int, C.c_void_p)
 exa_shape_table = _sig("exa_shape_table", C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 exa_set_quadrature_layout = _sig("exa_set_quadrature_layout", C.c_int, C.c_void_p, C.c_int)
 exa_get_quadrature_layout = _sig("exa_get_quadrature_layout", C.c_int, C.c_void_p)
+exa_set_aos_staging = _sig("exa_set_aos_staging", C.c_int, C.c_void_p, C.c_int)
+exa_get_aos_staging = _sig("exa_get_aos_staging", C.c_int, C.c_void_p)
 exa_qf_size = _sig("exa_qf_size", C.c_int64, C.c_void_p, C.c_int)
 EXA_QLAYOUT_AOS, EXA_QLAYOUT_EB64 = 0, 1
 EXA_OK, EXA_ERR_ARG, EXA_ERR_HIP, EXA_ERR_STATE, EXA_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
@@ -184,6 +186,7 @@ exa_bootstrap = _sig("exa_bootstrap", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c
 exa_driver_get_pcg_reduction = _sig("exa_driver_get_pcg_reduction", None, C.c_void_p, C.POINTER(C.c_double))
 exa_driver_bench_prepare = _sig("exa_driver_bench_prepare", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_char_p, C.c_int)
 exa_driver_bench_model = _sig("exa_driver_bench_model", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
+exa_driver_bench_adapter_route = _sig("exa_driver_bench_adapter_route", C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_driver_bench_pcg = _sig("exa_driver_bench_pcg", C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int)
 exa_choose_newton_cap = _sig("exa_choose_newton_cap", C.c_int, C.POINTER(C.c_int), C.c_double)
 exa_choose_newton_caps = _sig("exa_choose_newton_caps", C.c_int, C.POINTER(C.c_int), C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int))
@@ -313,6 +316,14 @@ class Driver:
         o = np.zeros(3)
         self._chk(exa_driver_bench_model(self.h, steps, o.ctypes.data_as(C.POINTER(C.c_double)), self._err, 512))
         return dict(loop_ms=o[0], kernel_ms=o[1], failed=int(o[2]))
+
+    def bench_adapter_route(self, steps, iters):
+        """The calls the MFEM adapters make (AOS exa_model_setup, exa_grad_setup, E-vector exa_grad_apply between L->E and E->L) at this driver's state."""
+        import numpy as np
+        o = np.zeros(16)
+        self._chk(exa_driver_bench_adapter_route(self.h, steps, iters, o.ctypes.data_as(C.POINTER(C.c_double)), self._err, 512))
+        return dict(model_ms=o[0], pass_ms=o[1], geometry_ms=o[2], grad_setup_ms=o[3], grad_apply_ms=o[4], action_ms=o[5], stress_rel_diff=o[6], state_rel_diff=o[7],
+                    action_rel_diff=o[8], failed=int(o[9]), driver_route_model_ms=o[10], driver_route_apply_ms=o[11], aos_staging=bool(o[12]), nfev_differing=int(o[13]))
 
     def bench_pcg(self, iters):
         import numpy as np

@@ -103,6 +103,9 @@ int exa_driver_get_qf_component(exa_driver* d, int which, int comp, double* out,
 int exa_driver_bench_prepare(exa_driver* d, int nsteps, const double* dts, double perturb, char* err, int errlen);
 int exa_driver_bench_model(exa_driver* d, int steps, double* out3, char* err, int errlen);
 int exa_driver_bench_pcg(exa_driver* d, int iters, double* out3, char* err, int errlen);
+/* the drop-in route (the calls of include/exaconstit_mfem_adapters.hpp: AOS exa_model_setup, exa_grad_setup, E-vector exa_grad_apply between the element
+ * restriction and its transpose) timed on a second context that is given this driver's state; out16 documented at the definition (host/driver_capi.hip) */
+int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* out16, char* err, int errlen);
 
 /* host-logic queries that need no GPU (used by the CPU tests) ------------------------------------------------------------ */
 /* options.toml reader (reference src/option_parser.cpp:26-932): fills out[0..19] =

@@ -87,6 +87,14 @@ int exa_shape_table(const exa_ctx* ctx, double* G_host /*(n,3,Q)*/, double* W_ho
  *                    the L-vector entry points only (exa_residual_setup / exa_residual_apply stay AOS).  An MFEM adapter keeps AOS. */
 enum { EXA_QLAYOUT_AOS = 0, EXA_QLAYOUT_EB64 = 1 };
 int exa_set_quadrature_layout(exa_ctx* ctx, int layout);
+/* EXA_QLAYOUT_AOS, constitutive launches (exa_model_setup, exa_model_setup_lvec): the 64 points of a wave are 64 x 28 / 6 / 9 / 36 CONTIGUOUS doubles of
+ * the state / stress / Jacobian / tangent arrays, so the wave moves them with coalesced 16-byte accesses and transposes them through the per-lane LDS
+ * stash the kernel owns anyway (inputs once, outputs in three rounds: two tangent halves, then state + stress) instead of 8-byte accesses at a
+ * 224 / 288-byte lane stride - the reference's layout at the element-blocked layout's speed, same bits out.  On by default; 0 restores the
+ * per-lane strided accesses (A/B runs).  exa_get_aos_staging: the setting (the staged kernels exist for every order and model; the dense
+ * launches of a tail split keep strided accesses - their lanes are scattered points). */
+int exa_set_aos_staging(exa_ctx* ctx, int on);
+int exa_get_aos_staging(const exa_ctx* ctx);
 int exa_get_quadrature_layout(const exa_ctx* ctx);               /* EXA_QLAYOUT_* currently selected */
 int64_t exa_qf_size(const exa_ctx* ctx, int vdim);
 
