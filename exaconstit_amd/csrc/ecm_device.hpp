@@ -710,8 +710,9 @@ constexpr int ST_NCD = ST_PB - ST_CD;
 // tangent waits in slots that are dead by then - the tail of the restore copy of x, the begin-of-step quaternion (read), the record scale (REC only), 1/sc
 // (Newton loop only), the bulk modulus (read) - instead of in registers across the tangent arithmetic (the allocator spilled 13 of them to scratch, and a
 // scratch reload behind the row stores waits for the store queue of the wave)
-constexpr int ST_EPI_E = ST_XS + 5, ST_EPI_Q0 = ST_EPI_E + 5, ST_EPI_Q2 = 31, ST_EPI_Q3 = 33, ST_EPI_WRK = 29;
-static_assert(ST_EPI_E == 18 && ST_EPI_Q0 + 1 == ST_CD + 3 && ST_EPI_E + 4 < ST_EPI_Q0, "epilogue parking slots: rows of the tangent halves end at slot 17; e_f in 18..22 (x tail, q_n[0..1])");
+// (1/detV is in a register by then as well.  Slot 18 stays free: padded tangent rows - 19 doubles, bank-conflict free - reach into it)
+constexpr int ST_EPI_E = ST_XS + 6, ST_EPI_Q0 = ST_EPI_E + 5, ST_EPI_Q1 = 31, ST_EPI_Q2 = 33, ST_EPI_Q3 = 35, ST_EPI_WRK = 29;
+static_assert(ST_EPI_E == 19 && ST_EPI_Q0 == ST_CD + 3, "epilogue parking slots: rows of the tangent halves end in slot 18; e_f in 19..23 (x tail, q_n[0..2]), q[0] in 24 (q_n[3])");
 // (the deviatoric stress work of the step needs D' and the old stress only through  sum (s_old + s_new) . D' = s_old . D' + s_lat . d_lat:
 //  the first scalar is parked, the second uses the lattice-frame D' of the converged evaluation - 10 slots fewer than parking both vectors)
 constexpr int CD_QN = 0, CD_VOLD = 4, CD_VNEW = 5, CD_ENEW = 6, CD_DEFF = 7, CD_BULK = 8, CD_HU = 9, CD_TSC = 10, CD_WRKOLD = 11;
@@ -1434,8 +1435,23 @@ ECM_DI void load_point_in(const double* __restrict__ sv0, const double* __restri
    for (int i = 0; i < 6; i++) p.s[i] = ld(&s0[i * QS]);
 }
 
+// Tangent output of the staged AOS launch: two rounds of 32 whole rows.  The rows of 32 points are 9 216 contiguous bytes of memory - 72 whole 128-byte
+// lines, each written by one wave in one round (rounds of 3 columns of all 64 rows, 144-byte pieces, left every line to be completed a microsecond later:
+// 4.96 against 4.80 ms at 128^3 depending on how long L2 kept the first piece).  Lanes 0-31 put their 36 entries into the stage (cmat = the lane's row there),
+// the wave stores them, then lanes 32-63; emit(put) produces the 36 entries from values both rounds keep in registers.
+template <class IO, class Emit>
+ECM_DI void staged_tangent(const IO& io, double* cmat, Emit&& emit) {
+#pragma unroll
+   for (int h = 0; h < 2; h++) {
+      if (io.half() == h) emit([&](const int i, const double v) { cmat[i] = v; });
+      ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();
+      io.flush_tangent(h);
+      ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();
+   }
+}
+
 // STG (staged AOS launch): the outputs go to the lane's rows of the wave's LDS stage - which is the wave's stash region - and the wave stores them
-// coalesced in three rounds (io.flush_tangent(0 | 1), io.flush_state()): every lane must stay in the wave until the last round (a point that is cut off by the
+// coalesced in three rounds (staged_tangent: io.flush_tangent(0 | 1); io.flush_state()): every lane must stay in the wave until the last round (a point that is cut off by the
 // tail split only marks itself), and nothing may be read from the stash once the first row of a round has been written.
 template <int KIN, int QS, bool REC = false, bool STG = false, class IO>
 ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io, const int kcap, const PointIn& pin,
@@ -1695,9 +1711,9 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
    double wrk_new = 0.0;   // s_new . D' in the lattice frame of the converged evaluation (the inner product of the 5-vectors is frame-invariant)
    for (int k = 0; k < 5; k++) wrk_new += s_lat[k] * J.dl[k];
    if constexpr (STG) {   // see ST_EPI_*
-      static_assert(ST_EPI_Q2 == ST_CD + CD_TSC && ST_EPI_Q3 == ST_PB + PB_SCI && ST_EPI_WRK == ST_CD + CD_BULK && !REC, "dead slots");
+      static_assert(ST_EPI_Q1 == ST_CD + CD_TSC && ST_EPI_Q2 == ST_PB + PB_SCI && ST_EPI_Q3 == ST_PB + PB_DETVRI && ST_EPI_WRK == ST_CD + CD_BULK && !REC, "dead slots");
       for (int i = 0; i < 5; i++) ECM_ST(st, ST_EPI_E + i) = e_f[i];
-      ECM_ST(st, ST_EPI_Q0) = qout[0]; ECM_ST(st, ST_EPI_Q0 + 1) = qout[1]; ECM_ST(st, ST_EPI_Q2) = qout[2]; ECM_ST(st, ST_EPI_Q3) = qout[3];
+      ECM_ST(st, ST_EPI_Q0) = qout[0]; ECM_ST(st, ST_EPI_Q1) = qout[1]; ECM_ST(st, ST_EPI_Q2) = qout[2]; ECM_ST(st, ST_EPI_Q3) = qout[3];
       ECM_ST(st, ST_EPI_WRK) = wrk_new;
       ECM_PARK_BARRIER();
    }
@@ -1732,7 +1748,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
       double eNew = ECM_CD(CD_ENEW);
       double ef[5], qo[4];
       for (int i = 0; i < 5; i++) ef[i] = ECM_ST(st, ST_EPI_E + i);
-      qo[0] = ECM_ST(st, ST_EPI_Q0); qo[1] = ECM_ST(st, ST_EPI_Q0 + 1); qo[2] = ECM_ST(st, ST_EPI_Q2); qo[3] = ECM_ST(st, ST_EPI_Q3);
+      qo[0] = ECM_ST(st, ST_EPI_Q0); qo[1] = ECM_ST(st, ST_EPI_Q1); qo[2] = ECM_ST(st, ST_EPI_Q2); qo[3] = ECM_ST(st, ST_EPI_Q3);
       ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();
       for (int i = 0; i < 4; i++) ost<true>(&sv1[(H_Q + i) * QS], qo[i]);
       double Cq[9]; quat_to_mat(qo, Cq);      // = Cf: the rotation matrix is even in the quaternion
@@ -1939,24 +1955,21 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
          T2a[k][4] = (SQR2I * D[3]) * dti;
          T2a[k][5] = (SQR2I * D[2]) * dti;
       }
+      // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[(i + 6 j) * QS]
+      auto emit = [&](auto&& put) {
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-         double T2[5];
+         for (int j = 0; j < 6; j++) {
+            double T2[5];
 #pragma unroll
-         for (int k = 0; k < 5; k++) T2[k] = T2a[k][j];
-         const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
-         const double bk = (j < 3) ? bulkNew : 0.0;
-         // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[(i + 6 j) * QS]
-         if constexpr (STG) {   // columns 0-2, then 3-5, through the lane's 18-double row of the stage (cmat = that row)
-            const int jj = j % 3;
-            cmat[0 + 6 * jj] = t1 - t2 + bk; cmat[1 + 6 * jj] = -t1 - t2 + bk; cmat[2 + 6 * jj] = SQR2B3 * T2[1] + bk;
-            cmat[3 + 6 * jj] = SQR2I * T2[4]; cmat[4 + 6 * jj] = SQR2I * T2[3]; cmat[5 + 6 * jj] = SQR2I * T2[2];
-            if (jj == 2) { ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier(); io.flush_tangent(j / 3); ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier(); }
-         } else {
-         stg(&cmat[(0 + 6 * j) * QS], t1 - t2 + bk); stg(&cmat[(1 + 6 * j) * QS], -t1 - t2 + bk); stg(&cmat[(2 + 6 * j) * QS], SQR2B3 * T2[1] + bk);
-         stg(&cmat[(3 + 6 * j) * QS], SQR2I * T2[4]); stg(&cmat[(4 + 6 * j) * QS], SQR2I * T2[3]); stg(&cmat[(5 + 6 * j) * QS], SQR2I * T2[2]);
+            for (int k = 0; k < 5; k++) T2[k] = T2a[k][j];
+            const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
+            const double bk = (j < 3) ? bulkNew : 0.0;
+            put(0 + 6 * j, t1 - t2 + bk); put(1 + 6 * j, -t1 - t2 + bk); put(2 + 6 * j, SQR2B3 * T2[1] + bk);
+            put(3 + 6 * j, SQR2I * T2[4]); put(4 + 6 * j, SQR2I * T2[3]); put(5 + 6 * j, SQR2I * T2[2]);
          }
-      }
+      };
+      if constexpr (STG) staged_tangent(io, cmat, emit);
+      else emit([&](const int i, const double v) { stg(&cmat[i * QS], v); });
       }
    }
    else
@@ -2086,24 +2099,21 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
          T1[k][4] = (SQR2I * D[3]) * dti;
          Llat[k][0] = (SQR2I * D[2]) * dti;   // sixth column parked in Llat's first column
       }
+      // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[(i + 6 j) * QS]
+      auto emit = [&](auto&& put) {
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-         double T2[5];
+         for (int j = 0; j < 6; j++) {
+            double T2[5];
 #pragma unroll
-         for (int k = 0; k < 5; k++) T2[k] = (j < 5) ? T1[k][j] : Llat[k][0];
-         const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
-         const double bk = (j < 3) ? bulkNew : 0.0;
-         // sigma_svec = V65 sigma_vecd; column-major C(i,j) at cmat[(i + 6 j) * QS]
-         if constexpr (STG) {   // columns 0-2, then 3-5, through the lane's 18-double row of the stage (cmat = that row)
-            const int jj = j % 3;
-            cmat[0 + 6 * jj] = t1 - t2 + bk; cmat[1 + 6 * jj] = -t1 - t2 + bk; cmat[2 + 6 * jj] = SQR2B3 * T2[1] + bk;
-            cmat[3 + 6 * jj] = SQR2I * T2[4]; cmat[4 + 6 * jj] = SQR2I * T2[3]; cmat[5 + 6 * jj] = SQR2I * T2[2];
-            if (jj == 2) { ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier(); io.flush_tangent(j / 3); ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier(); }
-         } else {
-         stg(&cmat[(0 + 6 * j) * QS], t1 - t2 + bk); stg(&cmat[(1 + 6 * j) * QS], -t1 - t2 + bk); stg(&cmat[(2 + 6 * j) * QS], SQR2B3 * T2[1] + bk);
-         stg(&cmat[(3 + 6 * j) * QS], SQR2I * T2[4]); stg(&cmat[(4 + 6 * j) * QS], SQR2I * T2[3]); stg(&cmat[(5 + 6 * j) * QS], SQR2I * T2[2]);
+            for (int k = 0; k < 5; k++) T2[k] = (j < 5) ? T1[k][j] : Llat[k][0];
+            const double t1 = SQR2I * T2[0], t2 = SQR6I * T2[1];
+            const double bk = (j < 3) ? bulkNew : 0.0;
+            put(0 + 6 * j, t1 - t2 + bk); put(1 + 6 * j, -t1 - t2 + bk); put(2 + 6 * j, SQR2B3 * T2[1] + bk);
+            put(3 + 6 * j, SQR2I * T2[4]); put(4 + 6 * j, SQR2I * T2[3]); put(5 + 6 * j, SQR2I * T2[2]);
          }
-      }
+      };
+      if constexpr (STG) staged_tangent(io, cmat, emit);
+      else emit([&](const int i, const double v) { stg(&cmat[i * QS], v); });
       }
    }
 #endif

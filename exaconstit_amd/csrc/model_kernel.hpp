@@ -17,6 +17,31 @@ using namespace ecmdev;
 static_assert(EXA_MODEL_BS % ECM_STASH_STRIDE == 0 && ECM_STASH_STRIDE % 64 == 0, "a block is a whole number of stash regions, a region a whole number of waves");
 constexpr int EXA_STASH_DOUBLES = ecmdev::ST_SLOTS * EXA_MODEL_BS;   // LDS stash of a block
 
+#ifndef EXA_STG_NT_LD
+#define EXA_STG_NT_LD 1   // row pieces of the staged launch: non-temporal loads / stores like the per-lane accesses of the other launches (A/B switches)
+#endif
+#ifndef EXA_STG_NT_ST
+#define EXA_STG_NT_ST 1   // (every round stores whole 128-byte lines: with the tangent in 144-byte pieces - rounds of 3 columns - plain stores were the faster ones)
+#endif
+__device__ __forceinline__ double2 ldg2(const double* p) {
+#if EXA_STG_NT_LD
+   typedef double vd2 __attribute__((ext_vector_type(2)));
+   const vd2 v = __builtin_nontemporal_load(reinterpret_cast<const vd2*>(p));
+   return make_double2(v.x, v.y);
+#else
+   return *reinterpret_cast<const double2*>(p);
+#endif
+}
+// Row strides (doubles) in the stage: the rows lie there as in memory.  (Measured: rows one double apart - odd strides 29 / 7, no LDS bank conflicts of the lanes'
+// 8-byte row accesses, two 8-byte LDS accesses per 16-byte piece - are slower, 4.87 against 4.83 ms at 128^3: the row accesses are not what the launch waits for.)
+constexpr int RS_SV = ecmdev::NSTATEV, RS_S = 6, RS_T = 36;
+__device__ __forceinline__ void stg2r(double* p, const double a, const double b) {
+#if EXA_STG_NT_ST
+   ecmdev::stg2(reinterpret_cast<double2*>(p), a, b);
+#else
+   *reinterpret_cast<double2*>(p) = make_double2(a, b);
+#endif
+}
 // Where one thread's quadrature point lives.  Everything is a function of (block index, thread index) and kernel-uniform data, so nothing
 // per-lane has to survive the local Newton solve: locate() derives the point from the thread index, refresh() does it again behind a compiler
 // barrier after the solve, and the accessors form the addresses where they are used.  Before, five 64-bit row pointers and two LDS addresses
@@ -52,53 +77,54 @@ struct PointIO {
    __device__ __forceinline__ double* wreg() const { return stash0 + wave() * (ecmdev::ST_SLOTS * 64); }
    __device__ __forceinline__ int row_in() const { return (int)(e * Q + q - pt0()); }
    // one round of coalesced row stores: n doubles of the stage at lds -> g (16-byte aligned), 16 bytes per lane and pass
-   __device__ __forceinline__ void flush_rows(const double* lds, double* g, const int n, const int total) const {
+   // (rows of W doubles RS apart in the stage; RS == W: the stage holds them as they lie in memory)
+   template <int W, int RS, int NROWS = 64>
+   __device__ __forceinline__ void flush_rows(const double* lds, double* g, const int n) const {
       const int lane = tid & 63;
 #pragma unroll
-      for (int m = 0; m < (total / 2 + 63) / 64; m++) {
+      for (int m = 0; m < (NROWS * W / 2 + 63) / 64; m++) {
          const int u = m * 64 + lane;
-         if (2 * u + 1 < n) ecmdev::stg2(reinterpret_cast<double2*>(g + 2 * u), lds[2 * u], lds[2 * u + 1]);
-         else if (2 * u < n) ecmdev::stg(g + 2 * u, lds[2 * u]);      // (odd row counts: Jacobian rows of a wave that ends the array at an odd-order element)
+         const int i0 = (RS == W) ? 2 * u : ((2 * u) / W) * RS + (2 * u) % W;      // (W even when RS != W: both doubles of a piece lie in one row)
+         if (2 * u + 1 < n) stg2r(g + 2 * u, lds[i0], lds[i0 + 1]);
+         else if (2 * u < n) ecmdev::stg(g + 2 * u, lds[i0]);      // (odd row counts: Jacobian rows of a wave that ends the array at an odd-order element)
       }
    }
-   // columns 3 h ... 3 h + 2 of the 64 tangents: rows of 18 doubles in the stage, 144-byte pieces of the points' 288-byte tangent rows in memory
+   // the 36-double tangent rows of points 32 h ... 32 h + 31 of the wave (staged_tangent, ecm_device.hpp): 9 216 contiguous bytes
+   __device__ __forceinline__ int half() const { return (tid >> 5) & 1; }
    __device__ __forceinline__ void flush_tangent(const int h) const {
-      if (tail_mode) {   // (uniform) this lane's 18 doubles to its own point
-         const double* row = wreg() + (tid & 63) * 18; double* g = cmat + (e * Q + q) * 36 + h * 18;
+      if (tail_mode) {   // (uniform) this lane's row to its own point
+         if (half() != h) return;
+         const double* row = wreg() + (tid & 31) * RS_T; double* g = cmat + (e * Q + q) * 36;
 #pragma unroll
-         for (int c = 0; c < 9; c++) ecmdev::stg2(reinterpret_cast<double2*>(g + 2 * c), row[2 * c], row[2 * c + 1]);
+         for (int c = 0; c < 18; c++) stg2r(g + 2 * c, row[2 * c], row[2 * c + 1]);
          return;
       }
-      const int lane = tid & 63; const int nv = nvalid(); const double* lds = wreg(); double* g = cmat + pt0() * 36 + h * 18;
-#pragma unroll
-      for (int m = 0; m < 9; m++) {
-         const int u = m * 64 + lane, k = u / 9, part = u - 9 * k;
-         if (k < nv) ecmdev::stg2(reinterpret_cast<double2*>(g + k * 36 + 2 * part), lds[2 * u], lds[2 * u + 1]);
-      }
+      const int nv = nvalid() - 32 * h;
+      if (nv > 0) flush_rows<36, 36, 32>(wreg(), cmat + (pt0() + 32 * h) * 36, (nv < 32 ? nv : 32) * 36);
    }
    __device__ __forceinline__ void flush_state() const {
       if (tail_mode) {
-         const double* row = wreg() + (tid & 63) * ecmdev::NSTATEV; double* g = state1 + (e * Q + q) * ecmdev::NSTATEV;
+         const double* row = wreg() + (tid & 63) * RS_SV; double* g = state1 + (e * Q + q) * ecmdev::NSTATEV;
 #pragma unroll
          for (int c = 0; c < ecmdev::NSTATEV / 2; c++) ecmdev::stg2(reinterpret_cast<double2*>(g + 2 * c), row[2 * c], row[2 * c + 1]);
-         const double* rs = wreg() + 64 * ecmdev::NSTATEV + (tid & 63) * 6; double* gs = stress1 + (e * Q + q) * 6;
+         const double* rs = wreg() + 64 * RS_SV + (tid & 63) * RS_S; double* gs = stress1 + (e * Q + q) * 6;
 #pragma unroll
          for (int c = 0; c < 3; c++) ecmdev::stg2(reinterpret_cast<double2*>(gs + 2 * c), rs[2 * c], rs[2 * c + 1]);
          return;
       }
       const int nv = nvalid();
-      flush_rows(wreg(), state1 + pt0() * ecmdev::NSTATEV, nv * ecmdev::NSTATEV, 64 * ecmdev::NSTATEV);
-      flush_rows(wreg() + 64 * ecmdev::NSTATEV, stress1 + pt0() * 6, nv * 6, 64 * 6);
+      flush_rows<ecmdev::NSTATEV, RS_SV>(wreg(), state1 + pt0() * ecmdev::NSTATEV, nv * ecmdev::NSTATEV);
+      flush_rows<6, RS_S>(wreg() + 64 * RS_SV, stress1 + pt0() * 6, nv * 6);
    }
    __device__ __forceinline__ void refresh() { int t = threadIdx.x; asm volatile("" : "+v"(t)); locate(t); }
    __device__ __forceinline__ const double* sv0() const { return state0 + qview<QB>(ecmdev::NSTATEV, Q, e, q).base; }
    __device__ __forceinline__ const double* s0() const { return stress0 + qview<QB>(6, Q, e, q).base; }
    // (STG: the lane's rows of the stage - state 28, stress 6 behind the 64 state rows, tangent half 18)
-   __device__ __forceinline__ double* sv1() const { return STG ? wreg() + (tid & 63) * ecmdev::NSTATEV : state1 + qview<QB>(ecmdev::NSTATEV, Q, e, q).base; }
-   __device__ __forceinline__ double* s1() const { return STG ? wreg() + 64 * ecmdev::NSTATEV + (tid & 63) * 6 : stress1 + qview<QB>(6, Q, e, q).base; }
+   __device__ __forceinline__ double* sv1() const { return STG ? wreg() + (tid & 63) * RS_SV : state1 + qview<QB>(ecmdev::NSTATEV, Q, e, q).base; }
+   __device__ __forceinline__ double* s1() const { return STG ? wreg() + 64 * RS_SV + (tid & 63) * RS_S : stress1 + qview<QB>(6, Q, e, q).base; }
    // REC: the lane's first 16-byte pair of its compact record ([block][q][13 pairs][64 lanes][2]); else the tangent slot
    __device__ __forceinline__ double* cm() const {
-      if (STG) return wreg() + (tid & 63) * 18;
+      if (STG) return wreg() + (tid & 31) * RS_T;      // (lanes l and l + 32 use the row one after the other)
       return REC ? cmat + pac_off<PAC_PAIRS>(e >> 6, Q, q, 0) + 2 * (e & 63) : cmat + qview<QB>(36, Q, e, q).base;
    }
    // slot s of this thread at stash()[s * ECM_STASH_STRIDE]: regions of ECM_STASH_STRIDE lanes, one behind the other
@@ -120,11 +146,6 @@ struct PointIO {
 // the velocity E-vector rows of the wave's 8 elements and the shape table) are requested as 16-byte pieces, contiguous across the wave, go through the
 // wave's stage and are read back by the lanes that own them; the Jacobians of an LVEC launch and all outputs leave the same way.  No block barrier: a
 // wave only ever touches its own region.  Never a tail launch (scattered points: the per-lane form takes those).
-__device__ __forceinline__ double2 ldg2(const double* p) {
-   typedef double vd2 __attribute__((ext_vector_type(2)));
-   const vd2 v = __builtin_nontemporal_load(reinterpret_cast<const vd2*>(p));
-   return make_double2(v.x, v.y);
-}
 // n doubles at g (16-byte aligned) -> registers, 16 bytes per lane and pass, contiguous across the wave; NU = passes (2 * 64 * NU >= total doubles)
 template <int NU>
 __device__ __forceinline__ void rows_load(const double* __restrict__ g, const int n, const int lane, double2 (&r)[NU]) {
@@ -137,12 +158,16 @@ __device__ __forceinline__ void rows_load(const double* __restrict__ g, const in
    }
 }
 // ... -> the stage (TOT = doubles the rows occupy there; pieces beyond are not written)
-template <int NU, int TOT>
+// (W, RS: rows of W doubles go RS apart; 0, 0: as they lie in memory)
+template <int NU, int TOT, int W = 0, int RS = 0>
 __device__ __forceinline__ void rows_to_stage(double* lds, const int lane, const double2 (&r)[NU]) {
 #pragma unroll
    for (int m = 0; m < NU; m++) {
       const int u = m * 64 + lane;
-      if (2 * NU * 64 <= TOT || 2 * u < TOT) *reinterpret_cast<double2*>(lds + 2 * u) = r[m];
+      if (2 * NU * 64 <= TOT || 2 * u < TOT) {
+         if constexpr (RS == W) *reinterpret_cast<double2*>(lds + 2 * u) = r[m];
+         else { const int i0 = ((2 * u) / W) * RS + (2 * u) % W; lds[i0] = r[m].x; lds[i0 + 1] = r[m].y; }
+      }
    }
 }
 constexpr int STG_J = 0, STG_V = 576, STG_G = 768;   // stage offsets (doubles) of the prologue: 64 Jacobian rows, 8 velocity E-vector rows, the trilinear shape table
@@ -218,17 +243,22 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
       // beyond the list have left, nothing here may need the whole wave; state and stress are requested behind the geometry - see below)
       if constexpr (!LVEC) { Jq_in = Jio + qview<QB>(9, Q, e, q).base; ve_in = vel + (int64_t)3 * n * e; }
    } else if constexpr (STG) {
+      // (requested in the order of use - loads return in order: the geometry rows first, so that L is formed while the state rows are still on their way)
       const int nv = io.nvalid(); const int64_t p0 = io.pt0(); double* wr = io.wreg();
+      [[maybe_unused]] double2 rg[2], rj[5], rv[2];
+      if constexpr (GSTG) rows_load<2>(G, 192, lane, rg);
+      if constexpr (!LVEC) {
+         rows_load<5>(Jio + p0 * 9, nv * 9, lane, rj);
+         if constexpr (NFIX == 8) rows_load<2>(vel + (p0 >> 3) * 24, (nv >> 3) * 24, lane, rv);   // Q = 8: the wave's 64 points are 8 whole elements, whose E-vector rows are contiguous
+      }
       rows_load<14>(state0 + p0 * ecmdev::NSTATEV, nv * ecmdev::NSTATEV, lane, rws);
       rows_load<3>(stress0 + p0 * 6, nv * 6, lane, rwt);
-      if constexpr (GSTG) { double2 rg[2]; rows_load<2>(G, 192, lane, rg); rows_to_stage<2, 192>(wr + STG_G, lane, rg); }
+      if constexpr (GSTG) rows_to_stage<2, 192>(wr + STG_G, lane, rg);
       if constexpr (!LVEC) {
-         double2 rj[5]; rows_load<5>(Jio + p0 * 9, nv * 9, lane, rj); rows_to_stage<5, 576>(wr + STG_J, lane, rj);
+         rows_to_stage<5, 576>(wr + STG_J, lane, rj);
          Jq_in = wr + STG_J + io.row_in() * 9;
-         if constexpr (NFIX == 8) {   // Q = 8: the wave's 64 points are 8 whole elements, whose E-vector rows are contiguous
-            double2 rv[2]; rows_load<2>(vel + (p0 >> 3) * 24, (nv >> 3) * 24, lane, rv); rows_to_stage<2, 192>(wr + STG_V, lane, rv);
-            ve_in = wr + STG_V + (io.row_in() >> 3) * 24;
-         } else ve_in = vel + (int64_t)3 * n * e;
+         if constexpr (NFIX == 8) { rows_to_stage<2, 192>(wr + STG_V, lane, rv); ve_in = wr + STG_V + (io.row_in() >> 3) * 24; }
+         else ve_in = vel + (int64_t)3 * n * e;
       }
       ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();
    } else {
@@ -243,7 +273,7 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
          double* Jo = io.wreg() + STG_J + (int)(threadIdx.x & 63) * 9;
          Jo[0] = a11; Jo[1] = a21; Jo[2] = a31; Jo[3] = a12; Jo[4] = a22; Jo[5] = a32; Jo[6] = a13; Jo[7] = a23; Jo[8] = a33;
          ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();
-         io.flush_rows(io.wreg() + STG_J, Jio + io.pt0() * 9, io.nvalid() * 9, 576);
+         io.template flush_rows<9, 9>(io.wreg() + STG_J, Jio + io.pt0() * 9, io.nvalid() * 9);
       } else {
          double* Jo = Jio + vJ.base;
          ecmdev::stg(Jo, a11); ecmdev::stg(Jo + QS, a21); ecmdev::stg(Jo + 2 * QS, a31); ecmdev::stg(Jo + 3 * QS, a12); ecmdev::stg(Jo + 4 * QS, a22); ecmdev::stg(Jo + 5 * QS, a32);
@@ -378,10 +408,10 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
    if constexpr (STG) { if (staged) {   // geometry done (J, velocity and table rows are in registers): the state and stress rows go through the stage
       ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();
       double* wr = io.wreg();
-      rows_to_stage<14, 64 * ecmdev::NSTATEV>(wr, lane, rws);
-      rows_to_stage<3, 64 * 6>(wr + 64 * ecmdev::NSTATEV, lane, rwt);
+      rows_to_stage<14, 64 * ecmdev::NSTATEV, ecmdev::NSTATEV, RS_SV>(wr, lane, rws);
+      rows_to_stage<3, 64 * 6, 6, RS_S>(wr + 64 * RS_SV, lane, rwt);
       ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();
-      ecmdev::load_point_in<1, true>(wr + io.row_in() * ecmdev::NSTATEV, wr + 64 * ecmdev::NSTATEV + io.row_in() * 6, pin);
+      ecmdev::load_point_in<1, true>(wr + io.row_in() * RS_SV, wr + 64 * RS_SV + io.row_in() * RS_S, pin);
       ECM_PARK_BARRIER(); __builtin_amdgcn_wave_barrier();   // (the stash slots of point_update overwrite the rows)
    } else ecmdev::load_point_in<1>(io.sv0(), io.s0(), pin); }   // (dense launch: not across the gathers - their registers are what the staged form's row pieces need)
    // per-thread stash behind the shape table in LDS (PointIO::stash)
@@ -401,7 +431,7 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
 // in global memory): with the stash and the slip table it must fit the 64 KB a launch gets without an attribute change.
 static_assert(64 * 3 * 64 > EXA_G_LDS_MAX_DOUBLES, "order-3 shape tables must not be staged in LDS by the constitutive launch");
 static_assert(sizeof(double) * ((size_t)27 * 3 * 27 + (size_t)EXA_STASH_DOUBLES + 8 * ecmdev::NSLIP) <= 65536, "dynamic LDS of k_model_setup exceeds 64 KB");
-static_assert(STG_G + 192 <= ecmdev::ST_SLOTS * 64 && 64 * (ecmdev::NSTATEV + 6) <= ecmdev::ST_SLOTS * 64, "the staged rows fit a wave's stash region");
+static_assert(STG_G + 192 <= ecmdev::ST_SLOTS * 64 && 64 * (RS_SV + RS_S) <= ecmdev::ST_SLOTS * 64 && 32 * RS_T <= 64 * ecmdev::ST_EPI_E, "the staged rows fit a wave's stash region (tangent rows below the parking slots)");
 // stg8: staged trilinear launch (k_model_setup, GSTG): the table lives in the waves' stages
 static size_t model_lds_bytes(const exa_ctx* ctx, bool km, bool p2f, bool qb, int tail_mode, bool lvec8, bool stg8 = false) {
    const int nrow = (qb && !tail_mode) ? EXA_MODEL_BS / 64 : ctx->Q;
