@@ -404,6 +404,16 @@ def main():
                                "driver_route_action_ms": ar["driver_route_apply_ms"], "ratio_to_driver_route": ar["action_ms"] / ar["driver_route_apply_ms"],
                                "note": "AddMultGradPA on E-vectors: 46-double record + x (24 / element) + y read and written; frac priced at SURVEY 8(d)'s 408 B/qpt; "
                                        "action = L->E + kernel + E->L, what an MFEM caller pays per PCG iteration"},
+                "lvec_pair": {"what": "HipExaModelLVec / HipExaNLFIntegratorLVec on the same AOS quadrature functions: exa_model_setup_lvec (node gathers + Jacobians + update in "
+                                      "one launch, rows staged), exa_grad_setup with the compact tangent form, exa_grad_apply_lvec (gather + action + scatter-add), exa_residual_lvec",
+                              "model_setup": {"avg_kernel_ms": ar["lvec_model_ms"], "qpt_updates_per_s": Pq / (ar["lvec_model_ms"] * 1e-3),
+                                              "frac": MODEL_BYTES_PER_QPT * Pq / (ar["lvec_model_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ratio_to_driver_route": ar["lvec_model_ms"] / ar["driver_route_model_ms"]},
+                              "grad_setup_ms": ar["lvec_grad_setup_ms"],
+                              "grad_apply": {"avg_kernel_ms": ar["lvec_apply_ms"], "bytes_per_qpt": APPLY_MOVED_BYTES_COMPACT,
+                                             "frac": APPLY_MOVED_BYTES_COMPACT * Pq / (ar["lvec_apply_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "ratio_to_driver_route": ar["lvec_apply_ms"] / ar["driver_route_apply_ms"]},
+                              "residual_ms": ar["lvec_residual_ms"],
+                              "stress_max_rel_diff": ar["lvec_stress_rel_diff"], "action_max_rel_diff": ar["lvec_action_rel_diff"]},
                 "parity_with_driver_route": {"stress_max_rel_diff": ar["stress_rel_diff"], "state_max_rel_diff": ar["state_rel_diff"], "action_max_rel_diff": ar["action_rel_diff"],
                                              "points_with_another_evaluation_count": ar["nfev_differing"],
                                              "note": "max |a - b| / max |a| over all points of the RVE: end-of-step stress and state (slot 3, the local solver's evaluation "

@@ -46,6 +46,7 @@ struct exa_ctx {
    bool qblk = false;                       // quadrature functions in the element-blocked layout (see QView below)
    bool aos_stage = true;                   // AOS layout: constitutive launches move a wave's contiguous point rows coalesced and transpose them through LDS (exa_set_aos_staging)
    bool have_resid = false, have_grad = false;
+   bool pa_lazy = false; const double* lazy_J = nullptr; const double* lazy_C = nullptr; double lazy_dt = 0.0;   // 46-double records not built yet (pa_kernels.hip, pa_full_on_demand)
    bool grad_records_only = false;          // gradient data = compact records written by the constitutive launch: no 46-double records, no element matrices
    // L-vector support
    const int32_t* conn = nullptr; int nnodes = 0;

@@ -360,13 +360,17 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out, char* err, int e
 //   out[8]  max |K x - driver's K x| / max |K x|              out[9]  non-converged points
 //   out[10] ms per launch of the driver's own route at this state (same loop)      out[11] ms of the driver's own gradient action
 //   out[12] AOS staging through LDS in effect (1 / 0)         out[13] points whose evaluation count (state slot 3, left out of out[7]) differs
+// and the L-vector pair (HipExaModelLVec / HipExaNLFIntegratorLVec) on the same context and quadrature functions:
+//   out[14] ms per exa_model_setup_lvec launch (gathers + Jacobians + update, AOS rows staged)      out[15] ms per exa_grad_apply_lvec (gather + action + scatter)
+//   out[16] max |stress1 - driver's| / max |stress1|          out[17] ms per exa_grad_setup with the compact tangent form
+//   out[18] max |K x - driver's K x| / max |K x|              out[19] ms per exa_residual_lvec                 out[20..23] 0
 int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* out, char* err, int errlen) {
    try {
       SystemDriver& sd = *d->sd; NonlinearMechOperator& op = sd.oper();
       if (sd.part.p != 1 || sd.comm.nranks != 1) throw std::runtime_error("exa_driver_bench_adapter_route: one rank, p = 1");
       hipStream_t s = op.stream(); const int nd = op.Height(); const int nn = nd / 3;
       const int64_t E = sd.part.E; const int Q = 8; const int64_t P = E * Q;
-      for (int i = 0; i < 16; i++) out[i] = 0.0;
+      for (int i = 0; i < 24; i++) out[i] = 0.0;
       // the driver's own residual evaluation + gradient data at this state: the outputs the adapter route is compared with
       DevBuf<double> r(nd), yC(nd), yA(nd);
       op.Mult(sd.v_sol.p, r.p);
@@ -445,6 +449,23 @@ int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* 
       EXA_HC(hipMemsetAsync(yA.p, 0, sizeof(double) * nd, s));
       action();
       out[8] = rel_diff(nd, yA.p, yC.p);
+      // ---- the L-vector pair on the same quadrature functions
+      auto model_lv = [&] { chk(exa_model_setup_lvec(ctxA, dt, op.x_cur.p, sd.v_sol.p, s0.p, sv0.p, s1.p, sv1.p, cm.p, J.p, s), "exa_model_setup_lvec"); };
+      model_lv(); model_lv();
+      {  ProfRegion prof(("adapter_route_lvec_model[passes=" + std::to_string(steps) + "]").c_str());
+         out[14] = timed(steps, model_lv); }
+      if (exa_model_status(ctxA, s) != 0) throw std::runtime_error("exa_driver_bench_adapter_route: the L-vector launch left unconverged points");
+      to_aos(6, op.stress1, tmp); out[16] = rel_diff(6 * P, s1.p, tmp.p);
+      chk(exa_set_tangent_form(ctxA, EXA_TANGENT_DEV5_BULK), "exa_set_tangent_form");
+      chk(exa_grad_setup(ctxA, dt, J.p, cm.p, s), "exa_grad_setup");
+      out[17] = timed(3, [&] { chk(exa_grad_setup(ctxA, dt, J.p, cm.p, s), "exa_grad_setup"); });
+      chk(exa_grad_set_coords(ctxA, op.x_cur.p), "exa_grad_set_coords");
+      EXA_HC(hipMemsetAsync(yA.p, 0, sizeof(double) * nd, s));
+      chk(exa_grad_apply_lvec(ctxA, r.p, yA.p, nullptr, s), "exa_grad_apply_lvec");
+      out[18] = rel_diff(nd, yA.p, yC.p);
+      {  ProfRegion prof(("adapter_route_lvec_apply[iters=" + std::to_string(iters) + "]").c_str());
+         out[15] = timed(iters, [&] { chk(exa_grad_apply_lvec(ctxA, r.p, yA.p, nullptr, s), "exa_grad_apply_lvec"); }); }
+      out[19] = timed(iters, [&] { chk(exa_residual_lvec(ctxA, J.p, s1.p, yA.p, s), "exa_residual_lvec"); });
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }

@@ -135,7 +135,11 @@ __global__ void k_residual_apply(const int Q, const int n, const int E, const do
 
 // pa record for every point of an element; one lane per element (coalesced 16-byte stores).  CMP: also the compact record.
 // TRD: the compact record holds D^T (element-assembly contexts: their action applies C^T, and the kernels then run the same code)
-template <bool QB, int CMP, bool TRD>
+// FULL = false: only the compact records are written - all that the L-vector action with recomputed geometry reads (46 of the 117 doubles this pass moves per
+// point otherwise); the 46-double records are then built on demand from the same arrays (exa_launch_grad_setup_pa, pa_lazy).
+// (Round 6, measured at 128^3 on the reference layout: one lane per POINT - contiguous 16-byte loads of its own 288-byte row, stores of 8 x 128-byte segments -
+//  is slower than this form, 5.2 against 2.5 ms for the 46-double records: 64 separate lines per load instruction either way, and the stores lose their 1 KB rows.)
+template <bool QB, int CMP, bool TRD, bool FULL = true>
 __global__ __launch_bounds__(PA_BLK) void k_grad_setup_pa(const int Q, const int E, const double dt, const double* __restrict__ W,
                                                           const double* __restrict__ J, const double* __restrict__ C, double* __restrict__ pa, double* __restrict__ pac) {
    const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
@@ -145,12 +149,14 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_setup_pa(const int Q, const int
       double adj[9], detJ; adj_det(J + vj.base, adj, detJ, vj.stride);
       const double sc = dt * W[q] / detJ;
       const double* c = C + vc.base;
+      if (FULL) {
       double2* rec = reinterpret_cast<double2*>(pa + pa_off(blk, Q, q, 0)) + lane;
 #pragma unroll
       for (int pr = 0; pr < 18; pr++) rec[pr * PA_BLK] = make_double2(c[(2 * pr) * vc.stride] * sc, c[(2 * pr + 1) * vc.stride] * sc);
 #pragma unroll
       for (int pr = 0; pr < 4; pr++) rec[(18 + pr) * PA_BLK] = make_double2(adj[2 * pr], adj[2 * pr + 1]);
       rec[22 * PA_BLK] = make_double2(adj[8], W[q] * detJ);
+      }
       if (CMP) {   // 13 pairs: D, K;  18 pairs: D, K, adj(J), W detJ
          double D[36], Dn[25]; tangent_to_d55(c, vc.stride, Dn, D[25]);
 #pragma unroll
@@ -650,12 +656,33 @@ int exa_launch_residual_p1(exa_ctx* ctx, const double* J, const double* S, doubl
    if (ev) return det_gather(ctx, y, nullptr, s);
    return EXA_OK;
 }
+// the 46-double records of a context whose last exa_grad_setup wrote the compact ones only: built now, from the arrays that call was given
+static int pa_full_on_demand(exa_ctx* ctx, hipStream_t s) {
+   if (!ctx->pa_lazy) return EXA_OK;
+   const dim3 grid(nblk(ctx->E, PA_BLK));
+   if (ctx->qblk) hipLaunchKernelGGL((k_grad_setup_pa<true, 0, false>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, ctx->lazy_dt, ctx->W_dev, ctx->lazy_J, ctx->lazy_C, ctx->pa, ctx->pa_c);
+   else hipLaunchKernelGGL((k_grad_setup_pa<false, 0, false>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, ctx->lazy_dt, ctx->W_dev, ctx->lazy_J, ctx->lazy_C, ctx->pa, ctx->pa_c);
+   EXA_HIP_CHECK(ctx, hipGetLastError());
+   ctx->pa_lazy = false;
+   return EXA_OK;
+}
+
 int exa_launch_grad_setup_pa(exa_ctx* ctx, double dt, const double* J, const double* C, hipStream_t s) {
+   ctx->pa_lazy = false;
    const dim3 grid(nblk(ctx->E, PA_BLK));
 #define GS_LAUNCH(QBV, NP, TR) hipLaunchKernelGGL((k_grad_setup_pa<QBV, NP, TR>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c)
 #define GS_LAUNCH2(NP, TR) do { if (ctx->qblk) GS_LAUNCH(true, NP, TR); else GS_LAUNCH(false, NP, TR); } while (0)
    const bool trd = ctx->cfg.assembly == EXA_ASSEMBLY_EA;
-   if (ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) { if (trd) GS_LAUNCH2(PAC_PAIRS, true); else GS_LAUNCH2(PAC_PAIRS, false); }
+   static const bool lazy_off = [] { const char* e = std::getenv("EXA_GRAD_SETUP_LAZY"); return e && std::strcmp(e, "off") == 0; }();   // A/B switch: both record sets in one pass, as in rounds 3-5
+   if (ctx->pa_c && ctx->pac_pairs == PAC_PAIRS && !trd && !lazy_off) {
+      // p = 1 partial assembly: the L-vector action with recomputed geometry streams the compact records alone (exa_grad_set_coords); the diagonal, the
+      // E-vector action and an action without coordinates need the 46-double ones, which are built on demand - J and C must stay as they are until the next
+      // exa_grad_setup (they do in a Newton iteration: the reference calls AssembleGradDiagonalPA right after AssembleGradPA, src/mechanics_operator.cpp:436-443)
+      if (ctx->qblk) hipLaunchKernelGGL((k_grad_setup_pa<true, PAC_PAIRS, false, false>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c);
+      else hipLaunchKernelGGL((k_grad_setup_pa<false, PAC_PAIRS, false, false>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c);
+      ctx->pa_lazy = true; ctx->lazy_J = J; ctx->lazy_C = C; ctx->lazy_dt = dt;
+   }
+   else if (ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) { if (trd) GS_LAUNCH2(PAC_PAIRS, true); else GS_LAUNCH2(PAC_PAIRS, false); }
    else if (ctx->pa_c) { if (trd) GS_LAUNCH2(PAC_PAIRS_GEO, true); else GS_LAUNCH2(PAC_PAIRS_GEO, false); }
    else GS_LAUNCH2(0, false);
 #undef GS_LAUNCH2
@@ -670,6 +697,7 @@ int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec
    const unsigned nb = ranged ? (unsigned)nblk_range : nball;
    if (!ranged) blk0 = 0;
    if (nb == 0) return EXA_OK;
+   if (!(lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS)) { if (int rc = pa_full_on_demand(ctx, s)) return rc; }   // every other form streams the 46-double records
    double* ev = nullptr;
    if (lvec && ctx->det) { if (int rc = exa_det_prepare(ctx)) return rc; ev = ctx->ev_det; }
 #define GA_LAUNCH(G, CM, T, REC, CRD) hipLaunchKernelGGL((k_grad_apply_p1<true, G, CM, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, REC, x, y, ctx->conn, ctx->nnodes, mask, gate, CRD, ev, blk0)
@@ -691,6 +719,7 @@ int exa_launch_tangent_defect(exa_ctx* ctx, const double* C, unsigned long long*
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }
 int exa_launch_grad_diag_p1(exa_ctx* ctx, double* y, hipStream_t s) {
+   if (int rc = pa_full_on_demand(ctx, s)) return rc;
    hipLaunchKernelGGL(k_grad_diag_p1, dim3(nblk(ctx->E, PA_BLK)), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, y);
    EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
 }

@@ -320,10 +320,11 @@ class Driver:
     def bench_adapter_route(self, steps, iters):
         """The calls the MFEM adapters make (AOS exa_model_setup, exa_grad_setup, E-vector exa_grad_apply between L->E and E->L) at this driver's state."""
         import numpy as np
-        o = np.zeros(16)
+        o = np.zeros(24)
         self._chk(exa_driver_bench_adapter_route(self.h, steps, iters, o.ctypes.data_as(C.POINTER(C.c_double)), self._err, 512))
         return dict(model_ms=o[0], pass_ms=o[1], geometry_ms=o[2], grad_setup_ms=o[3], grad_apply_ms=o[4], action_ms=o[5], stress_rel_diff=o[6], state_rel_diff=o[7],
-                    action_rel_diff=o[8], failed=int(o[9]), driver_route_model_ms=o[10], driver_route_apply_ms=o[11], aos_staging=bool(o[12]), nfev_differing=int(o[13]))
+                    action_rel_diff=o[8], failed=int(o[9]), driver_route_model_ms=o[10], driver_route_apply_ms=o[11], aos_staging=bool(o[12]), nfev_differing=int(o[13]),
+                    lvec_model_ms=o[14], lvec_apply_ms=o[15], lvec_stress_rel_diff=o[16], lvec_grad_setup_ms=o[17], lvec_action_rel_diff=o[18], lvec_residual_ms=o[19])
 
     def bench_pcg(self, iters):
         import numpy as np

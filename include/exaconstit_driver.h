@@ -104,8 +104,9 @@ int exa_driver_bench_prepare(exa_driver* d, int nsteps, const double* dts, doubl
 int exa_driver_bench_model(exa_driver* d, int steps, double* out3, char* err, int errlen);
 int exa_driver_bench_pcg(exa_driver* d, int iters, double* out3, char* err, int errlen);
 /* the drop-in route (the calls of include/exaconstit_mfem_adapters.hpp: AOS exa_model_setup, exa_grad_setup, E-vector exa_grad_apply between the element
- * restriction and its transpose) timed on a second context that is given this driver's state; out16 documented at the definition (host/driver_capi.hip) */
-int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* out16, char* err, int errlen);
+ * restriction and its transpose - and the L-vector pair's exa_model_setup_lvec / exa_grad_apply_lvec) timed on a second context that is given this driver's state;
+ * out24 documented at the definition (host/driver_capi.hip) */
+int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* out24, char* err, int errlen);
 
 /* host-logic queries that need no GPU (used by the CPU tests) ------------------------------------------------------------ */
 /* options.toml reader (reference src/option_parser.cpp:26-932): fills out[0..19] =

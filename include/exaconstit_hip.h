@@ -234,7 +234,11 @@ int exa_grad_set_coords(exa_ctx* ctx, const double* coords_lvec_dev);
  *                          plus a bulk term - what every ExaCMech evptn model returns (26 numbers, 13 instead of 18 16-byte loads per point).
  *                          exa_grad_setup projects ddsdde onto that form; the projection is exact only if the tangent has the form, which
  *                          exa_grad_tangent_defect measures (max over the points of |C - projection|_max / |C|_max; ~1e-16 for ExaCMech
- *                          tangents).  The caller is responsible for checking it; the stand-alone driver does on every GetGradient. */
+ *                          tangents).  The caller is responsible for checking it; the stand-alone driver does on every GetGradient.
+ *                          p = 1 partial assembly: exa_grad_setup then writes the compact records only (71 instead of 117 doubles moved per point); the
+ *                          46-double records that exa_grad_diagonal, exa_grad_apply on E-vectors and an L-vector action without exa_grad_set_coords
+ *                          read are built when one of them is first called, from the jacobian_dev / ddsdde_dev arrays of that exa_grad_setup - which
+ *                          must therefore stay unchanged until then (they do within a Newton iteration). */
 enum { EXA_TANGENT_FULL = 0, EXA_TANGENT_DEV5_BULK = 1 };
 int exa_set_tangent_form(exa_ctx* ctx, int form);
 int exa_grad_tangent_defect(exa_ctx* ctx, const double* ddsdde_dev, double* defect_host, exa_stream s);

@@ -2,7 +2,7 @@
 // include/exaconstit_mfem_adapters.hpp touches, so that the adapters are compiled and run in an image without MFEM:
 //   mfem::Vector (device-resident, Read/Write/ReadWrite/HostRead/HostWrite/SetSize/UseDevice/Size), QuadratureFunction, ParGridFunction,
 //   FiniteElement (GetGeomType/GetOrder), IntRules.Get, GeometricFactors (J laid out (Q,3,3,E)), Mesh::GetGeometricFactors,
-//   FiniteElementSpace (GetFE/GetMesh), NonlinearFormIntegrator (the PA / EA virtuals of the MFEM fork ExaConstit builds on),
+//   FiniteElementSpace (GetFE/GetMesh/GetNE/GetNDofs/GetElementDofs), Array<int> (SetSize/HostWrite/Read/Size/operator[]), NonlinearFormIntegrator (the PA / EA virtuals of the MFEM fork ExaConstit builds on),
 //   Assembly, ExaModel (reference src/mechanics_model.hpp:17-241: members, ctor :70-75, ModelSetup :109-111, accessors),
 //   ExaNLFIntegrator (reference src/mechanics_integrators.hpp:14-76).
 // Signatures follow the reference headers; bodies are the least that works.
@@ -31,6 +31,24 @@ class Vector {
    void FromHost(const double* p) { if (n_) (void)hipMemcpy(d_, p, sizeof(double) * n_, hipMemcpyHostToDevice); }
 };
 
+// mfem::Array<T>: host array with a device mirror that Read() brings up to date (the L-vector adapter's element -> node table)
+template <class T> class Array {
+   std::vector<T> h_; mutable T* d_ = nullptr; mutable int dn_ = 0;
+ public:
+   Array() = default; Array(const Array&) = delete; Array& operator=(const Array&) = delete;
+   ~Array() { if (d_) (void)hipFree(d_); }
+   void SetSize(int n) { h_.resize(n); }
+   int Size() const { return (int)h_.size(); }
+   T* HostWrite() { return h_.data(); }
+   T& operator[](int i) { return h_[i]; }
+   const T& operator[](int i) const { return h_[i]; }
+   const T* Read() const {
+      if (dn_ != (int)h_.size()) { if (d_) (void)hipFree(d_); d_ = nullptr; dn_ = (int)h_.size(); if (dn_ && hipMalloc(&d_, sizeof(T) * dn_) != hipSuccess) throw std::runtime_error("mock Array: hipMalloc"); }
+      if (dn_) (void)hipMemcpy(d_, h_.data(), sizeof(T) * dn_, hipMemcpyHostToDevice);
+      return d_;
+   }
+};
+
 class QuadratureFunction : public Vector { int vdim_ = 1; public: QuadratureFunction(int npts, int vdim) : Vector(npts * vdim), vdim_(vdim) {} int GetVDim() const { return vdim_; } };
 class ParGridFunction : public Vector { public: using Vector::Vector; };
 
@@ -50,10 +68,15 @@ class Mesh {
 };
 class FiniteElementSpace {
    Mesh* mesh_; FiniteElement fe_;
+   std::vector<int> conn_; int ne_ = 0, ndofs_ = 0, npe_ = 0;      // element -> scalar dof (node) table, native element order
  public:
    FiniteElementSpace(Mesh* m, int p) : mesh_(m), fe_(p) {}
+   void SetElementDofs(const int* conn, int npe, int ne, int ndofs) { conn_.assign(conn, conn + (size_t)npe * ne); npe_ = npe; ne_ = ne; ndofs_ = ndofs; }   // (mock only)
    const FiniteElement* GetFE(int) const { return &fe_; }
    Mesh* GetMesh() const { return mesh_; }
+   int GetNE() const { return ne_; }
+   int GetNDofs() const { return ndofs_; }
+   void GetElementDofs(int e, Array<int>& dofs) const { dofs.SetSize(npe_); for (int a = 0; a < npe_; a++) dofs[a] = conn_[a + (size_t)npe_ * e]; }
 };
 
 class NonlinearFormIntegrator {

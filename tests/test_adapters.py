@@ -14,9 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MOCK = os.path.join(ROOT, "tests", "mock_mfem")
 
 
-def _build(out):
+def _build(out, src="adapter_run.cpp"):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-Wall", "-Werror", "-I" + MOCK, "-I" + os.path.join(ROOT, "include"), "-o", out,
-           os.path.join(MOCK, "adapter_run.cpp"), "-L" + os.path.join(ROOT, "exaconstit_amd"), "-lexaconstit_hip", "-Wl,-rpath," + os.path.join(ROOT, "exaconstit_amd")]
+           os.path.join(MOCK, src), "-L" + os.path.join(ROOT, "exaconstit_amd"), "-lexaconstit_hip", "-Wl,-rpath," + os.path.join(ROOT, "exaconstit_amd")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
 
@@ -24,6 +24,7 @@ def _build(out):
 def test_adapters_compile_against_the_mock(tmp_path):
     import exaconstit_amd.lib  # noqa: F401  (builds the library if needed)
     _build(str(tmp_path / "adapter_run"))
+    _build(str(tmp_path / "adapter_run_lvec"), "adapter_run_lvec.cpp")
 
 
 def test_adapter_header_refuses_to_compile_without_mfem(tmp_path):
@@ -97,5 +98,75 @@ def test_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, ea, order, 
         if name in ("stress1", "state1", "matGrad", "AddMultPA") or (ea and name == "emat") or (not ea and name in ("AddMultGradPA", "diagonal")):
             assert np.linalg.norm(w) > 0, name
         assert np.array_equal(g, w), (name, np.abs(g - w).max())
+    assert off == got.size
+    assert np.abs(want[1].reshape(P, 28)[:, 14:26]).sum() > 0         # the step was plastic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,pfile,order,compact", [(0, "props_cp_voce.txt", 1, 1), (0, "props_cp_voce.txt", 1, 0), (5, "props_cp_mts.txt", 1, 1), (0, "props_cp_voce.txt", 2, 1)])
+def test_lvec_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, order, compact):
+    """The L-vector pair (HipExaModelLVec / HipExaNLFIntegratorLVec): ModelSetup with the velocity L-vector, AddMultPA / AddMultGradPA / the diagonal on
+    L-vectors, through base-class pointers of the mock - against the same sequence of direct C-ABI calls (constitutive outputs and Jacobians bit for bit;
+    the L-vector sums, which FP64 atomics add in a run-dependent order, to round-off) and, for the gradient action, against the oracle's restatement of the
+    reference's TransformMatGradTo4D -> AssembleGradPA -> AddMultGradPA chain on the same tangent and Jacobians."""
+    import exaconstit_amd.lib as L
+    import hipref
+    import torch
+    from hipref import ptr, rel_l2
+    orc = oracle
+    exe = str(tmp_path / "adapter_run_lvec")
+    _build(exe, "adapter_run_lvec.cpp")
+    dev = hipref.Dev()
+    rve = hipref.make_rve(orc, 3 if order == 1 else 2, p=order, distort=0.2 if order == 1 else 0.1, seed=3)
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]; P = E * Q
+    props = np.loadtxt(os.path.join(orc.REFDATA, pfile)).ravel()
+    quats = hipref.random_quats(E, seed=9)
+    dt = 0.4
+    v_nodes = hipref.velocity_field(rve, scale=3.0)
+    xend = rve["X"] + dt * v_nodes
+    x_act = np.random.default_rng(1).uniform(-1, 1, 3 * NN)
+    # ---- direct ABI calls
+    ctx = L.Context(model, props, 298.0, order, E)
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+    if compact:
+        ctx.check(L.exa_set_tangent_form(ctx.h, L.EXA_TANGENT_DEV5_BULK))
+    d_sv0 = dev.zeros(28 * P); ctx.check(L.exa_init_state(ctx.h, ptr(d_sv0), ptr(dev.up(quats.ravel())), None))
+    d_s0 = dev.zeros(6 * P); o = [dev.zeros(6 * P), dev.zeros(28 * P), dev.zeros(36 * P), dev.zeros(9 * P)]
+    d_x = dev.up(xend); d_v = dev.up(v_nodes)
+    ctx.check(L.exa_model_setup_lvec(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(d_s0), ptr(d_sv0), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), None))
+    assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+    yres, ygrad, diag, ev = dev.zeros(3 * NN), dev.zeros(3 * NN), dev.zeros(3 * NN), dev.zeros(3 * n * E)
+    ctx.check(L.exa_residual_lvec(ctx.h, ptr(o[3]), ptr(o[0]), ptr(yres), None))
+    ctx.check(L.exa_grad_setup(ctx.h, dt, ptr(o[3]), ptr(o[2]), None)); ctx.check(L.exa_grad_set_coords(ctx.h, ptr(d_x)))
+    d_xa = dev.up(x_act)
+    ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(d_xa), ptr(ygrad), None, None))
+    ctx.check(L.exa_grad_diagonal(ctx.h, ptr(ev), None)); ctx.check(L.exa_restrict_transpose_add(ctx.h, ptr(ev), ptr(diag), None))
+    want = [t.cpu().numpy() for t in (o[0], o[1], o[2], o[3], yres, ygrad, diag)]
+    # the action against the oracle's chain (reference src/mechanics_model.cpp:949-1061, src/mechanics_integrators.cpp:331-513, 562-622) between L->E and E->L
+    ye = np.zeros(3 * n * E); C4 = np.zeros(81 * P); D4 = np.zeros(81 * P)
+    orc.lib().orc_transform_4d(C.c_int64(P), orc._p(want[2]), orc._p(C4))
+    orc.lib().orc_assemble_grad_pa(Q, E, C.c_double(dt), orc._p(rve["W"]), orc._p(want[3]), orc._p(C4), orc._p(D4))
+    orc.lib().orc_add_mult_grad_pa(Q, E, n, orc._p(rve["G"]), orc._p(D4), orc._p(hipref.l_to_e(rve, x_act)), orc._p(ye))
+    assert rel_l2(want[5], hipref.e_to_l(rve, ye)) < 1e-12
+    ctx.close()
+    # ---- the same through the adapter classes
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("iiiiii", E, model, len(props), order, NN, compact)); f.write(struct.pack("d", dt))
+        f.write(np.ascontiguousarray(props, dtype=np.float64).tobytes()); f.write(np.ascontiguousarray(rve["conn"], dtype=np.int32).tobytes())
+        for a in (xend, v_nodes, quats.ravel(), x_act):
+            f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(fout, dtype=np.float64)
+    off = 0
+    for w, name in zip(want, ("stress1", "state1", "matGrad", "jacobians", "AddMultPA", "AddMultGradPA", "diagonal")):
+        g = got[off:off + w.size]; off += w.size
+        assert np.linalg.norm(w) > 0, name
+        if name in ("AddMultPA", "AddMultGradPA", "diagonal"):
+            assert rel_l2(g, w) < 1e-13, (name, rel_l2(g, w))
+        else:
+            assert np.array_equal(g, w), (name, np.abs(g - w).max())
     assert off == got.size
     assert np.abs(want[1].reshape(P, 28)[:, 14:26]).sum() > 0         # the step was plastic

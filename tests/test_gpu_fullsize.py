@@ -260,3 +260,97 @@ def test_config3_bcc_kmdd_128_sampled_against_oracle(oracle):
     assert np.abs(nf_gpu - nf_ref).max() <= 1 and np.mean(nf_gpu == nf_ref) >= 0.999, (np.abs(nf_gpu - nf_ref).max(), np.mean(nf_gpu == nf_ref))
     assert np.abs(sv.reshape(-1, 28)[:, 14:26]).sum() > 0                  # plastic
     ctx.close()
+
+
+def test_headline_record_route_128_sampled_against_oracle(oracle):
+    """The exact launch of the headline number - k_model_setup<8, true, 8, true, true>: FCC Voce with the exponent compiled in, fused L-vector gathers,
+    element-blocked layout, compact gradient records instead of a tangent field, no Jacobian field (exa_model_setup_lvec_records, what bench.py's `value`
+    times) - at 128^3 through the elastic-plastic transition.  512 sampled elements (4 096 points) are recomputed by the oracle from the inputs the last
+    launch consumed: stress, state, evaluation counts.  The records have no oracle counterpart point by point (the reference streams C4 / D4), so the
+    record-based gradient action is compared (a) over the whole RVE with the action built from the tangent FIELD of an AOS context at the same state,
+    and (b) that context's element-local action (exa_grad_apply on E-vectors) with the oracle's TransformMatGradTo4D -> AssembleGradPA -> AddMultGradPA
+    chain on the oracle's own tangents of the sampled elements (reference src/mechanics_model.cpp:949-1061, src/mechanics_integrators.cpp:331-513, 562-622)."""
+    import torch
+    import exaconstit_amd.lib as L
+    orc = oracle
+    dev = hipref.Dev()
+    N = 128
+    rve = hipref.make_rve(orc, N)
+    E, Q, n, NN = rve["E"], rve["Q"], rve["n"], rve["NN"]
+    P = E * Q
+    props = np.loadtxt(os.path.join(orc.REFDATA, "props_cp_voce.txt")).ravel()
+    d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
+    ctx = L.Context(L.EXA_FCC_VOCE, props, 298.0, 1, E, assembly=L.EXA_ASSEMBLY_PA)
+    ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
+    ctx.check(L.exa_set_quadrature_layout(ctx.h, L.EXA_QLAYOUT_EB64))
+    ctx.check(L.exa_set_tangent_form(ctx.h, L.EXA_TANGENT_DEV5_BULK))
+    nq = lambda w: int(L.exa_qf_size(ctx.h, w))
+    quats = hipref.random_quats(E)
+    d_sv = [dev.zeros(nq(28)), dev.zeros(nq(28))]; d_s = [dev.zeros(nq(6)), dev.zeros(nq(6))]
+    d_quats_keep = dev.up(quats.ravel())
+    ctx.check(L.exa_init_state(ctx.h, ptr(d_sv[0]), ptr(d_quats_keep), None))
+    v_nodes = hipref.velocity_field(rve)
+    d_v = dev.up(v_nodes); d_x = dev.up(rve["X"])
+    dts = [0.005, 0.195, 0.4, 0.4]
+    for i, dt in enumerate(dts):
+        d_x += dt * d_v
+        if i == len(dts) - 1:
+            sv_in, s_in = d_sv[0].clone(), d_s[0].clone()
+        ctx.check(L.exa_model_setup_lvec_records(ctx.h, dt, ptr(d_x), ptr(d_v), ptr(d_s[0]), ptr(d_sv[0]), ptr(d_s[1]), ptr(d_sv[1]), None, None))   # no Jacobian field
+        assert ctx.check(L.exa_model_status(ctx.h, None)) == 0
+        d_sv.reverse(); d_s.reverse()
+
+    def rows(t, w):   # element-blocked [block of 64][q][comp][lane] -> (P, w) in the reference's point order
+        nb = (E + 63) // 64
+        return t.view(nb, Q, w, 64).permute(0, 3, 1, 2).reshape(nb * 64 * Q, w)[:P]
+    rng = np.random.default_rng(11)
+    es = np.sort(rng.choice(E, 512, replace=False))
+    qidx = torch.from_numpy((es[:, None] * Q + np.arange(Q)[None, :]).ravel()).to(dev.dev)
+    take = lambda t, w: rows(t, w)[qidx].cpu().numpy().ravel()
+    conn = rve["conn"].reshape(E, n)[es]
+    x_end = d_x.cpu().numpy()
+    xe = np.stack([x_end[conn + NN * c] for c in range(3)], axis=1).ravel()
+    ve = np.stack([v_nodes[conn + NN * c] for c in range(3)], axis=1).ravel()
+    ns = len(es)
+    Js = np.zeros(9 * ns * Q); orc.lib().orc_jacobians(1, ns, orc._p(xe), orc._p(Js))
+    s1 = np.zeros(6 * ns * Q); sv = np.zeros(28 * ns * Q); cm = np.zeros(36 * ns * Q)
+    nf = orc.lib().orc_model_setup(0, 0, orc._p(props), len(props), Q, ns, n, 28, C.c_double(dts[-1]), C.c_double(298.0), orc._p(Js), orc._p(rve["G"]),
+                                   orc._p(ve), orc._p(take(s_in, 6)), orc._p(take(sv_in, 28)), orc._p(s1), orc._p(sv), orc._p(cm), None, 1, 0, 0)
+    assert nf == 0
+    assert rel_l2(take(d_s[0], 6), s1) < 1e-9
+    keep = np.ones(28, bool); keep[3] = False
+    assert rel_l2(take(d_sv[0], 28).reshape(-1, 28)[:, keep], sv.reshape(-1, 28)[:, keep]) < 1e-8
+    nf_gpu, nf_ref = take(d_sv[0], 28).reshape(-1, 28)[:, 3], sv.reshape(-1, 28)[:, 3]
+    assert nf_ref.max() > 4 and np.abs(sv.reshape(-1, 28)[:, 14:26]).sum() > 0          # plastic: the local solves iterated
+    assert np.abs(nf_gpu - nf_ref).max() <= 1 and np.mean(nf_gpu == nf_ref) >= 0.999, (np.abs(nf_gpu - nf_ref).max(), np.mean(nf_gpu == nf_ref))
+
+    # ---- the record-based action (geometry from the nodes, compact records of the launch above) over the whole RVE
+    ctx.check(L.exa_grad_set_coords(ctx.h, ptr(d_x)))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x1 = torch.rand(3 * NN, generator=g, dtype=torch.float64).to(dev.dev) - 0.5
+    y_rec = dev.zeros(3 * NN)
+    ctx.check(L.exa_grad_apply_lvec(ctx.h, ptr(x1), ptr(y_rec), None, None))
+    # the same state through an AOS context with a tangent field and full 46-double records
+    aos = L.Context(L.EXA_FCC_VOCE, props, 298.0, 1, E, assembly=L.EXA_ASSEMBLY_PA)
+    aos.check(L.exa_set_connectivity(aos.h, ptr(d_conn), NN))
+    a_sv0 = rows(sv_in, 28).contiguous().view(-1); a_s0 = rows(s_in, 6).contiguous().view(-1)
+    a_s1, a_sv1, a_cm, a_J = dev.zeros(6 * P), dev.zeros(28 * P), dev.zeros(36 * P), dev.zeros(9 * P)
+    aos.check(L.exa_model_setup_lvec(aos.h, dts[-1], ptr(d_x), ptr(d_v), ptr(a_s0), ptr(a_sv0), ptr(a_s1), ptr(a_sv1), ptr(a_cm), ptr(a_J), None))
+    assert aos.check(L.exa_model_status(aos.h, None)) == 0
+    assert float((a_s1.view(P, 6) - rows(d_s[0], 6)).abs().max()) < 1e-12 * float(a_s1.abs().max())      # (another instantiation of the kernel: round-off)
+    aos.check(L.exa_grad_setup(aos.h, dts[-1], ptr(a_J), ptr(a_cm), None))
+    y_tan = dev.zeros(3 * NN)
+    aos.check(L.exa_grad_apply_lvec(aos.h, ptr(x1), ptr(y_tan), None, None))
+    assert float((y_rec - y_tan).norm() / y_tan.norm()) < 1e-11
+    # ... and that context's element-local action against the oracle's chain on the oracle's tangents of the sampled elements
+    d_xe = dev.zeros(3 * n * E); d_ye = dev.zeros(3 * n * E)
+    aos.check(L.exa_restrict(aos.h, ptr(x1), ptr(d_xe), None))
+    aos.check(L.exa_grad_apply(aos.h, ptr(d_xe), ptr(d_ye), None))
+    eidx = torch.from_numpy(es).to(dev.dev)
+    ye_gpu = d_ye.view(E, 3 * n)[eidx].cpu().numpy().ravel(); xe_act = d_xe.view(E, 3 * n)[eidx].cpu().numpy().ravel()
+    C4 = np.zeros(81 * ns * Q); D4 = np.zeros(81 * ns * Q); ye_ref = np.zeros(3 * n * ns)
+    orc.lib().orc_transform_4d(C.c_int64(ns * Q), orc._p(cm), orc._p(C4))
+    orc.lib().orc_assemble_grad_pa(Q, ns, C.c_double(dts[-1]), orc._p(rve["W"]), orc._p(Js), orc._p(C4), orc._p(D4))
+    orc.lib().orc_add_mult_grad_pa(Q, ns, n, orc._p(rve["G"]), orc._p(D4), orc._p(xe_act), orc._p(ye_ref))
+    assert rel_l2(ye_gpu, ye_ref) < 1e-7          # (the tangents agree to 1e-7: the tolerance of the tangent comparison everywhere in this suite)
+    aos.close(); ctx.close()

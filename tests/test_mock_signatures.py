@@ -6,7 +6,8 @@ the real build.  Here a small C++ declaration reader extracts constructor and vi
 parameter types without names, const-ness, pure-ness) from the reference headers and fails when
   * the mock's ExaModel / ExaNLFIntegrator declare a constructor, virtual or override that the reference class does not have in that exact form,
   * a reference `override` (which the real MFEM base must therefore declare) is missing from the mock's mfem::NonlinearFormIntegrator,
-  * an `override` of HipExaModel / HipExaNLFIntegrator has no identical virtual in the reference base class,
+  * an `override` of HipExaModel / HipExaNLFIntegrator (or of the L-vector pair HipExaModelLVec / HipExaNLFIntegratorLVec) has no identical virtual in the
+    reference base class,
   * a non-virtual ExaModel member the adapters call (SetModelDt, GetStress1, ...) differs.
 Build-container test: the reference tree does not exist on the GPU box (skipped there).  test_checker_notices_a_drifted_mock edits one
 signature in memory and requires the checker to go red."""
@@ -144,7 +145,7 @@ def mismatches(mock_text, adapt_text, ref_model, ref_integ):
                 if b is None or not b["virtual"] or (b["ret"], b["const"]) != (r["ret"], r["const"]):
                     bad.append(f"mock mfem::NonlinearFormIntegrator lacks the virtual {key[0]}({', '.join(key[1])}) that {cls} overrides")
     # 3. every override of the adapters exists, identically, as a virtual of the reference base class
-    for cls, refcls in (("HipExaModel", "ExaModel"), ("HipExaNLFIntegrator", "ExaNLFIntegrator")):
+    for cls, refcls in (("HipExaModel", "ExaModel"), ("HipExaNLFIntegrator", "ExaNLFIntegrator"), ("HipExaModelLVec", "ExaModel"), ("HipExaNLFIntegratorLVec", "ExaNLFIntegrator")):
         for key, m in methods(adapt_text, cls).items():
             if not m["override"] or key[0].startswith("~"):
                 continue
