@@ -558,6 +558,13 @@ def main():
         if solve is not None:
             out["newton_pcg_solve"] = solve
         if in_solve is not None:
+            # the in-solve fractions first, as plain numbers of the roofline object (a truncated record of this line still carries them); the segments follow
+            for key, name in (("whole_solve", "in_solve_frac_whole_solve"), ("steps_ge_5", "in_solve_frac_steps_ge_5"), ("steps_ge_10", "in_solve_frac_steps_ge_10"),
+                              ("plateau", "in_solve_frac_plateau"), ("dt_0p2_segment", "in_solve_frac_dt_0p2_segment")):
+                if in_solve.get(key):
+                    out["roofline"][name] = in_solve[key]["frac"]
+            out["roofline"] = {k: out["roofline"][k] for k in (["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"] + [k for k in out["roofline"] if k.startswith("in_solve_frac_")]
+                                                                + [k for k in out["roofline"] if k not in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic") and not k.startswith("in_solve_frac_")])}
             out["roofline"]["in_solve"] = in_solve
         if adapter is not None:
             out["adapter_route"] = adapter
