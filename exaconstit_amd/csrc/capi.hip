@@ -6,6 +6,7 @@
 
 int exa_launch_model_setup(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, hipStream_t);
 int exa_launch_model_setup_rec(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
+int exa_launch_model_setup_p2(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, bool, hipStream_t);
 int exa_launch_init_state(exa_ctx*, double*, const double*, const double*, hipStream_t);
 int exa_launch_state_normalize(exa_ctx*, double*, hipStream_t);
 int exa_launch_nfev_hist(exa_ctx*, const double*, int*, hipStream_t);
@@ -90,7 +91,7 @@ void exa_destroy(exa_ctx* ctx) {
    if (!ctx) return;
    (void)hipFree(ctx->n2e_off); (void)hipFree(ctx->n2e_idx); (void)hipFree(ctx->ev_det);
    (void)hipFree(ctx->G_dev); (void)hipFree(ctx->W_dev); (void)hipFree(ctx->fail_count_dev); (void)hipFree(ctx->tail_dev); (void)hipFree(ctx->tail2_dev); (void)hipFree(ctx->resume_dev[0]); (void)hipFree(ctx->resume_dev[1]); (void)hipFree(ctx->scratch_dev);
-   (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->T1_dev); (void)hipFree(ctx->pa_c); (void)hipFree(ctx->tbuf);
+   (void)hipFree(ctx->dmat); (void)hipFree(ctx->pa); (void)hipFree(ctx->emat); (void)hipFree(ctx->eDS); (void)hipFree(ctx->T1_dev); (void)hipFree(ctx->pa_c); (void)hipFree(ctx->tbuf); (void)hipFree(ctx->vgrad_ref);
    delete ctx;
 }
 
@@ -150,16 +151,19 @@ int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* x_lvec, 
    if (!ctx || !x_lvec || !v_lvec || !stress0 || !state0 || !stress1 || !state1) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: null pointer");   // J_out may be null
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec_records: call exa_set_connectivity first");
    if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: dt must be positive");
-   if (ctx->p != 1 || ctx->cfg.integ != EXA_INTEG_FULL || !ctx->qblk || ctx->tangent_form != EXA_TANGENT_DEV5_BULK ||
-       !(ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree))
-      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_model_setup_lvec_records: needs p = 1 full integration, the element-blocked layout, the compact tangent form and PA or matrix-free EA");
-   if (ctx->pa_c && ctx->pac_pairs != PAC_PAIRS) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec_records: compact records of another shape exist");
+   const bool p1 = ctx->p == 1 && ctx->cfg.integ == EXA_INTEG_FULL, p2 = ctx->p == 2;      // p = 2: plain or B-bar, behind the geometry pre-pass (a Jacobian field is part of it)
+   if (!(p1 || p2) || !ctx->qblk || ctx->tangent_form != EXA_TANGENT_DEV5_BULK || !(ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree))
+      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_model_setup_lvec_records: needs p = 1 full integration or p = 2, the element-blocked layout, the compact tangent form and PA or matrix-free EA");
+   if (p2 && !J_out) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: at p = 2 the Jacobian field is not optional (the pre-pass writes it, the launch and the residual read it)");
+   const int npair = p1 ? PAC_PAIRS : PAC_PAIRS_GEO;
+   if (ctx->pa_c && ctx->pac_pairs != npair) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec_records: compact records of another shape exist");
    if (!ctx->pa_c) {
-      ctx->pac_pairs = PAC_PAIRS;
-      EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa_c, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 2 * PAC_PAIRS * PA_BLK * sizeof(double)));
-      EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa_c, 0, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 2 * PAC_PAIRS * PA_BLK * sizeof(double), S(s)));
+      ctx->pac_pairs = npair;
+      EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa_c, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 2 * npair * PA_BLK * sizeof(double)));
+      EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa_c, 0, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 2 * npair * PA_BLK * sizeof(double), S(s)));
    }
-   const int rc = exa_launch_model_setup_rec(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, S(s));
+   const int rc = p2 ? exa_launch_model_setup_p2(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, nullptr, true, S(s))
+                     : exa_launch_model_setup_rec(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, S(s));
    if (rc == EXA_OK) { ctx->have_grad = true; ctx->emat_valid = false; ctx->grad_records_only = true; }
    return rc;
 }

@@ -40,6 +40,7 @@ struct exa_ctx {
    double* T1_dev = nullptr;                // p = 2 matrix-free action: one-dimensional basis tables (3 x 6)
    double* eDS = nullptr;                   // B-bar: element-average shape gradient [block][n x 3][64 lanes]
    double* tbuf = nullptr;                  // generic PA action: per-point T (3,3,Q,E)
+   double* vgrad_ref = nullptr;             // p = 2 element-blocked constitutive launch: reference-space velocity gradients of its geometry pre-pass (3,3,Q,E)
    const double* resid_J = nullptr; const double* resid_S = nullptr;   // B-bar residual reads J and sigma at apply time, like the reference
    bool ea_generic = false;
    bool ea_matfree = false, emat_valid = false;   // EA, p = 2: L-vector action computed from the point records, matrices assembled on demand

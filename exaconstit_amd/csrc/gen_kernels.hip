@@ -395,6 +395,70 @@ __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const doubl
 }
 #undef P2X
 
+// ---- geometry pre-pass of the p = 2 constitutive launch ---------------------------------------------------------------------------------------------
+// The fused p = 2 launch lets every quadrature point gather its element's 27 nodes itself: 27 points x 162 gathered values per element, each behind a
+// connectivity load, in front of every wave's arithmetic (round 5: ~1.2 ms of a 2.6 ms launch at 64^3; SQ counters round 6: VALU busy 61 %, waiting 44 %,
+// 1 245 B/point at the L2 boundary against 920 algorithmic).  Here one lane owns one ELEMENT: it gathers the 27 nodes once per field and component,
+// contracts them towards all 27 points by sum factorisation (i, then j and k per point row) and writes, per point, the Jacobian J(i,j) = dx_i/dxi_j and
+// the reference-space velocity gradient dv_c/dxi_d, both (3,3,Q,E) element-blocked - 512-byte rows per value.  The constitutive launch then reads
+// 18 doubles per point (k_model_setup, VG) instead of 189 scattered ones.  Same multiply-add nesting as p2::gather: the Jacobians carry the bits of the fused form.
+__global__ __launch_bounds__(PA_BLK) void k_geom_p2(const int E, const double* __restrict__ T1, const double* __restrict__ xl, const double* __restrict__ vl,
+                                                    const int32_t* __restrict__ conn, const int nnodes, double* __restrict__ Jout, double* __restrict__ Lxout) {
+   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   if (e >= E) return;
+   const cptr t1 = as_const(T1);
+   double B[3][3], D[3][3];   // [1D point][1D node] (wave-uniform: scalar registers)
+#pragma unroll
+   for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) { B[q][i] = t1[6 * q + i]; D[q][i] = t1[6 * q + 3 + i]; }
+   int g[P2N];
+#pragma unroll
+   for (int a = 0; a < P2N; a++) g[a] = conn[a + P2N * e];
+#pragma unroll 1
+   for (int f = 0; f < 2; f++) {
+      const double* __restrict__ src = f == 0 ? xl : vl; double* __restrict__ out = f == 0 ? Jout : Lxout;
+      if (src == nullptr || out == nullptr) continue;   // (uniform)
+#pragma unroll 1
+      for (int c = 0; c < 3; c++) {
+         double X[27];
+#pragma unroll
+         for (int l = 0; l < 27; l++) X[l] = src[g[p2::NAT[l]] + (int64_t)nnodes * c];   // lexicographic l = i + 3 j + 9 k
+         double UB[3][9], UD[3][9];   // [qi][j + 3 k]
+#pragma unroll
+         for (int jk = 0; jk < 9; jk++) {
+            const double x0 = X[3 * jk], x1 = X[3 * jk + 1], x2 = X[3 * jk + 2];
+#pragma unroll
+            for (int qi = 0; qi < 3; qi++) {
+               UB[qi][jk] = fma(B[qi][2], x2, fma(B[qi][1], x1, B[qi][0] * x0));
+               UD[qi][jk] = fma(D[qi][2], x2, fma(D[qi][1], x1, D[qi][0] * x0));
+            }
+         }
+#pragma unroll
+         for (int qi = 0; qi < 3; qi++)
+#pragma unroll
+            for (int qj = 0; qj < 3; qj++) {
+               double bb[3], bd[3], db[3];
+#pragma unroll
+               for (int k = 0; k < 3; k++) {
+                  double a = 0.0, b = 0.0, d = 0.0;
+#pragma unroll
+                  for (int j = 0; j < 3; j++) { a = fma(B[qj][j], UB[qi][j + 3 * k], a); b = fma(D[qj][j], UB[qi][j + 3 * k], b); d = fma(B[qj][j], UD[qi][j + 3 * k], d); }
+                  bb[k] = a; bd[k] = b; db[k] = d;
+               }
+#pragma unroll
+               for (int qk = 0; qk < 3; qk++) {
+                  const int q = qi + 3 * qj + 9 * qk;
+                  double* o = out + (((blk * P2N + q) * 9 + c) << 6) + lane;      // entry (c, d) of the point at [(c + 3 d) * 64]
+                  o[0] = fma(B[qk][2], db[2], fma(B[qk][1], db[1], B[qk][0] * db[0]));
+                  o[3 * 64] = fma(B[qk][2], bd[2], fma(B[qk][1], bd[1], B[qk][0] * bd[0]));
+                  o[6 * 64] = fma(D[qk][2], bb[2], fma(D[qk][1], bb[1], D[qk][0] * bb[0]));
+               }
+            }
+      }
+   }
+}
+
 // ---- residual on L-vectors for p = 2, plain or B-bar (ExaNLFIntegrator / ICExaNLFIntegrator AssemblePA + AddMultPA fused with E->L) ---
 // y_a,c += sum_q W detJ B(-bar)_a,c . sigma.  One lane per element, points in sequence, y_e (81 doubles) in registers, the node
 // contraction as three one-dimensional passes (p2::scatter); 15 doubles per point from HBM, element-blocked or reference layout.
@@ -562,6 +626,19 @@ int exa_ensure_p2_tables(exa_ctx* ctx) {
    EXA_HIP_CHECK(ctx, hipMalloc(&ctx->T1_dev, sizeof(double) * t1.size()));
    EXA_HIP_CHECK(ctx, hipMemcpy(ctx->T1_dev, t1.data(), sizeof(double) * t1.size(), hipMemcpyHostToDevice));
    return EXA_OK;
+}
+// geometry pre-pass of the p = 2 constitutive launch on the element-blocked layout: J (and, with vl, the reference-space velocity gradient) for every point
+int exa_launch_geom_p2(exa_ctx* ctx, const double* xl, const double* vl, double* J, double* Lx, hipStream_t s) {
+   if (ctx->n != 27 || !ctx->qblk) { ctx->err = "geometry pre-pass: p = 2, element-blocked layout"; return EXA_ERR_UNSUPPORTED; }
+   if (int rc = exa_ensure_p2_tables(ctx)) return rc;
+   hipLaunchKernelGGL(k_geom_p2, dim3(nblk(ctx->E, PA_BLK)), dim3(PA_BLK), 0, s, ctx->E, ctx->T1_dev, xl, vl, ctx->conn, ctx->nnodes, J, Lx);
+   EXA_HIP_CHECK(ctx, hipGetLastError()); return EXA_OK;
+}
+// element-average gradients of the B-bar integrator from a Jacobian field (driver: the record route has no exa_grad_setup pass that would refresh them)
+int exa_grad_refresh_bbar(exa_ctx* ctx, const double* J, hipStream_t s) {
+   if (ctx->cfg.integ != EXA_INTEG_BBAR) return EXA_OK;
+   if (!ctx->eDS) EXA_HIP_CHECK(ctx, hipMalloc(&ctx->eDS, sizeof(double) * 3 * ctx->n * PA_BLK * (size_t)((ctx->E + PA_BLK - 1) / PA_BLK)));
+   return exa_launch_eds(ctx, J, s);
 }
 // residual on L-vectors at p = 2 (B-bar: element-average gradients refreshed from J first)
 int exa_launch_residual_p2(exa_ctx* ctx, const double* J, const double* S, double* y, hipStream_t s) {

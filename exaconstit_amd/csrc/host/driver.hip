@@ -24,6 +24,7 @@
 
 extern "C" const int* exa_model_fail_counter_dev(exa_ctx* ctx);
 extern "C" int exa_grad_apply_lvec_blocks(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, int blk0, int nblk, exa_stream s);
+int exa_grad_refresh_bbar(exa_ctx* ctx, const double* J, hipStream_t s);   // gen_kernels.hip (driver-internal)
 extern "C" int exa_grad_apply_lvec_gated(exa_ctx* ctx, const double* x, double* y, const uint8_t* mask, const double* gate, exa_stream s);
 
 
@@ -487,7 +488,10 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    // Gradient records straight from the constitutive launch (p = 1, compact form, identity "Jacobi" of the reference): no tangent field, no
    // defect check, no AssembleGradPA pass per Newton iteration.  EXA_TANGENT_RECORDS=off keeps the tangent field + exa_grad_setup (A/B switch);
    // true Jacobi needs the 46-double records for the diagonal and takes that route as well (SetPrecond).
-   records_setup_ = fast_p1_ && compact_tangent_ && fused_setup_ && !det && !env_is_off("EXA_TANGENT_RECORDS") &&
+   // p = 2 (round 6): the same behind the geometry pre-pass - the launch writes the 18-pair records of the matrix-free action (plain or B-bar, PA or EA)
+   const bool p2_records = part.p == 2 && !det && (opt.assembly == Assembly::PA || !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1")) &&
+                           !env_is_off("EXA_P2_PREPASS");
+   records_setup_ = (fast_p1_ || p2_records) && compact_tangent_ && fused_setup_ && !det && !env_is_off("EXA_TANGENT_RECORDS") &&
                     !(std::getenv("EXA_QLAYOUT") && std::string(std::getenv("EXA_QLAYOUT")) == "aos");
    geo_resid_ = !(std::getenv("EXA_JAC_FIELD") && std::string(std::getenv("EXA_JAC_FIELD")) == "on");   // A/B switch: the record route writes and reads the Jacobian field as before
    if (det) { abi_check(ctx_, exa_set_deterministic(ctx_, 1), "exa_set_deterministic"); comm_.deterministic = true; }
@@ -702,6 +706,8 @@ void NonlinearMechOperator::RefreshJacobians() {
 void NonlinearMechOperator::GetGradient() {
    if (use_records()) {   // the constitutive launch of the last residual evaluation wrote the records of this state; the action recomputes the geometry from x_cur
       abi_check(ctx_, exa_grad_set_coords(ctx_, x_cur.p), "exa_grad_set_coords");
+      // (B-bar, p = 2: the element-average gradients the action reads; the residual refreshes them as well, but GetUpdateBCsAction applies the gradient first)
+      if (!fast_p1_) abi_check(ctx_, exa_grad_refresh_bbar(ctx_, el_jac.p, stream_), "exa_grad_refresh_bbar");
       vk_jacobi_setup(nd_, ess_mask.p, diag.p, 1, dinv.p, stream_);
       return;
    }

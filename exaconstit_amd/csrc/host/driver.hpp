@@ -155,7 +155,7 @@ class NonlinearMechOperator {
    bool records_setup_ = false;   // gradient records written by the constitutive launch (p = 1 fast path, identity preconditioner)
    bool use_records() const { return records_setup_ && precond == Precond::IDENTITY; }
    bool geo_resid_ = true, jac_stale_ = false;   // record route + L-vector residual: no Jacobian field is written, both actions recompute the geometry (EXA_JAC_FIELD=on keeps it)
-   bool geo_resid() const { return geo_resid_ && lvec_resid_; }
+   bool geo_resid() const { return geo_resid_ && lvec_resid_ && fast_p1_; }      // (p = 2: the Jacobian field is written by the geometry pre-pass and read by the residual)
    void ensure_mat_grad();
    bool overlap_ = false; int nblk_bdr_ = 0;   // halo exchange overlapped with the interior element blocks (several ranks, atomic p = 1 record action)
    bool fast_p1_ = true, lvec_grad_ = true, fused_setup_ = true; bool lvec_resid_ = false; bool compact_tangent_ = false;

@@ -54,7 +54,7 @@ __device__ __forceinline__ void stg2r(double* p, const double a, const double b)
 // stores nothing: all 64 lanes take part in every round.  The dense launches of a tail split run the SAME kernel (tail_mode, so that a listed point is
 // finished with the bits the full launch would have given it): their lanes are scattered points, which read their inputs per lane, write their
 // output rows into the stage like everybody and copy them out per lane.
-template <bool QB, bool REC, bool STG = false>
+template <bool QB, bool REC, bool STG = false, int NPAIR = PAC_PAIRS>
 struct PointIO {
    const double* state0; const double* stress0; double* state1; double* stress1; double* cmat;   // kernel-uniform array bases
    double* stash0;                  // LDS stash of the block
@@ -125,7 +125,7 @@ struct PointIO {
    // REC: the lane's first 16-byte pair of its compact record ([block][q][13 pairs][64 lanes][2]); else the tangent slot
    __device__ __forceinline__ double* cm() const {
       if (STG) return wreg() + (tid & 31) * RS_T;      // (lanes l and l + 32 use the row one after the other)
-      return REC ? cmat + pac_off<PAC_PAIRS>(e >> 6, Q, q, 0) + 2 * (e & 63) : cmat + qview<QB>(36, Q, e, q).base;
+      return REC ? cmat + pac_off<NPAIR>(e >> 6, Q, q, 0) + 2 * (e & 63) : cmat + qview<QB>(36, Q, e, q).base;
    }
    // slot s of this thread at stash()[s * ECM_STASH_STRIDE]: regions of ECM_STASH_STRIDE lanes, one behind the other
    __device__ __forceinline__ double* stash() const { return stash0 + (tid / ECM_STASH_STRIDE) * (ecmdev::ST_SLOTS * ECM_STASH_STRIDE) + (tid % ECM_STASH_STRIDE); }
@@ -185,7 +185,12 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
    // tail: list this launch works on (tail_mode) or appends to; tail_out: list a tail launch appends the points to that it cuts off itself
    // (second level); rs_in / rs_out: solver states of the listed points, [RS_N][P] by list slot (nullptr: a listed point starts over)
    if (!tail_out) tail_out = tail;
-   static_assert(!REC || (LVEC && QB && NFIX == 8), "record output is built for the fused element-blocked p = 1 launch");
+   // VG (p = 2, element-blocked): the geometry comes from the pre-pass (gen_kernels.hip, k_geom_p2) - Jio holds the Jacobians (input), `vel` the reference-space
+   // velocity gradients dv_c/dxi_d, both (3,3,Q,E) - instead of 189 scattered loads per point.  With REC the launch writes the p = 2 record of the matrix-free
+   // action (18 pairs: D, K, then adj(J) and W detJ - the latter five pairs right here in the prologue, where J is at hand).
+   constexpr bool VG = !LVEC && NFIX == 27;
+   static_assert(!VG || QB, "velocity-gradient input: element-blocked layout");
+   static_assert(!REC || (QB && ((LVEC && NFIX == 8) || VG)), "record output is built for the fused element-blocked p = 1 launch and the p = 2 launch behind its geometry pre-pass");
    static_assert(!STG || (!QB && !REC && NFIX != 27), "staged rows: reference layout, tangent output, generic or trilinear node loops");
    const int tail_mode = tail_mode_rt;
    if (tail_mode && (int64_t)blockIdx.x * blockDim.x >= tail[0]) return;   // tail launch: its grid covers the worst case, blocks beyond the list leave before the table fill
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
       if (t >= tail[0]) return;
       if (rs_in) rs_in += t;   // this point's slot
    }
-   PointIO<QB, REC, STG> io{ state0, stress0, state1, stress1, cmat, sG + tab, tail, tail_mode, Q, bidx, wpb, 0, 0, 0, P, true };
+   PointIO<QB, REC, STG, (NFIX == 27) ? PAC_PAIRS_GEO : PAC_PAIRS> io{ state0, stress0, state1, stress1, cmat, sG + tab, tail, tail_mode, Q, bidx, wpb, 0, 0, 0, P, true };
    io.locate(threadIdx.x);
    const int q = io.q; const int64_t e = io.e;
    if (STG && !tail_mode) { if (io.nvalid() <= 0) return; }   // (wave-uniform: none of the wave's points exists)
@@ -283,7 +288,35 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
    double J11, J21, J31, J12, J22, J32, J13, J23, J33;
    double tsc = 0.0;   // REC: dt W_q / detJ
    double L[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-   if constexpr (P2F) {
+   if constexpr (VG) {
+      const double* Jq = Jio + vJ.base; const double* Lq = vel + vJ.base;
+      J11 = ecmdev::ldg(Jq); J21 = ecmdev::ldg(Jq + QS); J31 = ecmdev::ldg(Jq + 2 * QS); J12 = ecmdev::ldg(Jq + 3 * QS); J22 = ecmdev::ldg(Jq + 4 * QS); J32 = ecmdev::ldg(Jq + 5 * QS);
+      J13 = ecmdev::ldg(Jq + 6 * QS); J23 = ecmdev::ldg(Jq + 7 * QS); J33 = ecmdev::ldg(Jq + 8 * QS);
+      double gv[9];   // gv[c + 3 d] = dv_c/dxi_d
+#pragma unroll
+      for (int i = 0; i < 9; i++) gv[i] = ecmdev::ldg(Lq + i * QS);
+      // adj(J) exactly as AssembleGradPA stores it (pa_kernels.hip, adj_det)
+      const double a0 = J22 * J33 - J23 * J32, a1 = J32 * J13 - J12 * J33, a2 = J12 * J23 - J22 * J13;
+      const double a3 = J31 * J23 - J21 * J33, a4 = J11 * J33 - J13 * J31, a5 = J21 * J13 - J11 * J23;
+      const double a6 = J21 * J32 - J31 * J22, a7 = J31 * J12 - J11 * J32, a8 = J11 * J22 - J12 * J21;
+      const double detJ = J11 * (J22 * J33 - J32 * J23) - J21 * (J12 * J33 - J32 * J13) + J31 * (J12 * J23 - J22 * J13);
+      const double di = 1.0 / detJ;
+      if constexpr (REC) {
+         const int qu = tail_mode ? q : __builtin_amdgcn_readfirstlane(q);
+         const double wq = tail_mode ? Wq[q] : p2::as_const(Wq)[qu];
+         tsc = dt * wq * di;
+         double2* rc = reinterpret_cast<double2*>(io.cm());
+         ecmdev::stg2(&rc[13 * 64], a0, a1); ecmdev::stg2(&rc[14 * 64], a2, a3); ecmdev::stg2(&rc[15 * 64], a4, a5); ecmdev::stg2(&rc[16 * 64], a6, a7);
+         ecmdev::stg2(&rc[17 * 64], a8, wq * (J11 * a0 + J21 * a1 + J31 * a2));      // W detJ with detJ as adj_det forms it
+      }
+      const double Ji[3][3] = { { di * (J22 * J33 - J23 * J32), di * (J32 * J13 - J12 * J33), di * (J12 * J23 - J22 * J13) },
+                                { di * (J31 * J23 - J21 * J33), di * (J11 * J33 - J13 * J31), di * (J21 * J13 - J11 * J23) },
+                                { di * (J21 * J32 - J31 * J22), di * (J31 * J12 - J11 * J32), di * (J11 * J22 - J12 * J21) } };
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+         for (int t = 0; t < 3; t++) L[c + 3 * t] = gv[c] * Ji[0][t] + gv[c + 3] * Ji[1][t] + gv[c + 6] * Ji[2][t];
+   } else if constexpr (P2F) {
       static_assert(!P2F || LVEC, "the triquadratic fused path gathers from L-vectors");
       // both node contractions as three one-dimensional passes (p2_basis.hpp); q is wave-uniform except in the tail launch
       const int qu = (QB && !tail_mode) ? __builtin_amdgcn_readfirstlane(q) : q;

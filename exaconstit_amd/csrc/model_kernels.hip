@@ -9,6 +9,7 @@
 #include "model_kernel.hpp"
 
 int exa_launch_model_setup_aos(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, hipStream_t);   // model_kernels_aos.hip
+int exa_launch_model_setup_p2(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, bool, hipStream_t);   // model_kernels_p2.hip
 
 template <bool QB>
 __global__ void k_init_state(const int Q, const int64_t P, const double* __restrict__ hist, const double* __restrict__ quats, double* __restrict__ state0) {
@@ -195,6 +196,12 @@ int exa_launch_model_setup(exa_ctx* ctx, double dt, double* J, const double* vel
       if (int rc = exa_prepare_tail_lists(ctx, s)) return rc;
    }
    const bool lv = xl != nullptr;
+   // p = 2, element-blocked, L-vector form: geometry pre-pass + point launch on its velocity gradients (model_kernels_p2.hip); EXA_P2_PREPASS=off keeps the
+   // launch in which every point gathers its element's 27 nodes (A/B switch)
+   if (lv && ctx->n == 27 && J != nullptr) {
+      const char* e = std::getenv("EXA_P2_PREPASS");
+      if (!(e && std::strcmp(e, "off") == 0)) return exa_launch_model_setup_p2(ctx, dt, J, vel, xl, stress0, state0, stress1, state1, cmat, false, s);
+   }
    if (lv && ctx->n == 27) { if (int rc = exa_ensure_p2_tables(ctx)) return rc; }
    switch (ctx->mp.kin) {
       case KIN_VOCE:
