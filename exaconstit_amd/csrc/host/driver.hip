@@ -87,8 +87,8 @@ struct LoopbackGroup {
    std::vector<std::vector<int>> nbr_rank;               // [rank][slot] neighbour rank
    // stream-asynchronous exchange (Comm::exchange): "my send buffer is packed" / "I have read my neighbours' send buffers", recorded by every rank
    // on its own stream and waited for by its peers' streams - the host threads only meet to know that the events have been recorded
-   std::vector<hipEvent_t> ev_packed, ev_read; std::vector<char> ev_read_valid;
-   explicit LoopbackGroup(int n_) : n(n_), red(n_), sendbuf(n_), nbr_rank(n_), ev_packed(n_, nullptr), ev_read(n_, nullptr), ev_read_valid(n_, 0) {}
+   std::vector<hipEvent_t> ev_packed, ev_read;
+   explicit LoopbackGroup(int n_) : n(n_), red(n_), sendbuf(n_), nbr_rank(n_), ev_packed(n_, nullptr), ev_read(n_, nullptr) {}
    ~LoopbackGroup() { for (hipEvent_t e : ev_packed) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : ev_read) if (e) (void)hipEventDestroy(e); }
    void barrier() {
       std::unique_lock<std::mutex> lk(m);
@@ -204,6 +204,10 @@ void Comm::init(int rank_, int nranks_, const void* uid, bool force_rccl) {
    rank = rank_; nranks = nranks_;
    // EXA_FORCE_RCCL=1 routes the one-rank case through RCCL too (plumbing check on a single-GPU box)
    force_ = (nranks == 1 && (force_rccl || std::getenv("EXA_FORCE_RCCL") != nullptr));
+   // EXA_HALO_SELFTEST=1 (with the forced one-rank communicator): the rank is its own neighbour across its x-max face (SystemDriver adds the entry) and sends
+   // ZEROS of the real halo size to itself - the grouped ncclSend / ncclRecv of an exchange, on the communication stream beside the interior blocks when the
+   // overlapped form is on, between the all-reduces of the PCG on the main stream: the two-stream use of one communicator on the hardware there is
+   selftest_zero_ = force_ && std::getenv("EXA_HALO_SELFTEST") != nullptr;
    if (uid && std::memcmp(uid, kLoopMagic, 8) == 0) {
       LoopbackGroup* g; std::memcpy(&g, (const char*)uid + 8, sizeof(g));
       if (g->n != nranks) throw std::runtime_error("Comm::init: loopback group size mismatch");
@@ -319,6 +323,7 @@ void Comm::setup_halo(const Partition& part) {
 void Comm::halo_sum(const Partition& part, double* y, hipStream_t s) {
    if (nranks == 1 && !force_) return;
    vk_pack((int64_t)seg_off_.back(), idx_all_.p, y, sbuf_all_.p, s);
+   if (selftest_zero_) EXA_HC(hipMemsetAsync(sbuf_all_.p, 0, sizeof(double) * seg_off_.back(), s));
    exchange(part, s);
    unpack(y, s);
 }
@@ -332,6 +337,7 @@ void Comm::halo_begin(const Partition& part, double* y, hipStream_t s) {
    EXA_HC(hipEventRecord(ev_ready_, s));
    EXA_HC(hipStreamWaitEvent(cs_, ev_ready_, 0));
    vk_pack((int64_t)seg_off_.back(), idx_all_.p, y, sbuf_all_.p, cs_);
+   if (selftest_zero_) EXA_HC(hipMemsetAsync(sbuf_all_.p, 0, sizeof(double) * seg_off_.back(), cs_));
    exchange(part, cs_);
    EXA_HC(hipEventRecord(ev_done_, cs_));
 }
@@ -372,7 +378,7 @@ void Comm::exchange(const Partition& part, hipStream_t s) {
       if (loop_async_) {
          // Stream-asynchronous form (default; EXA_LOOPBACK_SYNC=1 keeps the host-synchronous one): NO stream is drained.  Every rank records
          // "packed" on its stream, its peers' streams wait for that event before they copy, every rank records "read" behind its copies and a
-         // rank's NEXT pack waits for its neighbours' "read" (issued by the pack's caller through wait_peers_read).  The host threads meet twice
+         // rank's NEXT pack waits for its neighbours' "read" (the waits at the end of this function, on the stream of this exchange).  The host threads meet twice
          // per exchange only so that an event is recorded before somebody waits for it - the device work of all ranks stays in flight, which is
          // how the overlapped halo (halo_begin / halo_end: cs_, ev_ready_, ev_done_) runs over RCCL.
          if (!g->ev_packed[rank]) { EXA_HC(hipEventCreateWithFlags(&g->ev_packed[rank], hipEventDisableTiming)); EXA_HC(hipEventCreateWithFlags(&g->ev_read[rank], hipEventDisableTiming)); }
@@ -382,7 +388,7 @@ void Comm::exchange(const Partition& part, hipStream_t s) {
             EXA_HC(hipStreamWaitEvent(s, g->ev_packed[part.nbrs[i].rank], 0));
             EXA_HC(hipMemcpyAsync(rb(i), peer_src(i), sizeof(double) * cnt(i), hipMemcpyDeviceToDevice, s));
          }
-         EXA_HC(hipEventRecord(g->ev_read[rank], s)); g->ev_read_valid[rank] = 1;
+         EXA_HC(hipEventRecord(g->ev_read[rank], s));
          g->barrier();                                            // every rank's "read" is recorded
          // nobody repacks its send buffer before its readers are done: the stream that packs next is the stream of this exchange or a later one of
          // this rank - ordered behind these waits either way (halo_sum packs on s, halo_begin on cs_, and cs_ waits for ev_ready_ recorded on s)
@@ -836,12 +842,23 @@ static void load_case_data(const ExaOptions& opt, const Partition& part, std::ve
 
 SystemDriver::~SystemDriver() { drop_cg_graph(); }
 
+// EXA_HALO_SELFTEST (Comm::init): the one rank lists itself as neighbour with the dofs of the nodes on its x-max face - (N + 1)^2 nodes x 3 components, the
+// size of a face exchange of a block decomposition - so that every halo_sum / halo_begin of a solve runs a real grouped send / receive (of zeros) over RCCL
+static void add_selftest_neighbour(Partition& part, const Comm& comm) {
+   if (!comm.selftest() || !part.nbrs.empty()) return;
+   double xmax = -1e300; for (int g = 0; g < part.NN; g++) xmax = std::max(xmax, part.X[g]);
+   Neighbor nb; nb.rank = comm.rank;
+   for (int c = 0; c < 3; c++) for (int g = 0; g < part.NN; g++) if (part.X[g] >= xmax - 1e-12) nb.dofs.push_back(g + part.NN * c);
+   part.nbrs.push_back(nb);
+}
+
 SystemDriver::SystemDriver(const ExaOptions& opt, int rank, int nranks, const void* uid) : opt_(opt) {
    comm.init(rank, nranks, uid);
    if (opt.mesh_type == "auto") {
       const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
       part.build(N, opt.length, rank, nranks, opt.order);
    } else part.build_from_mfem_mesh(opt.resolve(opt.mesh_file), rank, nranks, opt.order);
+   add_selftest_neighbour(part, comm);
    if (opt.order == 1) part.order_boundary_first();   // several ranks: elements at shared nodes first (exchange overlapped with the interior, GradMult)
    std::vector<double> props, quats; load_case_data(opt, part, props, quats);
    init(props, quats);
@@ -851,6 +868,7 @@ SystemDriver::SystemDriver(const ExaOptions& opt, const std::vector<double>& pro
    comm.init(rank, nranks, uid);
    const int f = 1 << opt.ref_ser; const int N[3] = { opt.ncuts[0] * f, opt.ncuts[1] * f, opt.ncuts[2] * f };
    part.build(N, opt.length, rank, nranks, opt.order);
+   add_selftest_neighbour(part, comm);
    if (opt.order == 1) part.order_boundary_first();
    std::vector<double> quats((size_t)4 * part.E);
    for (int e = 0; e < part.E; e++) for (int q = 0; q < 4; q++) quats[4 * (size_t)e + q] = quats_global[4 * (size_t)part.elem_gid[e] + q];

@@ -49,11 +49,13 @@ class Comm {
    void microbench(int iters, int n, double* us_allreduce, double* us_sendrecv);
    bool deterministic = false;               // halo contributions added segment by segment (fixed order) instead of one atomic pass
    size_t halo_dofs() const { return seg_off_.back(); }   // doubles this rank sends (= receives) per exchange, all neighbours
+   bool selftest() const { return selftest_zero_; }   // EXA_HALO_SELFTEST: the forced one-rank communicator exchanges zeros with itself (driver.hip, Comm::init)
    bool forced() const { return force_; }   // EXA_FORCE_RCCL=1: the one-rank communicator runs the multi-rank code paths and every RCCL call
  private:
    void unpack(double* y, hipStream_t s);
    void loopback_reduce(double* dev, int n, int op, hipStream_t s);
    void* comm_ = nullptr; void* loop_ = nullptr; void* ipc_ = nullptr; bool force_ = false;
+   bool selftest_zero_ = false;
    bool loop_async_ = false;   // loopback: exchanges ordered by events only, no stream is drained (driver.hip, Comm::exchange)
    DevBuf<int32_t> idx_all_; DevBuf<double> sbuf_all_, rbuf_all_; std::vector<size_t> seg_off_{ 0 };   // concatenated neighbour segments
    DevBuf<double> tmp_;

@@ -43,7 +43,7 @@ def main():
     comm_ranks, transport = d.comm_info()
     if rank == 0:
         with open(out, "w") as f:
-            json.dump(dict(ok=bool(ok), world=world, comm_ranks=comm_ranks, transport=transport, forced=bool(os.environ.get("EXA_FORCE_RCCL")), avg_stress=s.tolist(),
+            json.dump(dict(ok=bool(ok), world=world, comm_ranks=comm_ranks, transport=transport, forced=bool(os.environ.get("EXA_FORCE_RCCL")), avg_stress=s.tolist(), comm=d.comm_details(),
                            newton=[int(x) for x in newton], krylov=[int(x) for x in krylov]), f)
     d.close()
     if world > 1:

@@ -45,6 +45,24 @@ def test_forced_rccl_on_one_rank(oracle, tmp_path, case, jacobi):
     assert all(abs(x - y) <= max(3, 0.03 * x) for x, y in zip(plain["krylov"], forced["krylov"]))
 
 
+@pytest.mark.parametrize("overlap", ["on", "off"])
+def test_forced_rccl_self_exchange(oracle, tmp_path, overlap):
+    """EXA_HALO_SELFTEST=1 with the forced one-rank communicator: the rank is its own neighbour across its x-max face and every halo exchange of the solve is
+    a grouped ncclSend / ncclRecv of zeros of the real face size to itself - with EXA_HALO_OVERLAP=on issued on the communication stream while the interior
+    element blocks run on the main stream, between the fused all-reduces of the PCG on the main stream: the two-stream use of ONE communicator that the
+    overlapped halo makes of RCCL on several GPUs, executed on the hardware a one-GPU box has (reference coupling sites: src/mechanics_operator_ext.cpp:149-157
+    for the exchange, src/system_driver.cpp:167 for the dot products).  Zeros added to the shared dofs: the answers are the plain run's."""
+    n = 4
+    plain = _worker(tmp_path, "plain", "voce_pa", n)
+    st = _worker(tmp_path, "selftest", "voce_pa", n, {"EXA_FORCE_RCCL": "1", "EXA_HALO_SELFTEST": "1", "EXA_HALO_OVERLAP": overlap})
+    assert plain["ok"] and st["ok"] and st["forced"] and st["transport"] == "rccl"
+    assert st["comm"]["neighbours"] == 1 and st["comm"]["halo_bytes_per_exchange"] > 0 and st["comm"]["halo_overlap"] == (overlap == "on")
+    a, b = np.array(plain["avg_stress"]), np.array(st["avg_stress"])
+    assert np.max(np.abs(a - b)) < 1e-7 * np.abs(a).max()
+    assert plain["newton"] == st["newton"]
+    assert all(abs(x - y) <= max(3, 0.03 * x) for x, y in zip(plain["krylov"], st["krylov"]))
+
+
 def test_two_ranks_two_processes(oracle, tmp_path):
     """torchrun --nproc-per-node 2: two processes, TCP rendez-vous of torch beside this library's communicator, per-rank device mapping.  With
     two GPUs the ranks talk over RCCL; on a one-GPU box RCCL refuses the second rank on the device, and the same launch goes through the
