@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 #include <cstdint>
+#include <cstdlib>
 #include "../../include/exaconstit_hip.h"
 #include "ecm_device.hpp"
 
@@ -109,14 +110,20 @@ static inline size_t exa_qf_doubles(const exa_ctx* ctx, int vdim) {
 #ifndef EXA_APPLY_NT
 #define EXA_APPLY_NT 1
 #endif
+template <bool NT = (EXA_APPLY_NT != 0)>
 __device__ __forceinline__ double2 ld_rec(const double2* p) {
-#if EXA_APPLY_NT
-   typedef double vd2 __attribute__((ext_vector_type(2)));
-   const vd2 v = __builtin_nontemporal_load(reinterpret_cast<const vd2*>(p));
-   return make_double2(v.x, v.y);
-#else
-   return *p;
-#endif
+   if constexpr (NT) {
+      typedef double vd2 __attribute__((ext_vector_type(2)));
+      const vd2 v = __builtin_nontemporal_load(reinterpret_cast<const vd2*>(p));
+      return make_double2(v.x, v.y);
+   } else return *p;
+}
+// ... when the stream is larger than the caches can hold from one launch to the next.  Round 6, same call, PCG iterations/s with the hints | without: 16^3 (7 MB of
+// compact records) 40 226 | 42 137, 32^3 (54 MB) 30 469 | 31 393, 64^3 (436 MB) 8 494 | 7 738: a small partition's records and vectors live in L2 / MALL across
+// iterations and the hint throws that away.  The p = 1 action and the PCG vector kernels therefore carry it only above this size (EXA_NT_MIN_MB overrides; 0 = always)
+static inline bool exa_stream_nt(size_t bytes_per_launch) {
+   static const double min_mb = [] { const char* e = std::getenv("EXA_NT_MIN_MB"); return e ? std::atof(e) : 128.0; }();
+   return EXA_APPLY_NT != 0 && (double)bytes_per_launch >= min_mb * 1048576.0;
 }
 // ---- compact tangent form (include/exaconstit_hip.h, EXA_TANGENT_DEV5_BULK) ----------------------------------------------------
 // d sigma / d eps = V65 D V65^T + K m m^T: a 5 x 5 block in ExaCMech's deviatoric vector basis plus the bulk term, m = (1,1,1,0,0,0).

@@ -148,9 +148,13 @@ int exa_bootstrap_gather_reply(int rank, int nranks, const void* mine, int nbyte
             std::vector<char> theirs((size_t)nbytes);
             try {
                recv_all(fd, hello, sizeof(hello));
-               if (hello[0] != kMagic || hello[1] == 0 || hello[1] >= (uint32_t)nranks || hello[2] != (uint32_t)nbytes) continue;      // not one of ours
+               if (hello[0] != kMagic || hello[1] == 0 || hello[1] >= (uint32_t)nranks) continue;      // not one of ours
+               if (hello[2] != (uint32_t)nbytes)      // one of ours, but it speaks another record size (another build of the library): say so instead of letting it time out
+                  throw std::logic_error("rank " + std::to_string(hello[1]) + " contributes " + std::to_string(hello[2]) + " bytes where rank 0 expects " + std::to_string(nbytes) +
+                                         " (ranks running different builds of libexaconstit_hip?)");
                if (nbytes > 0) recv_all(fd, theirs.data(), (size_t)nbytes);
-            } catch (...) { continue; }                // a peer that went away does not end the rendez-vous
+            } catch (const std::logic_error&) { throw; }
+            catch (...) { continue; }                // a peer that went away does not end the rendez-vous
             if (nbytes > 0) std::memcpy(table.data() + (size_t)hello[1] * (size_t)nbytes, theirs.data(), (size_t)nbytes);
             if (peer_fd[hello[1]] >= 0) ::close(peer_fd[hello[1]]); else arrived++;      // (a rank that retries is kept once)
             peer_fd[hello[1]] = fd; fd_guard.fd = -1;

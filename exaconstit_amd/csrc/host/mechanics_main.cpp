@@ -12,9 +12,16 @@
 #include "../../../include/exaconstit_driver.h"
 
 int main(int argc, char** argv) {
-   // Hosts whose kernel driver offers dmabuf IPC only (this pool's): without this setting RCCL and hipIpcGetMemHandle fail between processes.  Set before
-   // the HIP runtime comes up (first HIP call: exa_bootstrap), never overriding what the user exported.
-   ::setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+   // Several ranks on hosts whose kernel driver offers dmabuf IPC only (this pool's): without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL and hipIpcGetMemHandle fail between
+   // processes.  Set before the HIP runtime comes up (first HIP call: exa_bootstrap), for multi-rank launches only, never overriding what the user exported, and
+   // said once on stderr (a host where only the legacy mode works wants HSA_ENABLE_IPC_MODE_LEGACY=1 exported instead: INTEGRATION.md, "Without MFEM").
+   {
+      int r0 = 0, n0 = 1, l0 = 0;
+      if (exa_bootstrap_env(&r0, &n0, &l0) == 0 && n0 > 1 && std::getenv("HSA_ENABLE_IPC_MODE_LEGACY") == nullptr) {
+         ::setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+         if (r0 == 0) std::fprintf(stderr, "mechanics: %d ranks, HSA_ENABLE_IPC_MODE_LEGACY was unset: running with 0 (dmabuf IPC)\n", n0);
+      }
+   }
    std::string opt = "options.toml";
    for (int i = 1; i < argc; i++) if ((!std::strcmp(argv[i], "-opt") || !std::strcmp(argv[i], "--option")) && i + 1 < argc) opt = argv[++i];
    char err[512] = { 0 };

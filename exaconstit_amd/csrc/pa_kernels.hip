@@ -213,7 +213,7 @@ __device__ __forceinline__ int64_t xcd_block(const unsigned b, const unsigned nb
    return x < r ? (int64_t)x * (q + 1) + i : (int64_t)r * (q + 1) + (int64_t)(x - r) * q + i;
 }
 
-template <bool LVEC, bool GEO, bool CMP = false, bool TRANS = false>
+template <bool LVEC, bool GEO, bool CMP = false, bool TRANS = false, bool NT = true>
 __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const double* __restrict__ pa, const double* __restrict__ x, double* __restrict__ y,
                                                           const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
                                                           const double* __restrict__ gate, const double* __restrict__ coords, double* __restrict__ ev = nullptr,
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
       const double2* rec = reinterpret_cast<const double2*>(pa + (CMP ? pac_off<PAC_PAIRS>(blk, 8, q, 0) : pa_off(blk, 8, q, 0))) + lane;
       double v[PA_SLOTS];
 #pragma unroll
-      for (int pr = 0; pr < (CMP ? PAC_PAIRS : (GEO ? 18 : PA_PAIRS)); pr++) { const double2 t = ld_rec(&rec[pr * PA_BLK]); v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
+      for (int pr = 0; pr < (CMP ? PAC_PAIRS : (GEO ? 18 : PA_PAIRS)); pr++) { const double2 t = ld_rec<NT>(&rec[pr * PA_BLK]); v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
       if (GEO) {   // J(i,j) = sum_a x_a,i dN_a/dxi_j, then adj(J) exactly as grad_setup stored it
          double Jl[9];
 #pragma unroll
@@ -700,7 +700,10 @@ int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec
    if (!(lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS)) { if (int rc = pa_full_on_demand(ctx, s)) return rc; }   // every other form streams the 46-double records
    double* ev = nullptr;
    if (lvec && ctx->det) { if (int rc = exa_det_prepare(ctx)) return rc; ev = ctx->ev_det; }
-#define GA_LAUNCH(G, CM, T, REC, CRD) hipLaunchKernelGGL((k_grad_apply_p1<true, G, CM, T>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, REC, x, y, ctx->conn, ctx->nnodes, mask, gate, CRD, ev, blk0)
+   // record stream of this launch: non-temporal loads only when it is larger than what the caches keep from one launch to the next (exa_internal.hpp, exa_stream_nt)
+   const bool nt = exa_stream_nt((size_t)ctx->P * 16 * ((lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) ? PAC_PAIRS : ((lvec && ctx->coords_lvec) ? 18 : PA_PAIRS)));
+#define GA_LAUNCH(G, CM, T, REC, CRD) do { if (nt) hipLaunchKernelGGL((k_grad_apply_p1<true, G, CM, T, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, REC, x, y, ctx->conn, ctx->nnodes, mask, gate, CRD, ev, blk0); \
+      else hipLaunchKernelGGL((k_grad_apply_p1<true, G, CM, T, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, REC, x, y, ctx->conn, ctx->nnodes, mask, gate, CRD, ev, blk0); } while (0)
    const double* none = nullptr;
    if (lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) GA_LAUNCH(true, true, false, ctx->pa_c, ctx->coords_lvec);   // D or D^T in the record
    else if (lvec && ctx->coords_lvec) { if (trans) GA_LAUNCH(true, false, true, ctx->pa, ctx->coords_lvec); else GA_LAUNCH(true, false, false, ctx->pa, ctx->coords_lvec); }

@@ -116,7 +116,7 @@ __global__ void k_reduce_cg(int nb, const double* __restrict__ partial, double* 
 #ifndef EXA_CG_X_NT
 #define EXA_CG_X_NT 1
 #endif
-template <bool IDENT>
+template <bool IDENT, bool XNT = (EXA_CG_X_NT != 0)>
 __global__ void k_cg_step1(int64_t n, int64_t nn, const double* __restrict__ S, const double* __restrict__ w, const double* __restrict__ dinv,
                            const double* __restrict__ d, double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial) {
    __shared__ double sm[RBLK];
@@ -124,11 +124,8 @@ __global__ void k_cg_step1(int64_t n, int64_t nn, const double* __restrict__ S, 
    const double alpha = S[4];
    double acc = 0;
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-#if EXA_CG_X_NT
-      __builtin_nontemporal_store(__builtin_nontemporal_load(&x[i]) + alpha * d[i], &x[i]);      // x is touched once per iteration: it need not displace d, r, z from the caches
-#else
-      x[i] += alpha * d[i];
-#endif
+      if constexpr (XNT) __builtin_nontemporal_store(__builtin_nontemporal_load(&x[i]) + alpha * d[i], &x[i]);      // x is touched once per iteration: it need not displace d, r, z from the caches
+      else x[i] += alpha * d[i];      // (small systems: every vector stays cached from one iteration to the next, vk_x_nt)
       const double ri = r[i] - alpha * z[i];
       r[i] = ri;
       const double zi = IDENT ? ri : dinv[i] * ri;
@@ -176,7 +173,7 @@ __global__ void k_cg2_scalars(double* S, double max_iter) {               // new
    S[5] = beta; S[4] = gn / den; S[0] = gn;
 }
 // p = u + beta p; q = s + beta q; x += alpha p; r -= alpha q; u = dinv r; s = 0 (the operator action that follows accumulates into it)
-template <bool IDENT>
+template <bool IDENT, bool XNT = (EXA_CG_X_NT != 0)>
 __global__ void k_cg2_update(int64_t n, const double* __restrict__ S, const double* __restrict__ dinv, double* __restrict__ x, double* __restrict__ r,
                              double* __restrict__ u, double* __restrict__ p, double* __restrict__ sv, double* __restrict__ q) {
    if (S[6] != 0.0) return;
@@ -185,11 +182,8 @@ __global__ void k_cg2_update(int64_t n, const double* __restrict__ S, const doub
       const double ui = IDENT ? r[i] : u[i];
       const double pi = ui + beta * p[i], qi = sv[i] + beta * q[i];
       p[i] = pi; q[i] = qi;
-#if EXA_CG_X_NT
-      __builtin_nontemporal_store(__builtin_nontemporal_load(&x[i]) + alpha * pi, &x[i]);      // (x and q are touched once per iteration: see k_cg_step1)
-#else
-      x[i] += alpha * pi;
-#endif
+      if constexpr (XNT) __builtin_nontemporal_store(__builtin_nontemporal_load(&x[i]) + alpha * pi, &x[i]);      // (x and q are touched once per iteration: see k_cg_step1)
+      else x[i] += alpha * pi;
       const double ri = r[i] - alpha * qi;
       r[i] = ri;
       if (!IDENT) u[i] = dinv[i] * ri;
@@ -344,7 +338,16 @@ void vk_jacobi_setup(int64_t n, const uint8_t* m, const double* diag, int identi
 void vk_pointwise(int64_t n, const double* a, const double* b, double* y, hipStream_t s) { hipLaunchKernelGGL(k_pointwise, dim3(nblk(n)), dim3(256), 0, s, n, a, b, y); }
 void vk_fill_if(int64_t n, const double* flag, double val, double* y, hipStream_t s) { hipLaunchKernelGGL(k_fill_if, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, flag, val, y); }
 // local part of the weighted dot: result in out[0] (device)
+// non-temporal update of the solution vector only when the six vectors of an iteration do not stay cached anyway (exa_internal.hpp, exa_stream_nt: 64^3 and up;
+// measured with the record stream's hint in one A/B, see there)
+static inline bool vk_x_nt(int64_t n) {
+   static const double min_mb = [] { const char* e = std::getenv("EXA_NT_MIN_MB"); return e ? std::atof(e) : 128.0; }();
+   return EXA_CG_X_NT != 0 && (double)n * 8.0 * 6.0 >= min_mb * 1048576.0 * 0.25;
+}
+// (node_of: the weighted sums take a byNODES vector of at most three components)
+static inline void check_3nn(int64_t n, int64_t nn) { if (n > 3 * nn) throw std::invalid_argument("weighted vector kernels: n must not exceed 3 * nn (byNODES, three components)"); }
 void vk_dot(int64_t n, int64_t nn, const double* w, const double* a, const double* b, const double* flag, double* partial, double* out, hipStream_t s) {
+   check_3nn(n, nn);
    const unsigned nb = gblk(n);
    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(RBLK), 0, s, n, nn, w, a, b, flag, partial);
    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out);
@@ -363,6 +366,7 @@ void vk_cg_step2z(int64_t n, const double* S, double* z, const double* r, double
    else hipLaunchKernelGGL(k_cg_step2z<false>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, r, d);
 }
 void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* a, double* b, const double* flag, double* partial, double* out, hipStream_t s, double* fuse_den_S) {
+   check_3nn(n, nn);
    const unsigned nb = gblk(n);
    hipLaunchKernelGGL(k_mask_dot_partial, dim3(nb), dim3(RBLK), 0, s, n, nn, w, m, a, b, flag, partial);
    if (fuse_den_S) hipLaunchKernelGGL(k_reduce_cg<2>, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, fuse_den_S, 0.0);
@@ -382,21 +386,25 @@ void vk_cg_beta(double* S, int max_iter, hipStream_t s) { hipLaunchKernelGGL(k_c
 // fuse_beta: one rank, the reduction also performs the beta update (no vk_cg_beta launch afterwards)
 void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, bool ident,
                  bool fuse_beta, int max_iter, hipStream_t s) {
+   check_3nn(n, nn);
    const unsigned nb = gblk(n);
-   if (ident) hipLaunchKernelGGL(k_cg_step1<true>, dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial);
-   else hipLaunchKernelGGL(k_cg_step1<false>, dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial);
+   const bool xnt = vk_x_nt(n);
+   if (ident) { if (xnt) hipLaunchKernelGGL((k_cg_step1<true, true>), dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial); else hipLaunchKernelGGL((k_cg_step1<true, false>), dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial); }
+   else { if (xnt) hipLaunchKernelGGL((k_cg_step1<false, true>), dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial); else hipLaunchKernelGGL((k_cg_step1<false, false>), dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial); }
    if (fuse_beta) hipLaunchKernelGGL(k_reduce_cg<1>, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S, (double)max_iter);
    else hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S + 6, S + 8);
 }
 void vk_cg2_init(double* S, double rel, double abs_, hipStream_t s) { hipLaunchKernelGGL(k_cg2_init, dim3(1), dim3(1), 0, s, S, rel, abs_); }
 void vk_cg2_scalars(double* S, int max_iter, hipStream_t s) { hipLaunchKernelGGL(k_cg2_scalars, dim3(1), dim3(1), 0, s, S, (double)max_iter); }
 void vk_cg2_update(int64_t n, const double* S, const double* dinv, double* x, double* r, double* u, double* p, double* sv, double* q, bool ident, hipStream_t s) {
-   if (ident) hipLaunchKernelGGL(k_cg2_update<true>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, dinv, x, r, u, p, sv, q);
-   else hipLaunchKernelGGL(k_cg2_update<false>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, dinv, x, r, u, p, sv, q);
+   const bool xnt = vk_x_nt(n);
+   if (ident) { if (xnt) hipLaunchKernelGGL((k_cg2_update<true, true>), dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, dinv, x, r, u, p, sv, q); else hipLaunchKernelGGL((k_cg2_update<true, false>), dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, dinv, x, r, u, p, sv, q); }
+   else { if (xnt) hipLaunchKernelGGL((k_cg2_update<false, true>), dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, dinv, x, r, u, p, sv, q); else hipLaunchKernelGGL((k_cg2_update<false, false>), dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, dinv, x, r, u, p, sv, q); }
 }
 // local parts of (r, u)_w and (s, u)_w -> out2[0..1] (device); masks the essential rows of s on the way
 void vk_cg2_dots(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* r, const double* u, double* sv, const double* flag, double* partial, double* out2,
                  bool ident, hipStream_t s) {
+   check_3nn(n, nn);
    const unsigned nb = gblk(n) < (unsigned)(DOT_BLOCKS / 2) ? gblk(n) : (unsigned)(DOT_BLOCKS / 2);
    if (ident) hipLaunchKernelGGL(k_cg2_dots<true>, dim3(nb), dim3(RBLK), 0, s, n, nn, w, m, r, u, sv, flag, partial);
    else hipLaunchKernelGGL(k_cg2_dots<false>, dim3(nb), dim3(RBLK), 0, s, n, nn, w, m, r, u, sv, flag, partial);
