@@ -413,6 +413,12 @@ def main():
                                              "frac": APPLY_MOVED_BYTES_COMPACT * Pq / (ar["lvec_apply_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "ratio_to_driver_route": ar["lvec_apply_ms"] / ar["driver_route_apply_ms"]},
                               "residual_ms": ar["lvec_residual_ms"],
+                              "fused_records": {"what": "HipExaModelLVec(.., fused_records = true): exa_model_setup_lvec_records on the reference layout - state and stress rows staged, the "
+                                                        "compact records of the action written by the launch instead of the tangent field; no exa_grad_setup pass",
+                                                "avg_kernel_ms": ar["lvec_records_model_ms"], "qpt_updates_per_s": Pq / (ar["lvec_records_model_ms"] * 1e-3),
+                                                "frac": MODEL_BYTES_PER_QPT * Pq / (ar["lvec_records_model_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "ratio_to_driver_route": ar["lvec_records_model_ms"] / ar["driver_route_model_ms"],
+                                                "stress_max_rel_diff": ar["lvec_records_stress_rel_diff"], "action_max_rel_diff": ar["lvec_records_action_rel_diff"]},
                               "stress_max_rel_diff": ar["lvec_stress_rel_diff"], "action_max_rel_diff": ar["lvec_action_rel_diff"]},
                 "parity_with_driver_route": {"stress_max_rel_diff": ar["stress_rel_diff"], "state_max_rel_diff": ar["state_rel_diff"], "action_max_rel_diff": ar["action_rel_diff"],
                                              "points_with_another_evaluation_count": ar["nfev_differing"],

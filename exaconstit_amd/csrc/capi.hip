@@ -7,6 +7,7 @@
 int exa_launch_model_setup(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, hipStream_t);
 int exa_launch_model_setup_rec(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
 int exa_launch_model_setup_p2(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, double*, bool, hipStream_t);
+int exa_launch_model_setup_aos_rec(exa_ctx*, double, double*, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
 int exa_launch_init_state(exa_ctx*, double*, const double*, const double*, hipStream_t);
 int exa_launch_state_normalize(exa_ctx*, double*, hipStream_t);
 int exa_launch_nfev_hist(exa_ctx*, const double*, int*, hipStream_t);
@@ -152,8 +153,8 @@ int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* x_lvec, 
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec_records: call exa_set_connectivity first");
    if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: dt must be positive");
    const bool p1 = ctx->p == 1 && ctx->cfg.integ == EXA_INTEG_FULL, p2 = ctx->p == 2;      // p = 2: plain or B-bar, behind the geometry pre-pass (a Jacobian field is part of it)
-   if (!(p1 || p2) || !ctx->qblk || ctx->tangent_form != EXA_TANGENT_DEV5_BULK || !(ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree))
-      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_model_setup_lvec_records: needs p = 1 full integration or p = 2, the element-blocked layout, the compact tangent form and PA or matrix-free EA");
+   if (!(p1 || p2) || (!ctx->qblk && !p1) || ctx->tangent_form != EXA_TANGENT_DEV5_BULK || !(ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree))
+      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_model_setup_lvec_records: needs p = 1 full integration (either layout) or p = 2 (element-blocked layout), the compact tangent form and PA or matrix-free EA");
    if (p2 && !J_out) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec_records: at p = 2 the Jacobian field is not optional (the pre-pass writes it, the launch and the residual read it)");
    const int npair = p1 ? PAC_PAIRS : PAC_PAIRS_GEO;
    if (ctx->pa_c && ctx->pac_pairs != npair) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec_records: compact records of another shape exist");
@@ -163,6 +164,7 @@ int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* x_lvec, 
       EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa_c, 0, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 2 * npair * PA_BLK * sizeof(double), S(s)));
    }
    const int rc = p2 ? exa_launch_model_setup_p2(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, nullptr, true, S(s))
+                     : !ctx->qblk ? exa_launch_model_setup_aos_rec(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, S(s))
                      : exa_launch_model_setup_rec(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, S(s));
    if (rc == EXA_OK) { ctx->have_grad = true; ctx->emat_valid = false; ctx->grad_records_only = true; }
    return rc;

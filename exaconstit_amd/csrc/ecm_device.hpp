@@ -1456,7 +1456,8 @@ ECM_DI void staged_tangent(const IO& io, double* cmat, Emit&& emit) {
 template <int KIN, int QS, bool REC = false, bool STG = false, class IO>
 ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io, const int kcap, const PointIn& pin,
                         const double* pq_lds = nullptr, const double tsc = 0.0, const bool trd = false, const TailIO tio = TailIO()) {
-   static_assert(!STG || (QS == 1 && !REC && ECM_STASH_STRIDE == 64 && ECM_EPI_NO_LOADS && ECM_TANGENT_FIRST && ECM_KM_GDOT_AT_END), "staged outputs: AOS rows, per-wave stash regions, tangent first");
+   // (STG with REC: state and stress rows staged, the compact record written by each lane straight to its slot of the element-blocked record array)
+   static_assert(!STG || (QS == 1 && ECM_STASH_STRIDE == 64 && ECM_EPI_NO_LOADS && ECM_TANGENT_FIRST && ECM_KM_GDOT_AT_END), "staged outputs: AOS rows, per-wave stash regions, tangent first");
    bool cut = false;   // STG: handed over to the dense launch (the lane stays for the wave's stores; what it writes the dense launch overwrites)
    const bool resume = tio.rs_in != nullptr;
    const double* __restrict__ sv0 = io.sv0();
@@ -1710,8 +1711,10 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
    const double hu_keep = ECM_CD(CD_HU), deff_keep = ECM_CD(CD_DEFF);      // (STG: read again in write_state_staged, not carried)
    double wrk_new = 0.0;   // s_new . D' in the lattice frame of the converged evaluation (the inner product of the 5-vectors is frame-invariant)
    for (int k = 0; k < 5; k++) wrk_new += s_lat[k] * J.dl[k];
+   [[maybe_unused]] double rsc_keep = 0.0;
    if constexpr (STG) {   // see ST_EPI_*
-      static_assert(ST_EPI_Q1 == ST_CD + CD_TSC && ST_EPI_Q2 == ST_PB + PB_SCI && ST_EPI_Q3 == ST_PB + PB_DETVRI && ST_EPI_WRK == ST_CD + CD_BULK && !REC, "dead slots");
+      static_assert(ST_EPI_Q1 == ST_CD + CD_TSC && ST_EPI_Q2 == ST_PB + PB_SCI && ST_EPI_Q3 == ST_PB + PB_DETVRI && ST_EPI_WRK == ST_CD + CD_BULK, "dead slots");
+      if constexpr (REC) rsc_keep = ECM_CD(CD_TSC);      // (the record scale sits where q[1] is about to be parked)
       for (int i = 0; i < 5; i++) ECM_ST(st, ST_EPI_E + i) = e_f[i];
       ECM_ST(st, ST_EPI_Q0) = qout[0]; ECM_ST(st, ST_EPI_Q1) = qout[1]; ECM_ST(st, ST_EPI_Q2) = qout[2]; ECM_ST(st, ST_EPI_Q3) = qout[3];
       ECM_ST(st, ST_EPI_WRK) = wrk_new;
@@ -1921,7 +1924,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
             for (int c = 0; c < 5; c++) { double v = 0; for (int l = 0; l < 5; l++) v += T1[k][l] * Q5[c][l]; D55[k][c] = v; }
       }
       if constexpr (REC) {
-         const double rsc = ECM_CD(CD_TSC);
+         const double rsc = STG ? rsc_keep : ECM_CD(CD_TSC);
          const double dsc = rsc * pb.dt_ri * (okT ? 1.0 : 0.0);
          double Dm[26];
 #pragma unroll
@@ -2063,7 +2066,7 @@ ECM_DI int point_update(const MatParams& mp, double dt, const double L[9], IO io
 #pragma unroll
          for (int c = 0; c < 5; c++) { double v = 0; for (int l = 0; l < 5; l++) v += Q5[k][l] * Llat[l][c]; T1[k][c] = v; }
       if constexpr (REC) {
-         const double rsc = ECM_CD(CD_TSC);
+         const double rsc = STG ? rsc_keep : ECM_CD(CD_TSC);
          const double dsc = rsc * pb.dt_ri * (okT ? 1.0 : 0.0);
          double Dm[26];
 #pragma unroll

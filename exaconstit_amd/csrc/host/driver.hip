@@ -497,8 +497,9 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    // p = 2 (round 6): the same behind the geometry pre-pass - the launch writes the 18-pair records of the matrix-free action (plain or B-bar, PA or EA)
    const bool p2_records = part.p == 2 && !det && (opt.assembly == Assembly::PA || !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1")) &&
                            !env_is_off("EXA_P2_PREPASS");
+   // (p = 1: on either layout - the reference layout through the staged launch; p = 2: element-blocked only)
    records_setup_ = (fast_p1_ || p2_records) && compact_tangent_ && fused_setup_ && !det && !env_is_off("EXA_TANGENT_RECORDS") &&
-                    !(std::getenv("EXA_QLAYOUT") && std::string(std::getenv("EXA_QLAYOUT")) == "aos");
+                    (fast_p1_ || !(std::getenv("EXA_QLAYOUT") && std::string(std::getenv("EXA_QLAYOUT")) == "aos"));
    geo_resid_ = !(std::getenv("EXA_JAC_FIELD") && std::string(std::getenv("EXA_JAC_FIELD")) == "on");   // A/B switch: the record route writes and reads the Jacobian field as before
    if (det) { abi_check(ctx_, exa_set_deterministic(ctx_, 1), "exa_set_deterministic"); comm_.deterministic = true; }
    abi_check(ctx_, exa_set_newton_caps(ctx_, newton_cap_, newton_cap2_, tail_resume_ ? 1 : 0), "exa_set_newton_caps");   // A/B switch for measurements; the fused launch is the product path

@@ -363,7 +363,9 @@ int exa_driver_bench_pcg(exa_driver* d, int iters, double* out, char* err, int e
 // and the L-vector pair (HipExaModelLVec / HipExaNLFIntegratorLVec) on the same context and quadrature functions:
 //   out[14] ms per exa_model_setup_lvec launch (gathers + Jacobians + update, AOS rows staged)      out[15] ms per exa_grad_apply_lvec (gather + action + scatter)
 //   out[16] max |stress1 - driver's| / max |stress1|          out[17] ms per exa_grad_setup with the compact tangent form
-//   out[18] max |K x - driver's K x| / max |K x|              out[19] ms per exa_residual_lvec                 out[20..23] 0
+//   out[18] max |K x - driver's K x| / max |K x|              out[19] ms per exa_residual_lvec
+//   out[20] ms per exa_model_setup_lvec_records on the reference layout (records instead of the tangent field: no exa_grad_setup)
+//   out[21] its max |stress1 - driver's| / max |stress1|      out[22] max |K x - driver's K x| / max |K x| of the action on its records      out[23] 0
 int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* out, char* err, int errlen) {
    try {
       SystemDriver& sd = *d->sd; NonlinearMechOperator& op = sd.oper();
@@ -466,6 +468,16 @@ int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* 
       {  ProfRegion prof(("adapter_route_lvec_apply[iters=" + std::to_string(iters) + "]").c_str());
          out[15] = timed(iters, [&] { chk(exa_grad_apply_lvec(ctxA, r.p, yA.p, nullptr, s), "exa_grad_apply_lvec"); }); }
       out[19] = timed(iters, [&] { chk(exa_residual_lvec(ctxA, J.p, s1.p, yA.p, s), "exa_residual_lvec"); });
+      // ... and with AssembleGradPA fused into ModelSetup (HipExaModelLVec(.., fused_records = true)): the compact records instead of the tangent field, no exa_grad_setup
+      auto model_rec = [&] { chk(exa_model_setup_lvec_records(ctxA, dt, op.x_cur.p, sd.v_sol.p, s0.p, sv0.p, s1.p, sv1.p, J.p, s), "exa_model_setup_lvec_records"); };
+      model_rec(); model_rec();
+      {  ProfRegion prof(("adapter_route_lvec_records[passes=" + std::to_string(steps) + "]").c_str());
+         out[20] = timed(steps, model_rec); }
+      if (exa_model_status(ctxA, s) != 0) throw std::runtime_error("exa_driver_bench_adapter_route: the record launch left unconverged points");
+      to_aos(6, op.stress1, tmp); out[21] = rel_diff(6 * P, s1.p, tmp.p);
+      EXA_HC(hipMemsetAsync(yA.p, 0, sizeof(double) * nd, s));
+      chk(exa_grad_apply_lvec(ctxA, r.p, yA.p, nullptr, s), "exa_grad_apply_lvec");
+      out[22] = rel_diff(nd, yA.p, yC.p);
       return 0;
    } catch (const std::exception& e) { set_err(err, errlen, e.what()); return -1; }
 }

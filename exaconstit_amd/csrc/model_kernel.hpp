@@ -62,7 +62,7 @@ struct PointIO {
    int Q; int64_t bidx; int wpb;    // points per element, (remapped) block index, waves per block
    int q; int64_t e; int tid;       // this thread's point and its index in the block
    int64_t P; bool live;            // STG: points of the launch; this lane's point exists
-   static_assert(!STG || (!QB && !REC && ECM_STASH_STRIDE == 64), "staged rows: AOS layout, per-wave stash regions");
+   static_assert(!STG || (!QB && ECM_STASH_STRIDE == 64), "staged rows: AOS layout, per-wave stash regions");
    __device__ __forceinline__ int wave() const { return STG ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6); }   // (STG: wave-uniform row addresses in scalar registers)
    __device__ __forceinline__ int64_t pt0() const { return (bidx * wpb + wave()) * 64; }
    __device__ __forceinline__ int nvalid() const { const int64_t r = P - pt0(); return r < 64 ? (int)r : 64; }   // points of this wave that exist (may be <= 0)
@@ -124,7 +124,7 @@ struct PointIO {
    __device__ __forceinline__ double* s1() const { return STG ? wreg() + 64 * RS_SV + (tid & 63) * RS_S : stress1 + qview<QB>(6, Q, e, q).base; }
    // REC: the lane's first 16-byte pair of its compact record ([block][q][13 pairs][64 lanes][2]); else the tangent slot
    __device__ __forceinline__ double* cm() const {
-      if (STG) return wreg() + (tid & 31) * RS_T;      // (lanes l and l + 32 use the row one after the other)
+      if (STG && !REC) return wreg() + (tid & 31) * RS_T;      // (lanes l and l + 32 use the row one after the other)
       return REC ? cmat + pac_off<NPAIR>(e >> 6, Q, q, 0) + 2 * (e & 63) : cmat + qview<QB>(36, Q, e, q).base;
    }
    // slot s of this thread at stash()[s * ECM_STASH_STRIDE]: regions of ECM_STASH_STRIDE lanes, one behind the other
@@ -190,8 +190,10 @@ __global__ __launch_bounds__(EXA_MODEL_BS, EXA_MODEL_OCC) void k_model_setup(con
    // action (18 pairs: D, K, then adj(J) and W detJ - the latter five pairs right here in the prologue, where J is at hand).
    constexpr bool VG = !LVEC && NFIX == 27;
    static_assert(!VG || QB, "velocity-gradient input: element-blocked layout");
-   static_assert(!REC || (QB && ((LVEC && NFIX == 8) || VG)), "record output is built for the fused element-blocked p = 1 launch and the p = 2 launch behind its geometry pre-pass");
-   static_assert(!STG || (!QB && !REC && NFIX != 27), "staged rows: reference layout, tangent output, generic or trilinear node loops");
+   // REC with STG (round 6): the fused p = 1 launch on the REFERENCE layout - state and stress rows staged, the record written per lane: for one pair the 8 points x
+   // 8 consecutive elements of a wave store 8 whole 128-byte lines of the record array ([block][q][pair][lane = element])
+   static_assert(!REC || (LVEC && NFIX == 8 && (QB || STG)) || (QB && VG), "record output: the fused p = 1 launches (element-blocked, or staged reference layout) and the p = 2 launch behind its geometry pre-pass");
+   static_assert(!STG || (!QB && NFIX != 27), "staged rows: reference layout, generic or trilinear node loops");
    const int tail_mode = tail_mode_rt;
    if (tail_mode && (int64_t)blockIdx.x * blockDim.x >= tail[0]) return;   // tail launch: its grid covers the worst case, blocks beyond the list leave before the table fill
    const int n = NFIX ? NFIX : n_rt;

@@ -324,7 +324,8 @@ class Driver:
         self._chk(exa_driver_bench_adapter_route(self.h, steps, iters, o.ctypes.data_as(C.POINTER(C.c_double)), self._err, 512))
         return dict(model_ms=o[0], pass_ms=o[1], geometry_ms=o[2], grad_setup_ms=o[3], grad_apply_ms=o[4], action_ms=o[5], stress_rel_diff=o[6], state_rel_diff=o[7],
                     action_rel_diff=o[8], failed=int(o[9]), driver_route_model_ms=o[10], driver_route_apply_ms=o[11], aos_staging=bool(o[12]), nfev_differing=int(o[13]),
-                    lvec_model_ms=o[14], lvec_apply_ms=o[15], lvec_stress_rel_diff=o[16], lvec_grad_setup_ms=o[17], lvec_action_rel_diff=o[18], lvec_residual_ms=o[19])
+                    lvec_model_ms=o[14], lvec_apply_ms=o[15], lvec_stress_rel_diff=o[16], lvec_grad_setup_ms=o[17], lvec_action_rel_diff=o[18], lvec_residual_ms=o[19],
+                    lvec_records_model_ms=o[20], lvec_records_stress_rel_diff=o[21], lvec_records_action_rel_diff=o[22])
 
     def bench_pcg(self, iters):
         import numpy as np

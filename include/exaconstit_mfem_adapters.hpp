@@ -143,12 +143,12 @@ class HipExaNLFIntegrator : public ExaNLFIntegrator {
 class HipExaModelLVec : public HipExaModel {
    mfem::Vector jac_;            // (3,3,Q,E) of the end-of-step configuration, written by the constitutive launch
    mfem::Array<int> conn_;       // (n, E) element -> node, ElementDofOrdering::NATIVE (src/mechanics_operator.cpp:228)
-   int nnodes_ = 0;
+   int nnodes_ = 0; bool fused_ = false;
  public:
    HipExaModelLVec(mfem::QuadratureFunction* q_stress0, mfem::QuadratureFunction* q_stress1, mfem::QuadratureFunction* q_matGrad,
                    mfem::QuadratureFunction* q_matVars0, mfem::QuadratureFunction* q_matVars1, mfem::ParGridFunction* beg_coords,
                    mfem::ParGridFunction* end_coords, mfem::Vector* props, int nProps, int nStateVars, double temp_k, int model_id,
-                   const mfem::FiniteElementSpace& fes, Assembly assembly_, bool bbar = false, bool check_local_solves = true)
+                   const mfem::FiniteElementSpace& fes, Assembly assembly_, bool bbar = false, bool check_local_solves = true, bool fused_records = false)
       : HipExaModel(q_stress0, q_stress1, q_matGrad, q_matVars0, q_matVars1, beg_coords, end_coords, props, nProps, nStateVars, temp_k, model_id,
                     fes.GetFE(0)->GetOrder(), fes.GetNE(), assembly_, bbar, check_local_solves) {
       const int n = exa_nodes_per_elem(ctx()), E = fes.GetNE();
@@ -164,14 +164,21 @@ class HipExaModelLVec : public HipExaModel {
       static_assert(sizeof(int) == sizeof(int32_t), "the connectivity table is 32-bit");
       EXA_ADAPTER_VERIFY(exa_set_connectivity(ctx(), conn_.Read(), nnodes_) == EXA_OK, exa_last_error(ctx()));
       jac_.SetSize(9 * exa_qpts_per_elem(ctx()) * E); jac_.UseDevice(true);
+      // fused_records (p = 1 full integration, the reference's identity "Jacobi"): ModelSetup writes the compact records the L-vector action streams instead of
+      // matGrad - AssembleGradPA rides in the constitutive launch and matGrad is NOT written; the diagonal and AssembleEA then have nothing to read
+      fused_ = fused_records;
+      if (fused_) EXA_ADAPTER_VERIFY(exa_set_tangent_form(ctx(), EXA_TANGENT_DEV5_BULK) == EXA_OK, exa_last_error(ctx()));
    }
+   bool FusedRecords() const { return fused_; }
    // vel: the velocity L-vector (3 * nnodes, byNODES).  jacobian and loc_grad are not read: the launch gathers end_coords and writes Jacobians().
    void ModelSetup(const int nqpts, const int /*nelems*/, const int /*space_dim*/, const int nnodes, const mfem::Vector& /*jacobian*/,
                    const mfem::Vector& /*loc_grad*/, const mfem::Vector& vel) override {
       EXA_ADAPTER_VERIFY(nqpts == exa_qpts_per_elem(ctx()) && nnodes == exa_nodes_per_elem(ctx()), "element order does not match the context");
       EXA_ADAPTER_VERIFY(vel.Size() == 3 * nnodes_ && end_coords->Size() == 3 * nnodes_, "HipExaModelLVec::ModelSetup takes the velocity L-vector");
-      int rc = exa_model_setup_lvec(ctx(), dt, end_coords->Read(), vel.Read(), stress0->Read(), matVars0->Read(), stress1->Write(), matVars1->Write(),
-                                    matGrad->Write(), jac_.Write(), nullptr);
+      int rc = fused_ ? exa_model_setup_lvec_records(ctx(), dt, end_coords->Read(), vel.Read(), stress0->Read(), matVars0->Read(), stress1->Write(), matVars1->Write(),
+                                                     jac_.Write(), nullptr)
+                      : exa_model_setup_lvec(ctx(), dt, end_coords->Read(), vel.Read(), stress0->Read(), matVars0->Read(), stress1->Write(), matVars1->Write(),
+                                             matGrad->Write(), jac_.Write(), nullptr);
       EXA_ADAPTER_VERIFY(rc >= EXA_OK, exa_last_error(ctx()));
       if (checks_local_solves()) {
          rc = exa_model_status(ctx(), nullptr);
@@ -189,6 +196,10 @@ class HipExaNLFIntegratorLVec : public ExaNLFIntegrator {
    mutable mfem::Vector ev_;         // E-vector scratch of the diagonal
    exa_ctx* ctx() const { return hmodel_->ctx(); }
    void GradSetup() {
+      if (hmodel_->FusedRecords()) {   // the records were written by ModelSetup; the action only needs the coordinates they belong to
+         EXA_ADAPTER_VERIFY(exa_grad_set_coords(ctx(), hmodel_->EndCoords()->Read()) == EXA_OK, exa_last_error(ctx()));
+         return;
+      }
       if (compact_) {                // valid for every ExaCMech tangent; a matGrad that is not of the form (another model behind the seam) switches it off for good
          double defect = 0.0;
          EXA_ADAPTER_VERIFY(exa_grad_tangent_defect(ctx(), model->GetMatGrad()->Read(), &defect, nullptr) == EXA_OK, exa_last_error(ctx()));
@@ -199,7 +210,7 @@ class HipExaNLFIntegratorLVec : public ExaNLFIntegrator {
       EXA_ADAPTER_VERIFY(exa_grad_set_coords(ctx(), hmodel_->EndCoords()->Read()) == EXA_OK, exa_last_error(ctx()));
    }
  public:
-   explicit HipExaNLFIntegratorLVec(HipExaModelLVec* m, bool compact_tangent = true) : ExaNLFIntegrator(m), hmodel_(m), compact_(compact_tangent) {
+   explicit HipExaNLFIntegratorLVec(HipExaModelLVec* m, bool compact_tangent = true) : ExaNLFIntegrator(m), hmodel_(m), compact_(compact_tangent || m->FusedRecords()) {
       if (compact_) EXA_ADAPTER_VERIFY(exa_set_tangent_form(ctx(), EXA_TANGENT_DEV5_BULK) == EXA_OK, exa_last_error(ctx()));
    }
    using ExaNLFIntegrator::AssemblePA;

@@ -103,7 +103,8 @@ def test_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, ea, order, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model,pfile,order,compact", [(0, "props_cp_voce.txt", 1, 1), (0, "props_cp_voce.txt", 1, 0), (5, "props_cp_mts.txt", 1, 1), (0, "props_cp_voce.txt", 2, 1)])
+@pytest.mark.parametrize("model,pfile,order,compact", [(0, "props_cp_voce.txt", 1, 1), (0, "props_cp_voce.txt", 1, 0), (5, "props_cp_mts.txt", 1, 1), (0, "props_cp_voce.txt", 2, 1),
+                                                        (0, "props_cp_voce.txt", 1, 3), (5, "props_cp_mts.txt", 1, 3)])
 def test_lvec_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, order, compact):
     """The L-vector pair (HipExaModelLVec / HipExaNLFIntegratorLVec): ModelSetup with the velocity L-vector, AddMultPA / AddMultGradPA / the diagonal on
     L-vectors, through base-class pointers of the mock - against the same sequence of direct C-ABI calls (constitutive outputs and Jacobians bit for bit;
@@ -129,7 +130,7 @@ def test_lvec_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, order,
     ctx = L.Context(model, props, 298.0, order, E)
     d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
     ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
-    if compact:
+    if compact & 1:
         ctx.check(L.exa_set_tangent_form(ctx.h, L.EXA_TANGENT_DEV5_BULK))
     d_sv0 = dev.zeros(28 * P); ctx.check(L.exa_init_state(ctx.h, ptr(d_sv0), ptr(dev.up(quats.ravel())), None))
     d_s0 = dev.zeros(6 * P); o = [dev.zeros(6 * P), dev.zeros(28 * P), dev.zeros(36 * P), dev.zeros(9 * P)]
@@ -161,11 +162,18 @@ def test_lvec_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, order,
     assert r.returncode == 0, r.stderr
     got = np.fromfile(fout, dtype=np.float64)
     off = 0
+    fused = bool(compact & 2)      # HipExaModelLVec(.., fused_records = true): ModelSetup = exa_model_setup_lvec_records, matGrad and the diagonal stay untouched
     for w, name in zip(want, ("stress1", "state1", "matGrad", "jacobians", "AddMultPA", "AddMultGradPA", "diagonal")):
         g = got[off:off + w.size]; off += w.size
         assert np.linalg.norm(w) > 0, name
-        if name in ("AddMultPA", "AddMultGradPA", "diagonal"):
+        if fused and name in ("matGrad", "diagonal"):
+            assert not g.any(), name
+        elif fused and name in ("stress1", "state1"):      # another instantiation of the kernel: round-off (evaluation counts equal)
+            if name == "state1":
+                assert np.array_equal(g.reshape(P, 28)[:, 3], w.reshape(P, 28)[:, 3])
             assert rel_l2(g, w) < 1e-13, (name, rel_l2(g, w))
+        elif name in ("AddMultPA", "AddMultGradPA", "diagonal"):
+            assert rel_l2(g, w) < (1e-12 if fused else 1e-13), (name, rel_l2(g, w))
         else:
             assert np.array_equal(g, w), (name, np.abs(g - w).max())
     assert off == got.size
