@@ -125,6 +125,16 @@ static inline bool exa_stream_nt(size_t bytes_per_launch) {
    static const double min_mb = [] { const char* e = std::getenv("EXA_NT_MIN_MB"); return e ? std::atof(e) : 128.0; }();
    return EXA_APPLY_NT != 0 && (double)bytes_per_launch >= min_mb * 1048576.0;
 }
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remapped, XCD x works on one contiguous eighth of the element blocks, so the node rows
+// neighbouring blocks share (gathers of x / coordinates, scatter atomics) stay within one L2 (p = 1 action since round 4; p = 2 action / residual / pre-pass: round 6)
+#ifndef EXA_XCD_REMAP
+#define EXA_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int64_t xcd_block(const unsigned b, const unsigned nb) {
+   if (!EXA_XCD_REMAP) return b;
+   const unsigned q = nb >> 3, r = nb & 7u, x = b & 7u, i = b >> 3;
+   return x < r ? (int64_t)x * (q + 1) + i : (int64_t)r * (q + 1) + (int64_t)(x - r) * q + i;
+}
 // ---- compact tangent form (include/exaconstit_hip.h, EXA_TANGENT_DEV5_BULK) ----------------------------------------------------
 // d sigma / d eps = V65 D V65^T + K m m^T: a 5 x 5 block in ExaCMech's deviatoric vector basis plus the bulk term, m = (1,1,1,0,0,0).
 constexpr int PAC_PAIRS = 13;       // compact record of the p = 1 action: 25 D entries + K, scaled by dt W / detJ

@@ -252,6 +252,11 @@ __global__ __launch_bounds__(PA_BLK) void k_ea_apply_rt(const int n, const int E
 // Software pipeline: the record of point q+1 is requested as soon as the record of point q is consumed and lands behind the two
 // long register-only passes (scatter of q, gather of q+1: 2 x 270 FMAs) - at one wave per SIMD nothing else hides it.
 constexpr int P2N = p2::N, P2ND = p2::ND, P2XL = 76;
+#ifndef EXA_P2_XCD
+#define EXA_P2_XCD 0   // p = 2 action / residual / geometry pre-pass with the element blocks dealt to the XCDs in contiguous eighths (exa_internal.hpp, xcd_block): measured at
+                       // 64^3 B-bar (round 6, same call, twice): action 0.589 | 0.589 ms with, 0.579 | 0.580 ms without - a block of 64 triquadratic elements shares few
+                       // nodes with the next one along x, and the round-robin order spreads the 7.8 KB record rows of a block over more channels.  Off (A/B switch)
+#endif
 using p2::cptr; using p2::as_const;
 typedef p2::Rows Rows1D;
 
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const doubl
                                                         const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
                                                         const double* __restrict__ gate) {
    __shared__ double sXall[P2XL * PA_BLK];
-   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   const int lane = threadIdx.x; const int64_t blk = EXA_P2_XCD ? xcd_block(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x; const int64_t e = blk * PA_BLK + lane;
    if (e >= E) return;
    if (gate != nullptr && gate[0] != 0.0) return;
    double* sX = sXall + lane;
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(PA_BLK) void k_mf_apply_p2(const int E, const doubl
 // 18 doubles per point (k_model_setup, VG) instead of 189 scattered ones.  Same multiply-add nesting as p2::gather: the Jacobians carry the bits of the fused form.
 __global__ __launch_bounds__(PA_BLK) void k_geom_p2(const int E, const double* __restrict__ T1, const double* __restrict__ xl, const double* __restrict__ vl,
                                                     const int32_t* __restrict__ conn, const int nnodes, double* __restrict__ Jout, double* __restrict__ Lxout) {
-   const int lane = threadIdx.x; const int64_t blk = blockIdx.x; const int64_t e = blk * PA_BLK + lane;
+   const int lane = threadIdx.x; const int64_t blk = EXA_P2_XCD ? xcd_block(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x; const int64_t e = blk * PA_BLK + lane;
    if (e >= E) return;
    const cptr t1 = as_const(T1);
    double B[3][3], D[3][3];   // [1D point][1D node] (wave-uniform: scalar registers)
@@ -466,7 +471,7 @@ template <bool BBAR, bool QB>
 __global__ __launch_bounds__(PA_BLK) void k_residual_p2(const int E, const double* __restrict__ T1, const double* __restrict__ W, const double* __restrict__ J,
                                                         const double* __restrict__ S, const double* __restrict__ eDS, double* __restrict__ y,
                                                         const int32_t* __restrict__ conn, const int nnodes) {
-   const int lane = threadIdx.x; const int64_t e = (int64_t)blockIdx.x * PA_BLK + lane;
+   const int lane = threadIdx.x; const int64_t e = (EXA_P2_XCD ? xcd_block(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x) * PA_BLK + lane;
    if (e >= E) return;
    double Y[P2ND];
 #pragma unroll

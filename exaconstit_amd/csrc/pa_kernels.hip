@@ -204,15 +204,6 @@ __global__ void k_tangent_defect(const int Q, const int64_t P, const double* __r
 // the element-assembly action without the 24 x 24 matrices.
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remapped, XCD x works on one contiguous eighth of the element
 // blocks, so the node rows neighbouring blocks share (gathers of x / coordinates, scatter atomics) stay within one L2.
-#ifndef EXA_XCD_REMAP
-#define EXA_XCD_REMAP 1
-#endif
-__device__ __forceinline__ int64_t xcd_block(const unsigned b, const unsigned nb) {
-   if (!EXA_XCD_REMAP) return b;
-   const unsigned q = nb >> 3, r = nb & 7u, x = b & 7u, i = b >> 3;
-   return x < r ? (int64_t)x * (q + 1) + i : (int64_t)r * (q + 1) + (int64_t)(x - r) * q + i;
-}
-
 template <bool LVEC, bool GEO, bool CMP = false, bool TRANS = false, bool NT = true>
 __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const double* __restrict__ pa, const double* __restrict__ x, double* __restrict__ y,
                                                           const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
