@@ -394,15 +394,16 @@ def main():
                                 "note": "frac = 928 B x qpts / kernel time / 8 TB/s (SURVEY 8(d)); this launch moves all of them (Jacobian field in, 36 tangent entries out); "
                                         "driver_route = exa_model_setup_lvec_records on the element-blocked layout (`value`)"},
                 "geometry_ms": ar["geometry_ms"],
-                "grad_setup": {"avg_kernel_ms": ar["grad_setup_ms"], "bytes_per_qpt": 8.0 * (36 + 9 + 46),
-                               "frac": 8.0 * (36 + 9 + 46) * Pq / (ar["grad_setup_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "note": "AssembleGradPA: reads tangent 36 + Jacobian 9, writes the 46-double record (the reference writes 81; the record route has no such pass)"},
+                "grad_setup": {"avg_kernel_ms": ar["grad_setup_ms"], "bytes_per_qpt": 8.0 * (36 + 9 + 36),
+                               "frac": 8.0 * (36 + 9 + 36) * Pq / (ar["grad_setup_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "AssembleGradPA: reads tangent 36 + Jacobian 9, writes the 36-double record (compact tangent 26 + adj(J) 9 + W detJ; the 46-double one "
+                                       "on demand for the diagonal; the reference writes 81; the record route has no such pass)"},
                 "grad_apply": {"avg_kernel_ms": ar["grad_apply_ms"], "bytes_per_qpt": APPLY_BYTES_PER_QPT,
                                "frac": APPLY_BYTES_PER_QPT * Pq / (ar["grad_apply_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "bytes_moved_per_qpt": 8.0 * (46 + 3 + 6), "frac_on_bytes_moved": 8.0 * 55 * Pq / (ar["grad_apply_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "bytes_moved_per_qpt": 8.0 * (36 + 3 + 6), "frac_on_bytes_moved": 8.0 * 45 * Pq / (ar["grad_apply_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "action_ms_with_restriction_and_transpose": ar["action_ms"],
                                "driver_route_action_ms": ar["driver_route_apply_ms"], "ratio_to_driver_route": ar["action_ms"] / ar["driver_route_apply_ms"],
-                               "note": "AddMultGradPA on E-vectors: 46-double record + x (24 / element) + y read and written; frac priced at SURVEY 8(d)'s 408 B/qpt; "
+                               "note": "AddMultGradPA on E-vectors: 36-double record (compact tangent + geometry) + x (24 / element) + y read and written; frac priced at SURVEY 8(d)'s 408 B/qpt; "
                                        "action = L->E + kernel + E->L, what an MFEM caller pays per PCG iteration"},
                 "lvec_pair": {"what": "HipExaModelLVec / HipExaNLFIntegratorLVec on the same AOS quadrature functions: exa_model_setup_lvec (node gathers + Jacobians + update in "
                                       "one launch, rows staged), exa_grad_setup with the compact tangent form, exa_grad_apply_lvec (gather + action + scatter-add), exa_residual_lvec",

@@ -276,9 +276,11 @@ static int assemble_ea(exa_ctx* ctx, hipStream_t s) {
 }
 
 int exa_set_tangent_form(exa_ctx* ctx, int form) {
-   if (!ctx || (form != EXA_TANGENT_FULL && form != EXA_TANGENT_DEV5_BULK)) return fail(ctx, EXA_ERR_ARG, "exa_set_tangent_form: bad argument");
+   if (!ctx || (form != EXA_TANGENT_FULL && form != EXA_TANGENT_DEV5_BULK && form != EXA_TANGENT_DEV5_BULK_GEO)) return fail(ctx, EXA_ERR_ARG, "exa_set_tangent_form: bad argument");
+   if (form == EXA_TANGENT_DEV5_BULK_GEO && !(ctx->p == 1 && ctx->cfg.integ == EXA_INTEG_FULL && ctx->cfg.assembly == EXA_ASSEMBLY_PA))
+      return fail(ctx, EXA_ERR_UNSUPPORTED, "exa_set_tangent_form: the compact record with geometry serves the E-vector action of p = 1 partial assembly");
+   if (form != ctx->tangent_form && ctx->pa_c) { (void)hipFree(ctx->pa_c); ctx->pa_c = nullptr; ctx->pac_pairs = 0; ctx->have_grad = false; }      // (records of another shape)
    ctx->tangent_form = form;
-   if (form == EXA_TANGENT_FULL && ctx->pa_c) { (void)hipFree(ctx->pa_c); ctx->pa_c = nullptr; ctx->pac_pairs = 0; }
    return EXA_OK;
 }
 
@@ -307,6 +309,10 @@ int exa_set_ea_matrix_free(exa_ctx* ctx, int on) {
 int exa_grad_setup(exa_ctx* ctx, double dt, const double* J, const double* C, exa_stream s) {
    if (!ctx || !J || !C) return fail(ctx, EXA_ERR_ARG, "exa_grad_setup: null pointer");
    if (!ctx->pa) { EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa, pa_bytes(ctx->E, ctx->Q))); EXA_HIP_CHECK(ctx, hipMemsetAsync(ctx->pa, 0, pa_bytes(ctx->E, ctx->Q), S(s))); }
+   if (ctx->tangent_form == EXA_TANGENT_DEV5_BULK_GEO && !ctx->pa_c) {
+      ctx->pac_pairs = PAC_PAIRS_GEO;
+      EXA_HIP_CHECK(ctx, hipMalloc(&ctx->pa_c, (size_t)((ctx->E + PA_BLK - 1) / PA_BLK) * ctx->Q * 2 * ctx->pac_pairs * PA_BLK * sizeof(double)));
+   }
    if (ctx->tangent_form == EXA_TANGENT_DEV5_BULK && !ctx->pa_c) {   // compact records for the actions that can stream them
       const bool p1 = ctx->p == 1 && ctx->cfg.integ == EXA_INTEG_FULL && (ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree);   // k_grad_apply_p1<.., GEO, CMP>
       const bool p2 = ctx->n == 27 && (ctx->cfg.assembly == EXA_ASSEMBLY_PA || ctx->ea_matfree);               // k_mf_apply_p2<.., CMP>

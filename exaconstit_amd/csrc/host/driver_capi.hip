@@ -430,7 +430,10 @@ int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* 
       };
       to_aos(6, op.stress1, tmp); out[6] = rel_diff(6 * P, s1.p, tmp.p);
       to_aos(28, op.matVars1, tmp); out[7] = rel_diff(28 * P, sv1.p, tmp.p, 28, 3); out[13] = (double)differing;   // slot 3 = the local solver's evaluation count
-      // AssembleGradPA
+      // AssembleGradPA (HipExaNLFIntegrator: the compact tangent + adj(J) records after its defect check)
+      {  double defect = 1.0; chk(exa_set_tangent_form(ctxA, EXA_TANGENT_DEV5_BULK_GEO), "exa_set_tangent_form");
+         chk(exa_grad_tangent_defect(ctxA, cm.p, &defect, s), "exa_grad_tangent_defect");
+         if (!(defect < 1e-11)) throw std::runtime_error("exa_driver_bench_adapter_route: tangent not of the compact form"); }
       chk(exa_grad_setup(ctxA, dt, J.p, cm.p, s), "exa_grad_setup");
       {  ProfRegion prof("adapter_route_grad_setup");
          out[3] = timed(3, [&] { chk(exa_grad_setup(ctxA, dt, J.p, cm.p, s), "exa_grad_setup"); }); }

@@ -204,7 +204,8 @@ __global__ void k_tangent_defect(const int Q, const int64_t P, const double* __r
 // the element-assembly action without the 24 x 24 matrices.
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remapped, XCD x works on one contiguous eighth of the element
 // blocks, so the node rows neighbouring blocks share (gathers of x / coordinates, scatter atomics) stay within one L2.
-template <bool LVEC, bool GEO, bool CMP = false, bool TRANS = false, bool NT = true>
+// CG (E-vector action without coordinates): the 18-pair record - compact tangent (D, K) + adj(J) + W detJ (EXA_TANGENT_DEV5_BULK_GEO).
+template <bool LVEC, bool GEO, bool CMP = false, bool TRANS = false, bool NT = true, bool CG = false>
 __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const double* __restrict__ pa, const double* __restrict__ x, double* __restrict__ y,
                                                           const int32_t* __restrict__ conn, const int nnodes, const uint8_t* __restrict__ mask,
                                                           const double* __restrict__ gate, const double* __restrict__ coords, double* __restrict__ ev = nullptr,
@@ -257,10 +258,11 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
 #pragma unroll
    for (int q = 0; q < 8; q++) {
       static_assert(!CMP || GEO, "the compact record carries no geometry");
-      const double2* rec = reinterpret_cast<const double2*>(pa + (CMP ? pac_off<PAC_PAIRS>(blk, 8, q, 0) : pa_off(blk, 8, q, 0))) + lane;
+      static_assert(!CG || (!GEO && !CMP && !TRANS), "the record with geometry is a form of its own");
+      const double2* rec = reinterpret_cast<const double2*>(pa + (CG ? pac_off<PAC_PAIRS_GEO>(blk, 8, q, 0) : (CMP ? pac_off<PAC_PAIRS>(blk, 8, q, 0) : pa_off(blk, 8, q, 0)))) + lane;
       double v[PA_SLOTS];
 #pragma unroll
-      for (int pr = 0; pr < (CMP ? PAC_PAIRS : (GEO ? 18 : PA_PAIRS)); pr++) { const double2 t = ld_rec<NT>(&rec[pr * PA_BLK]); v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
+      for (int pr = 0; pr < (CG ? PAC_PAIRS_GEO : (CMP ? PAC_PAIRS : (GEO ? 18 : PA_PAIRS))); pr++) { const double2 t = ld_rec<NT>(&rec[pr * PA_BLK]); v[2 * pr] = t.x; v[2 * pr + 1] = t.y; }
       if (GEO) {   // J(i,j) = sum_a x_a,i dN_a/dxi_j, then adj(J) exactly as grad_setup stored it
          double Jl[9];
 #pragma unroll
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
             for (int i = 0; i < 3; i++) { double t = 0; for (int a = 0; a < 8; a++) t += G1(a, j, q) * XC[i][a]; Jl[i + 3 * j] = t; }
          double dj; adj_det(Jl, v + 36, dj);
       }
-      const double* Ct = v; const double* adj = v + 36;
+      const double* Ct = v; const double* adj = v + (CG ? 26 : 36);
       // gx[c][j] = sum_a G(a,j,q) X[c][a]
       double gx[3][3];
 #pragma unroll
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(PA_BLK) void k_grad_apply_p1(const int E, const dou
       const double eps[6] = { h[0][0], h[1][1], h[2][2], h[1][2] + h[2][1], h[0][2] + h[2][0], h[0][1] + h[1][0] };
       double sg[6];
       static_assert(!(CMP && TRANS), "compact records are stored in the orientation the action needs");
-      if (CMP) d55_apply(v, v[25], eps, sg);
+      if (CMP || CG) d55_apply(v, v[25], eps, sg);
       else {
 #pragma unroll
          for (int i = 0; i < 6; i++) { double s = 0; for (int j = 0; j < 6; j++) s += (TRANS ? Ct[j + 6 * i] : Ct[i + 6 * j]) * eps[j]; sg[i] = s; }
@@ -673,6 +675,11 @@ int exa_launch_grad_setup_pa(exa_ctx* ctx, double dt, const double* J, const dou
       else hipLaunchKernelGGL((k_grad_setup_pa<false, PAC_PAIRS, false, false>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c);
       ctx->pa_lazy = true; ctx->lazy_J = J; ctx->lazy_C = C; ctx->lazy_dt = dt;
    }
+   else if (ctx->pa_c && ctx->pac_pairs == PAC_PAIRS_GEO && ctx->n == 8 && !trd && !lazy_off) {      // p = 1, E-vector action on the compact records with geometry: same scheme
+      if (ctx->qblk) hipLaunchKernelGGL((k_grad_setup_pa<true, PAC_PAIRS_GEO, false, false>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c);
+      else hipLaunchKernelGGL((k_grad_setup_pa<false, PAC_PAIRS_GEO, false, false>), grid, dim3(PA_BLK), 0, s, ctx->Q, ctx->E, dt, ctx->W_dev, J, C, ctx->pa, ctx->pa_c);
+      ctx->pa_lazy = true; ctx->lazy_J = J; ctx->lazy_C = C; ctx->lazy_dt = dt;
+   }
    else if (ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) { if (trd) GS_LAUNCH2(PAC_PAIRS, true); else GS_LAUNCH2(PAC_PAIRS, false); }
    else if (ctx->pa_c) { if (trd) GS_LAUNCH2(PAC_PAIRS_GEO, true); else GS_LAUNCH2(PAC_PAIRS_GEO, false); }
    else GS_LAUNCH2(0, false);
@@ -688,7 +695,9 @@ int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec
    const unsigned nb = ranged ? (unsigned)nblk_range : nball;
    if (!ranged) blk0 = 0;
    if (nb == 0) return EXA_OK;
-   if (!(lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS)) { if (int rc = pa_full_on_demand(ctx, s)) return rc; }   // every other form streams the 46-double records
+   if (!(lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) && !(!lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS_GEO && ctx->n == 8)) {
+      if (int rc = pa_full_on_demand(ctx, s)) return rc;   // every other form streams the 46-double records
+   }
    double* ev = nullptr;
    if (lvec && ctx->det) { if (int rc = exa_det_prepare(ctx)) return rc; ev = ctx->ev_det; }
    // record stream of this launch: non-temporal loads only when it is larger than what the caches keep from one launch to the next (exa_internal.hpp, exa_stream_nt)
@@ -699,6 +708,8 @@ int exa_launch_grad_apply_p1(exa_ctx* ctx, const double* x, double* y, bool lvec
    if (lvec && ctx->coords_lvec && ctx->pa_c && ctx->pac_pairs == PAC_PAIRS) GA_LAUNCH(true, true, false, ctx->pa_c, ctx->coords_lvec);   // D or D^T in the record
    else if (lvec && ctx->coords_lvec) { if (trans) GA_LAUNCH(true, false, true, ctx->pa, ctx->coords_lvec); else GA_LAUNCH(true, false, false, ctx->pa, ctx->coords_lvec); }
    else if (lvec) { if (trans) GA_LAUNCH(false, false, true, ctx->pa, none); else GA_LAUNCH(false, false, false, ctx->pa, none); }
+   else if (ctx->pa_c && ctx->pac_pairs == PAC_PAIRS_GEO && ctx->n == 8)      // E-vector action on the compact records with geometry
+      hipLaunchKernelGGL((k_grad_apply_p1<false, false, false, false, true, true>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa_c, x, y, ctx->conn, ctx->nnodes, mask, gate, none);
    else hipLaunchKernelGGL((k_grad_apply_p1<false, false>), dim3(nb), dim3(PA_BLK), 0, s, ctx->E, ctx->pa, x, y, ctx->conn, ctx->nnodes, mask, gate, none);
 #undef GA_LAUNCH
    EXA_HIP_CHECK(ctx, hipGetLastError());

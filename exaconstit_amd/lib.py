@@ -89,7 +89,7 @@ exa_grad_apply_lvec = _sig("exa_grad_apply_lvec", C.c_int, C.c_void_p, dptr, dpt
 exa_set_tangent_form = _sig("exa_set_tangent_form", C.c_int, C.c_void_p, C.c_int)
 exa_set_deterministic = _sig("exa_set_deterministic", C.c_int, C.c_void_p, C.c_int)
 exa_grad_tangent_defect = _sig("exa_grad_tangent_defect", C.c_int, C.c_void_p, dptr, C.POINTER(C.c_double), C.c_void_p)
-EXA_TANGENT_FULL, EXA_TANGENT_DEV5_BULK = 0, 1
+EXA_TANGENT_FULL, EXA_TANGENT_DEV5_BULK, EXA_TANGENT_DEV5_BULK_GEO = 0, 1, 2
 exa_set_ea_matrix_free = _sig("exa_set_ea_matrix_free", C.c_int, C.c_void_p, C.c_int)
 exa_grad_set_coords = _sig("exa_grad_set_coords", C.c_int, C.c_void_p, dptr)
 exa_residual_lvec = _sig("exa_residual_lvec", C.c_int, C.c_void_p, dptr, dptr, dptr, C.c_void_p)

@@ -238,8 +238,11 @@ int exa_grad_set_coords(exa_ctx* ctx, const double* coords_lvec_dev);
  *                          p = 1 partial assembly: exa_grad_setup then writes the compact records only (71 instead of 117 doubles moved per point); the
  *                          46-double records that exa_grad_diagonal, exa_grad_apply on E-vectors and an L-vector action without exa_grad_set_coords
  *                          read are built when one of them is first called, from the jacobian_dev / ddsdde_dev arrays of that exa_grad_setup - which
- *                          must therefore stay unchanged until then (they do within a Newton iteration). */
-enum { EXA_TANGENT_FULL = 0, EXA_TANGENT_DEV5_BULK = 1 };
+ *                          must therefore stay unchanged until then (they do within a Newton iteration).
+ *   EXA_TANGENT_DEV5_BULK_GEO  the same compact tangent with adj(J) and W detJ kept in the record (36 numbers, 18 pairs): for the E-vector action
+ *                          exa_grad_apply at p = 1 partial assembly, which has no nodal coordinates to recompute the geometry from - 360 instead of 440 bytes per
+ *                          point and action (what HipExaNLFIntegrator selects after the same defect check); the 46-double records are built on demand as above. */
+enum { EXA_TANGENT_FULL = 0, EXA_TANGENT_DEV5_BULK = 1, EXA_TANGENT_DEV5_BULK_GEO = 2 };
 int exa_set_tangent_form(exa_ctx* ctx, int form);
 int exa_grad_tangent_defect(exa_ctx* ctx, const double* ddsdde_dev, double* defect_host, exa_stream s);
 /* Element assembly without the element matrices: with `on` != 0 exa_grad_setup stops after the per-point records (and the

@@ -94,6 +94,8 @@ class HipExaModel : public ExaModel {
 // materialised, and the tangent in matGrad is already column-major (no transpose pass, cf. src/mechanics_ecmech.cpp:155-170).
 class HipExaNLFIntegrator : public ExaNLFIntegrator {
    HipExaModel* hmodel_;
+   bool compact_;              // p = 1 partial assembly: AddMultGradPA streams the tangent as its 5 x 5 deviatoric block + bulk term with adj(J) (EXA_TANGENT_DEV5_BULK_GEO:
+                               // 36 instead of 46 doubles per point), after a check of matGrad per AssembleGradPA; other contexts refuse the form and keep the full records
    mfem::Vector jac_;          // (3,3,Q,E)
    // geometric factors of the current (end-of-step) mesh nodes, re-laid-out as src/mechanics_integrators.cpp:225-238 does
    void RefreshJacobians(const mfem::FiniteElementSpace& fes) {
@@ -104,7 +106,8 @@ class HipExaNLFIntegrator : public ExaNLFIntegrator {
       EXA_ADAPTER_VERIFY(exa_jacobians_from_geom(hmodel_->ctx(), g->J.Read(), jac_.Write(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
    }
  public:
-   explicit HipExaNLFIntegrator(HipExaModel* m) : ExaNLFIntegrator(m), hmodel_(m) {}
+   explicit HipExaNLFIntegrator(HipExaModel* m, bool compact_tangent = true)
+      : ExaNLFIntegrator(m), hmodel_(m), compact_(compact_tangent && exa_set_tangent_form(m->ctx(), EXA_TANGENT_DEV5_BULK_GEO) == EXA_OK) {}
    using ExaNLFIntegrator::AssemblePA;
    void AssemblePA(const mfem::FiniteElementSpace& fes) override {                                   // src/mechanics_integrators.cpp:160-314
       RefreshJacobians(fes);
@@ -116,6 +119,11 @@ class HipExaNLFIntegrator : public ExaNLFIntegrator {
    void AssembleGradPA(const mfem::Vector& /*x*/, const mfem::FiniteElementSpace& fes) override { AssembleGradPA(fes); }
    void AssembleGradPA(const mfem::FiniteElementSpace& fes) override {                               // :331-513
       RefreshJacobians(fes);
+      if (compact_) {   // exact for every ExaCMech tangent; a matGrad of another form switches it off for good
+         double defect = 0.0;
+         EXA_ADAPTER_VERIFY(exa_grad_tangent_defect(hmodel_->ctx(), model->GetMatGrad()->Read(), &defect, nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
+         if (!(defect < 1e-11)) { compact_ = false; EXA_ADAPTER_VERIFY(exa_set_tangent_form(hmodel_->ctx(), EXA_TANGENT_FULL) == EXA_OK, exa_last_error(hmodel_->ctx())); }
+      }
       EXA_ADAPTER_VERIFY(exa_grad_setup(hmodel_->ctx(), model->GetModelDt(), jac_.Read(), model->GetMatGrad()->Read(), nullptr) == EXA_OK, exa_last_error(hmodel_->ctx()));
    }
    void AddMultGradPA(const mfem::Vector& x, mfem::Vector& y) const override {                       // :562-622

@@ -75,11 +75,23 @@ def test_adapters_forward_to_the_abi(oracle, tmp_path, model, pfile, ea, order, 
     yres, ygrad, diag = dev.zeros(3 * n * E), dev.zeros(3 * n * E), dev.zeros(3 * n * E)
     emat = dev.zeros(9 * n * n * E); dp = dev.zeros(9 * P); d_x = dev.up(x_act)
     ctx.check(L.exa_residual_setup(ctx.h, ptr(d_J), ptr(o[0]), None)); ctx.check(L.exa_residual_apply(ctx.h, ptr(yres), None))
+    # (what HipExaNLFIntegrator does: p = 1 partial assembly streams the compact tangent + adj(J) after the defect check; other contexts refuse the form)
+    if L.exa_set_tangent_form(ctx.h, L.EXA_TANGENT_DEV5_BULK_GEO) == L.EXA_OK:
+        assert order == 1 and not ea and not bbar
+        defect = C.c_double(1.0); ctx.check(L.exa_grad_tangent_defect(ctx.h, ptr(o[2]), C.byref(defect), None)); assert defect.value < 1e-11
+    else:
+        assert order != 1 or ea or bbar
     ctx.check(L.exa_grad_setup(ctx.h, dt, ptr(d_J), ptr(o[2]), None))
     if ea:
         ctx.check(L.exa_grad_get_ea(ctx.h, ptr(emat), None))
     else:
         ctx.check(L.exa_grad_apply(ctx.h, ptr(d_x), ptr(ygrad), None)); ctx.check(L.exa_grad_diagonal(ctx.h, ptr(diag), None))
+        if order == 1:   # the compact form against the oracle's TransformMatGradTo4D -> AssembleGradPA -> AddMultGradPA chain on the same tangent and Jacobians
+            cmh = o[2].cpu().numpy(); Jh = d_J.cpu().numpy(); C4 = np.zeros(81 * P); D4 = np.zeros(81 * P); ye = np.zeros(3 * n * E)
+            orc.lib().orc_transform_4d(C.c_int64(P), orc._p(cmh), orc._p(C4))
+            orc.lib().orc_assemble_grad_pa(Q, E, C.c_double(dt), orc._p(rve["W"]), orc._p(Jh), orc._p(C4), orc._p(D4))
+            orc.lib().orc_add_mult_grad_pa(Q, E, n, orc._p(rve["G"]), orc._p(D4), orc._p(x_act), orc._p(ye))
+            assert hipref.rel_l2(ygrad.cpu().numpy(), ye) < 1e-12
     ctx.check(L.exa_calc_dp(ctx.h, ptr(o[1]), ptr(dp), None))
     want = [t.cpu().numpy() for t in (o[0], o[1], o[2], yres, ygrad, diag, emat, dp)]
     ctx.close()
