@@ -525,9 +525,10 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    // is the A/B switch.  part.E_bdr > 0 only after Partition::order_boundary_first (SystemDriver).
    {
       const bool ea_rec = opt.assembly == Assembly::EA && !(std::getenv("EXA_EA_ASSEMBLED") && std::string(std::getenv("EXA_EA_ASSEMBLED")) == "1");
-      // Over RCCL the overlapped form is OPT-IN (EXA_HALO_OVERLAP=on) until a run on two or more GPUs has passed with it: it issues the grouped
-      // send/recv on a second stream of the communicator that carries the PCG all-reduces, and no box with two devices has been available to
-      // this repo yet (the shared-device transports exercise the stream / event choreography, not RCCL's two-stream behaviour)
+      // Over RCCL the overlapped form is OPT-IN (EXA_HALO_OVERLAP=on).  Round 6 ran it on the hardware a one-GPU box has - the forced one-rank communicator
+      // exchanging a face of the real size with itself (EXA_HALO_SELFTEST, tests/test_gpu_rccl.py): the grouped send/recv on the second stream between the
+      // all-reduces of the main stream works, but at 64^3 per rank it costs 162 us per PCG iteration against 141 us in line (profiles/r06_rccl_self_exchange.txt):
+      // two launches of the action and two cross-stream waits to hide a 24 us exchange.  A box with real xGMI neighbours has to show where the balance tips.
       const char* ho = std::getenv("EXA_HALO_OVERLAP");
       const bool want = ho ? std::string(ho) != "off" && std::string(ho) != "0" : std::string(comm.transport()) != "rccl";
       overlap_ = fast_p1_ && lvec_grad_ && !det && part.E_bdr > 0 && !part.nbrs.empty() && (opt.assembly == Assembly::PA || ea_rec) && want;
