@@ -187,12 +187,74 @@ def cpu_baseline(props, seconds_target=12.0, gpu_step=None):
                       f"in {elc:.1f} s with an OpenMP loop over all {cores} host threads (rtmodel=OPENMP analogue; `value`)"}
 
 
+def bench_order2(args, L, N, props, quats, mk, rank, world, fresh_uid, barrier, max_over_ranks):
+    """--order 2 [--bbar]: BASELINE config 5's shape (64^3 triquadratic hexahedra, element assembly, B-bar) in a line of the contract's form.  A step is one
+    constitutive pass over the RVE (geometry pre-pass + the fused p = 2 launch, which writes the records of the matrix-free action) on the kinematically driven
+    plastic state; the PCG block times fixed-length CG on the same state (action computed from the point records, no 81 x 81 matrices)."""
+    drv = L.Driver.synthetic(N, props, quats.ravel(), np.array(PREP_DTS), assembly=1, order=2, bbar=args.bbar, nrls=True, krylov=(1000, 1e-7, 1e-27),
+                             rank=rank, nranks=world, uid=fresh_uid(), **mk)
+    P_global = 27 * N ** 3
+    drv.bench_prepare(PREP_DTS[:1], advance=False); drv.bench_model(2); me = drv.bench_model(max(1, args.steps // 2))
+    el_ms = max_over_ranks(me["kernel_ms"]) / max(1, args.steps // 2)
+    drv.bench_prepare(PREP_DTS)
+    P_local = L.exa_driver_local_qpts(drv.h)
+    drv.bench_model(max(args.warmup, 1))
+    barrier(); t0 = time.perf_counter()
+    m = drv.bench_model(args.steps)
+    barrier(); t_model = max_over_ranks(time.perf_counter() - t0)
+    kern_ms = max_over_ranks(m["kernel_ms"]) / args.steps
+    nfev = drv.nfev_hist()
+    drv.bench_pcg(10)
+    barrier(); t0 = time.perf_counter()
+    pc = drv.bench_pcg(args.pcg_iters)
+    barrier(); t_pcg = max_over_ranks(time.perf_counter() - t0)
+    it_ms = max_over_ranks(pc["pcg_ms"]) / max(pc["iters"], 1); ap_ms = max_over_ranks(pc["apply_ms"]) / max(pc["iters"], 1)
+    if rank == 0:
+        kid = L.exa_kernel_build_id().decode(); traffic = {}; tsrc = None
+        for f in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
+            try:
+                d = json.load(open(os.path.join(ROOT, "profiles", f)))
+            except Exception:
+                continue
+            if d.get("kernel_build_id") == kid and "config5_bytes_per_qpt" in d:
+                traffic = d["config5_bytes_per_qpt"]; tsrc = "profiles/" + f
+                break
+        tr_model = (traffic["k_model_setup_p2_vg_records"] + traffic["k_geom_p2"]) * P_local if args.bbar and "k_geom_p2" in traffic else None
+        gbs = MODEL_BYTES_PER_QPT * P_local / (kern_ms * 1e-3) / 1e9
+        out = {"metric": "quadrature-point constitutive updates/s + Newton-PCG iter/s, 128^3 hex RVE",
+               "value": P_global * args.steps / t_model, "unit": "qpt-updates/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "warmup_requested": args.warmup,
+               "ms_per_step": t_model / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"NOT the headline: BASELINE config 5's shape - {N}^3 hex RVE p=2{', B-bar' if args.bbar else ''}, element assembly served matrix-free, "
+                                      f"{MODEL_NAMES[args.model]}, kinematically driven plastic state", "elements": N ** 3, "qpts": P_global, "decomposition": f"{world} block(s)"},
+               "library": {"path": L.LIB_PATH, "build_id": L.exa_build_id().decode(), "kernel_build_id": kid},
+               "pcg_iters_per_s": pc["iters"] / t_pcg, "pcg_iters": pc["iters"], "pcg_ms_per_iter": it_ms, "nonconverged_points": m["failed"],
+               "local_solver_evals": {"mean": float((nfev * np.arange(64)).sum() / max(nfev.sum(), 1)), "max": int(np.nonzero(nfev)[0].max()) if nfev.any() else 0},
+               "elastic_regime": {"avg_kernel_ms": el_ms, "value": P_local * world / (el_ms * 1e-3), "unit": "qpt-updates/s"},
+               "roofline": {"kernel": "k_geom_p2 + k_model_setup<.., 27, element-blocked, records> (geometry pre-pass over the elements, then the fused ExaCMech update that writes the "
+                                      "18-pair records of the matrix-free action)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "traffic": tr_model, "traffic_source": tsrc, "bytes_per_qpt": MODEL_BYTES_PER_QPT, "avg_kernel_ms": kern_ms,
+                            "note": "HIP events around the two launches of a pass; frac on SURVEY 8(d)'s 928 B/qpt; traffic = L2-boundary bytes of both kernels from the PMC passes of "
+                                    "this kernel build (profiles/*_pmc_traffic.json, config5_bytes_per_qpt), null otherwise"},
+               "roofline_pcg_apply": {"kernel": "k_mf_apply_p2<BBAR, TRANS, compact records> (action of the element matrices computed from the point records)", "bound": "hbm",
+                                      "bytes_per_qpt": 288.0, "avg_kernel_ms": ap_ms, "achieved": 288.0 * P_local / (ap_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": 288.0 * P_local / (ap_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "traffic": traffic["k_mf_apply_p2"] * P_local if "k_mf_apply_p2" in traffic else None,
+                                      "note": "288 B/qpt = the 18 16-byte pairs of a point record; the kernel also reads the element-average gradients (B-bar) and gathers / scatters "
+                                              "the 81 element dofs (PMC: 385 B/qpt)"},
+               "cpu_baseline": None, "cpu_baseline_note": "reported with the headline workload only (python bench.py)"}
+        print(json.dumps(out))
+    drv.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300, help="timed constitutive passes (default 300: a timed region of about 2 s)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=int(os.environ.get("EXA_BENCH_N", "128")), help="elements per edge of the RVE (default 128)")
+    ap.add_argument("--n", type=int, default=int(os.environ["EXA_BENCH_N"]) if "EXA_BENCH_N" in os.environ else None, help="elements per edge of the RVE (default 128; 64 with --order 2)")
+    ap.add_argument("--order", type=int, default=1, choices=[1, 2], help="2: the shape of BASELINE config 5 (triquadratic elements, element assembly served matrix-free; with --bbar "
+                    "the B-bar integrator) in a line of the same form - its own workload, named in config.workload, never the headline")
+    ap.add_argument("--bbar", action="store_true", help="B-bar integrator (with --order 2)")
     ap.add_argument("--pcg-iters", type=int, default=100)
     ap.add_argument("--assembly", default="PA")
     ap.add_argument("--model", default="fcc_voce", choices=["fcc_voce", "bcc_voce", "fcc_voce_nl", "fcc_kmdd", "bcc_kmdd"],
@@ -205,6 +267,8 @@ def main():
     ap.add_argument("--solve-steps-total", type=int, default=int(os.environ.get("EXA_BENCH_SOLVE_STEPS_TOTAL", str(SOLVE_STEPS_TOTAL_DEFAULT))),
                     help="after the timed regions the solve continues (committing --solve-steps) up to this step of the schedule, for the in-solve rates")
     args = ap.parse_args()
+    if args.n is None:
+        args.n = 128 if args.order == 1 else 64
 
     import torch
     import exaconstit_amd.lib as L
@@ -265,6 +329,11 @@ def main():
     rng = np.random.default_rng(20240928)
     quats = rng.standard_normal((N ** 3, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
     asm = 0 if args.assembly.upper() == "PA" else 1
+    if args.order == 2:
+        bench_order2(args, L, N, props, quats, mk, rank, world, fresh_uid, barrier, max_over_ranks)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     drv = L.Driver.synthetic(N, props, quats.ravel(), np.array(PREP_DTS), assembly=asm,
                              krylov=(1000, 1e-7, 1e-27), rank=rank, nranks=world, uid=fresh_uid(), jacobi=args.jacobi, **mk)
     del quats
@@ -544,9 +613,9 @@ def main():
                                                       "26 record doubles: no Jacobian field, effective shear rate from state slot 0); frac stays priced at SURVEY 8(d)'s 928 B/qpt",
                          "note": "the contract's HBM fraction of the ALGORITHMIC bytes (928 B/qpt) is reported in frac; the launch is bound by FP64 VALU issue at the clock "
                                  "the chip sustains at its 1 400 W package limit (~1.93 GHz, not the nominal 2.4 GHz the fp64_issue figures are priced at): SQ counters "
-                                 + ("(profiles/r05_sq_fcc_voce.txt) show the VALU busy 89 % of the wave cycles and waiting 12 % of them, 6 820 VALU instructions per wave of which 5 947 FP64 "
-                                    "arithmetic, no scratch (round 4: 86 % / 19.5 % / 6 845; profiles/r05_kernel_experiments.txt); " if args.model == "fcc_voce" else
-                                    f"of the Kocks-Mecking launches (main + tail) in profiles/r05_sq_{args.model}.txt; fp64_* figures are quoted for the Voce kernel only; ")
+                                 + ("(profiles/r06_sq_fcc_voce.txt) show the VALU busy 90 % of the wave cycles and waiting 12 % of them, 6 943 VALU instructions per wave, "
+                                    "no scratch (round 4: 86 % / 19.5 % / 6 845; profiles/r05_kernel_experiments.txt); " if args.model == "fcc_voce" else
+                                    f"of the Kocks-Mecking launches (main + tail) in profiles/r06_sq_{args.model}.txt; fp64_* figures are quoted for the Voce kernel only; ")
                                  + "traffic = L2-boundary bytes from the PMC "
                                  "passes of THIS kernel build and instantiation (profiles/*_pmc_traffic.json with the library's kernel_build_id; null otherwise); "
                                  "roofline_pcg_apply is the HBM-bound half of the metric"},

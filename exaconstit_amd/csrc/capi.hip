@@ -132,11 +132,36 @@ int exa_state_normalize(exa_ctx* ctx, double* state, exa_stream s) {
    return exa_launch_state_normalize(ctx, state, S(s));
 }
 
+// exa_set_newton_cap_auto: the cap of the NEXT launches from the evaluation counts this launch left in state1 (slot 3).  The distribution drifts slowly: the first
+// four launches and every fourth one after them are looked at (a histogram launch + one 256-byte read-back, which waits for the stream) - the schedule and the cost
+// model of the stand-alone driver (host/driver.hip, NonlinearMechOperator::Setup, choose_newton_cap), which keeps its own call so that its launch timers stay clean.
+extern "C" int exa_choose_newton_cap(const int* hist64, double tail_cost);   // host/driver_capi.hip (include/exaconstit_driver.h)
+static int cap_controller(exa_ctx* ctx, int rc, const double* state1, exa_stream s) {
+   if (rc != EXA_OK || !ctx->cap_auto) return rc;
+   ctx->cap_calls++;
+   if (!(ctx->cap_calls <= 4 || ctx->cap_calls % 4 == 0)) return rc;
+   int h[64];
+   if (int r = exa_model_nfev_hist(ctx, state1, h, s)) return r;
+   return exa_set_newton_caps(ctx, exa_choose_newton_cap(h, ctx->cap_tail_cost), 0, ctx->tail_resume);
+}
+
+int exa_set_newton_cap_auto(exa_ctx* ctx, int mode, double tail_cost) {
+   if (!ctx || mode < 0 || mode > 2) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_cap_auto: mode 0 (off), 1 (Kocks-Mecking models only) or 2 (every model)");
+   if (mode && ctx->P >= (int64_t)INT32_MAX) return fail(ctx, EXA_ERR_ARG, "exa_set_newton_cap_auto: the deferred-point list holds 32-bit point ids (P < 2^31)");
+   const bool km = ecmdev::kin_is_km(ctx->mp.kin);
+   ctx->cap_auto = (mode == 2 || (mode == 1 && km)) ? 1 : 0;
+   ctx->cap_tail_cost = tail_cost > 0.0 ? tail_cost : (km ? 1.5 : 4.0);   // dense launch's cost per evaluation relative to the full launch's (measured at 128^3, host/driver.hip)
+   ctx->cap_calls = 0;
+   if (!mode) { ctx->newton_cap = 0; ctx->newton_cap2 = 0; }
+   return EXA_OK;
+}
+int exa_get_newton_cap(exa_ctx* ctx) { return ctx ? ctx->newton_cap : EXA_ERR_ARG; }
+
 int exa_model_setup(exa_ctx* ctx, double dt, const double* J, const double* vel, const double* stress0, const double* state0,
                     double* stress1, double* state1, double* ddsdde, exa_stream s) {
    if (!ctx || !J || !vel || !stress0 || !state0 || !stress1 || !state1 || !ddsdde) return fail(ctx, EXA_ERR_ARG, "exa_model_setup: null pointer");
    if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup: dt must be positive");
-   return exa_launch_model_setup(ctx, dt, const_cast<double*>(J), vel, nullptr, stress0, state0, stress1, state1, ddsdde, S(s));
+   return cap_controller(ctx, exa_launch_model_setup(ctx, dt, const_cast<double*>(J), vel, nullptr, stress0, state0, stress1, state1, ddsdde, S(s)), state1, s);
 }
 
 int exa_model_setup_lvec(exa_ctx* ctx, double dt, const double* x_lvec, const double* v_lvec, const double* stress0, const double* state0,
@@ -144,7 +169,7 @@ int exa_model_setup_lvec(exa_ctx* ctx, double dt, const double* x_lvec, const do
    if (!ctx || !x_lvec || !v_lvec || !stress0 || !state0 || !stress1 || !state1 || !ddsdde || !J_out) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec: null pointer");
    if (!ctx->conn) return fail(ctx, EXA_ERR_STATE, "exa_model_setup_lvec: call exa_set_connectivity first");
    if (!(dt > 0.0)) return fail(ctx, EXA_ERR_ARG, "exa_model_setup_lvec: dt must be positive");
-   return exa_launch_model_setup(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, ddsdde, S(s));
+   return cap_controller(ctx, exa_launch_model_setup(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, ddsdde, S(s)), state1, s);
 }
 
 int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* x_lvec, const double* v_lvec, const double* stress0, const double* state0,
@@ -167,7 +192,7 @@ int exa_model_setup_lvec_records(exa_ctx* ctx, double dt, const double* x_lvec, 
                      : !ctx->qblk ? exa_launch_model_setup_aos_rec(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, S(s))
                      : exa_launch_model_setup_rec(ctx, dt, J_out, v_lvec, x_lvec, stress0, state0, stress1, state1, S(s));
    if (rc == EXA_OK) { ctx->have_grad = true; ctx->emat_valid = false; ctx->grad_records_only = true; }
-   return rc;
+   return cap_controller(ctx, rc, state1, s);
 }
 
 // driver-internal: device address of the failed-point counter of the last constitutive launch (consumed on the device by the residual norm)

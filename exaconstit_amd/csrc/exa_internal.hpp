@@ -63,6 +63,7 @@ struct exa_ctx {
    int newton_cap = 0; int* tail_dev = nullptr;   // tail split of the constitutive launch: [0] = count, [1..] = deferred point ids
    int newton_cap2 = 0; int* tail2_dev = nullptr; // second level (exa_set_newton_caps): list of the points the first tail launch cuts off
    int tail_resume = 1; double* resume_dev[2] = { nullptr, nullptr };   // solver states of the listed points, [RS_N][P] by list slot
+   int cap_auto = 0; double cap_tail_cost = 0.0; long cap_calls = 0;   // exa_set_newton_cap_auto: the library picks newton_cap from the evaluation counts of its own launches
    double* scratch_dev = nullptr; size_t scratch_bytes = 0;   // reductions
    double hist_init[ecmdev::NUM_HIST];
 };

@@ -403,6 +403,7 @@ int exa_driver_bench_adapter_route(exa_driver* d, int steps, int iters, double* 
       struct Guard { exa_ctx* c; ~Guard() { exa_destroy(c); } } guard{ ctxA };
       auto chk = [&](int rc, const char* what) { if (rc < 0) throw std::runtime_error(std::string(what) + ": " + exa_last_error(ctxA)); };
       chk(exa_set_connectivity(ctxA, op.conn.p, nn), "exa_set_connectivity");
+      chk(exa_set_newton_cap_auto(ctxA, 1, 0.0), "exa_set_newton_cap_auto");   // as the adapters' constructors do
       DevBuf<double> sv0((size_t)28 * P), s0((size_t)6 * P), sv1((size_t)28 * P), s1((size_t)6 * P), cm((size_t)36 * P), J((size_t)9 * P), tmp((size_t)28 * P);
       DevBuf<double> elx((size_t)24 * E), elv((size_t)24 * E), ely((size_t)24 * E), sc(3);
       auto to_aos = [&](int W, const DevBuf<double>& src, DevBuf<double>& dst) {

@@ -70,6 +70,8 @@ exa_set_newton_cap = _sig("exa_set_newton_cap", C.c_int, C.c_void_p, C.c_int)
 exa_selftest_km_math = _sig("exa_selftest_km_math", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 exa_set_newton_caps = _sig("exa_set_newton_caps", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
 exa_model_tail_count = _sig("exa_model_tail_count", C.c_int, C.c_void_p, C.c_void_p)
+exa_set_newton_cap_auto = _sig("exa_set_newton_cap_auto", C.c_int, C.c_void_p, C.c_int, C.c_double)
+exa_get_newton_cap = _sig("exa_get_newton_cap", C.c_int, C.c_void_p)
 exa_model_nfev_hist = _sig("exa_model_nfev_hist", C.c_int, C.c_void_p, dptr, C.POINTER(C.c_int), C.c_void_p)
 exa_model_status = _sig("exa_model_status", C.c_int, C.c_void_p, C.c_void_p)
 exa_calc_dp = _sig("exa_calc_dp", C.c_int, C.c_void_p, dptr, dptr, C.c_void_p)

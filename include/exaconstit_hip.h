@@ -182,6 +182,16 @@ int exa_set_newton_cap(exa_ctx* ctx, int max_evals);
  * exa_set_newton_cap(ctx, K) is exa_set_newton_caps(ctx, K, 0, <current resume setting>). */
 int exa_set_newton_caps(exa_ctx* ctx, int max_evals, int max_evals_2, int resume);
 int exa_model_tail_count(exa_ctx* ctx, exa_stream s);
+/* Let the library choose max_evals itself (what the stand-alone driver does for its own launches, host/driver.hip): after the first four launches
+ * of exa_model_setup / _lvec / _lvec_records and after every fourth one from then on, the evaluation counts the launch left in state1 are binned
+ * (exa_model_nfev_hist: one small launch and a 256-byte read-back that waits for the stream) and the cap of the next launches is the K that
+ * minimises  E[max of 64 draws of min(n, K)] + 0.2 + (share of points above K) * tail_cost * (E[max of 64 draws | n > K] + 2)  - or no cap when that
+ * does not beat the uncapped launch by 3 %.  mode: 0 = off (and the cap is cleared), 1 = for the Kocks-Mecking models only - the driver's default:
+ * at 128^3 the BCC launch takes 7.2 ms with it and 17.3 ms without; the Voce launches never find a paying cap in steady state -, 2 = every model.
+ * tail_cost <= 0: the measured defaults (1.5 Kocks-Mecking, 4 Voce).  Results do not depend on the cap (see above), only the launch time does.
+ * The MFEM adapters (include/exaconstit_mfem_adapters.hpp) switch mode 1 on. */
+int exa_set_newton_cap_auto(exa_ctx* ctx, int mode, double tail_cost);
+int exa_get_newton_cap(exa_ctx* ctx);   /* the cap in force (0 = none) */
 /* histogram (64 bins, last bin = 63 and more) of the evaluation counts stored in slot 3 of a state array; synchronises.  The driver
  * picks max_evals from it (host/driver.hip, choose_newton_cap). */
 int exa_model_nfev_hist(exa_ctx* ctx, const double* state_dev, int* hist64_host, exa_stream s);

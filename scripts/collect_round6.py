@@ -20,7 +20,7 @@ for f in sorted(glob.glob("gpurun_out/r06_*")):
         bad.append((f, f"unreadable: {e}")); continue
     if rid is not None and rid != kid and "--allow-other-build" not in sys.argv:
         bad.append((f, f"kernel build {rid}, tree is {kid}")); continue
-    if f.endswith((".log", ".err")):
+    if f.endswith((".log", ".err")) and not f.endswith("_gpu_tests.log"):
         continue
     shutil.copy(f, os.path.join("profiles", os.path.basename(f))); n += 1
 print(f"tree kernel build id {kid}: copied {n} files into profiles/")

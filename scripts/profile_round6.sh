@@ -15,15 +15,6 @@ python scripts/region_summary.py gpurun_out/${T}_trace gpurun_out/${T}_region_su
 cp $(ls gpurun_out/${T}_trace/*/*kernel_stats.csv | head -1) gpurun_out/${T}_kernel_stats.csv 2>/dev/null
 grep '^{"metric"' gpurun_out/${T}_trace.log > gpurun_out/${T}_bench_under_rocprof.json
 rm -rf gpurun_out/${T}_trace/*/*marker* gpurun_out/${T}_trace/*/*kernel_trace.csv 2>/dev/null
-# ---- 2. bench records
-python bench.py --gpus 1 --steps 20 --warmup 5 2> gpurun_out/${T}_bench_driver_form.err | grep '^{"metric"' > gpurun_out/${T}_bench_driver_form.json
-python bench.py --model bcc_kmdd --steps 50 --warmup 5 --no-cpu-baseline --no-adapter-route 2>/dev/null | grep '^{"metric"' > gpurun_out/${T}_bench_n128_bcc_kmdd.json
-python bench.py --model fcc_kmdd --steps 30 --warmup 5 --no-cpu-baseline --no-adapter-route --solve-steps-total 14 2>/dev/null | grep '^{"metric"' > gpurun_out/${T}_bench_n128_fcc_kmdd.json
-python bench.py --n 64 --steps 100 --warmup 5 --no-cpu-baseline --pcg-iters 400 2>/dev/null | grep '^{"metric"' > gpurun_out/${T}_bench_n64.json
-python bench.py --n 64 --jacobi --steps 100 --warmup 5 --no-cpu-baseline --no-adapter-route --pcg-iters 400 2>/dev/null | grep '^{"metric"' > gpurun_out/${T}_bench_n64_jacobi.json
-python bench.py --jacobi --steps 50 --warmup 5 --no-cpu-baseline --no-adapter-route --solve-steps-total 14 2>/dev/null | grep '^{"metric"' > gpurun_out/${T}_bench_n128_jacobi.json
-python scripts/bench_config5.py 64 2>/dev/null | grep '^{' > gpurun_out/${T}_config5_rates.json
-python scripts/adapter_route.py --model bcc_kmdd --steps 10 --iters 10 2>/dev/null | grep '^{' > gpurun_out/${T}_adapter_route_bcc_kmdd.json
 # ---- 3. traffic
 export EXA_BENCH_SOLVE_STEPS=0
 for m in fcc_voce bcc_kmdd fcc_kmdd; do
@@ -80,6 +71,10 @@ python - <<PY
 import json
 d = json.load(open("gpurun_out/${T}_pmc_flops.json")); d["kernel_build_id"] = "$KID"; json.dump(d, open("gpurun_out/${T}_pmc_flops.json", "w"), indent=1)
 PY
+# ---- 2. bench records (after the counter passes: bench.py fills roofline.traffic from profiles/*_pmc_traffic.json of THIS kernel build)
+unset EXA_BENCH_SOLVE_STEPS
+cp gpurun_out/${T}_pmc_traffic.json profiles/${T}_pmc_traffic.json
+bash scripts/bench_records_round6.sh
 for f in gpurun_out/${T}_sq_*.txt; do sed -i "1i kernel_build_id $KID" $f; done
 rm -rf gpurun_out/${T}_*_pmc_FETCH_SIZE gpurun_out/${T}_*_pmc_WRITE_SIZE gpurun_out/${T}_sq_fcc_kmdd gpurun_out/${T}_sq_fcc_voce gpurun_out/${T}_sq_bcc_kmdd gpurun_out/${T}_pmc_flops gpurun_out/${T}_sq_adapter_trace gpurun_out/${T}_sq_c5_trace gpurun_out/${T}_trace 2>/dev/null
 cat gpurun_out/${T}_sq_fcc_voce.txt gpurun_out/${T}_sq_bcc_kmdd.txt gpurun_out/${T}_sq_adapter_staged.txt gpurun_out/${T}_sq_config5.txt; tail -1 gpurun_out/${T}_pmc_flops.out; cat gpurun_out/${T}_pmc_traffic.json

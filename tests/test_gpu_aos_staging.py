@@ -32,7 +32,7 @@ def _props(orc, fname, overrides):
     return props
 
 
-def _run(orc, model, props, N, order, lvec, staging, cap=0):
+def _run(orc, model, props, N, order, lvec, staging, cap=0, auto=None):
     """four kinematic steps through exa_model_setup (E-vector form) or exa_model_setup_lvec; returns the final outputs as device tensors"""
     import torch
     import exaconstit_amd.lib as L
@@ -45,6 +45,8 @@ def _run(orc, model, props, N, order, lvec, staging, cap=0):
     assert L.exa_get_aos_staging(ctx.h) == staging and L.exa_get_quadrature_layout(ctx.h) == L.EXA_QLAYOUT_AOS
     if cap:
         ctx.check(L.exa_set_newton_caps(ctx.h, cap, 0, 1))
+    if auto:
+        ctx.check(L.exa_set_newton_cap_auto(ctx.h, *auto))
     d_conn = torch.from_numpy(rve["conn"].astype(np.int32)).to(dev.dev)
     ctx.check(L.exa_set_connectivity(ctx.h, ptr(d_conn), NN))
     sv = [dev.zeros(28 * P), dev.zeros(28 * P)]; sg = [dev.zeros(6 * P), dev.zeros(6 * P)]; cm = dev.zeros(36 * P); J = dev.zeros(9 * P)
@@ -67,6 +69,8 @@ def _run(orc, model, props, N, order, lvec, staging, cap=0):
         tails += L.exa_model_tail_count(ctx.h, None)
         sv.reverse(); sg.reverse()
     out = (sv[0].clone(), sg[0].clone(), cm.clone(), J.clone())
+    if auto:
+        tails = (tails, L.exa_get_newton_cap(ctx.h))
     ctx.close()
     return out, tails
 
@@ -115,3 +119,24 @@ def test_staged_launch_with_tail_split(oracle, name, pfile, model, cap, lvec):
     assert t0 == 0 and t1 > 0
     for a, b, what in zip(ref, got, ("state", "stress", "tangent", "jacobian")):
         assert torch.equal(a, b), (name, what, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("lvec", [False, True], ids=["evec", "lvec"])
+def test_library_chosen_cap_is_bit_neutral(oracle, lvec):
+    """exa_set_newton_cap_auto (what the MFEM adapters switch on): the library bins the evaluation counts of its own launches and caps the next ones.
+    Same bits as the uncapped launches; mode 1 leaves a Voce context alone, mode 0 clears the cap."""
+    import torch
+    import exaconstit_amd.lib as L
+    props = _props(oracle, "props_cp_mts.txt", {})
+    ref, t0 = _run(oracle, 5, props, 5, 1, lvec, 1)
+    got, (t1, cap) = _run(oracle, 5, props, 5, 1, lvec, 1, auto=(1, 0.05))      # a cheap dense launch in the cost model: a cap pays on this small RVE too
+    assert t0 == 0 and t1 > 0 and cap >= 3, (t1, cap)
+    for a, b, what in zip(ref, got, ("state", "stress", "tangent", "jacobian")):
+        assert torch.equal(a, b), (what, float((a - b).abs().max()))
+    _, (t2, cap2) = _run(oracle, 0, _props(oracle, "props_cp_voce.txt", {}), 5, 1, lvec, 1, auto=(1, 0.05))
+    assert t2 == 0 and cap2 == 0
+    ctx = L.Context(5, props, 298.0, 1, 8)
+    ctx.check(L.exa_set_newton_caps(ctx.h, 4, 0, 1)); assert L.exa_get_newton_cap(ctx.h) == 4
+    ctx.check(L.exa_set_newton_cap_auto(ctx.h, 0, 0.0)); assert L.exa_get_newton_cap(ctx.h) == 0
+    assert L.exa_set_newton_cap_auto(ctx.h, 3, 0.0) != 0
+    ctx.close()

@@ -102,3 +102,15 @@ def test_bench_ranks_under_torchrun(tmp_path, nproc):
     assert [p["rank"] for p in pr] == list(range(nproc)) and sum(p["elements"] for p in pr) == 32 ** 3
     assert all(p["neighbours"] == (1 if nproc == 2 else 7) and p["halo_bytes_per_exchange"] > 0 for p in pr)
     assert d["roofline"]["in_solve"]["solved_to_step"] == ss + 1 and os.path.basename(d["library"]["path"]).startswith("libexaconstit_hip")
+
+
+def test_bench_order2_line():
+    """`python bench.py --order 2 --bbar`: BASELINE config 5's shape in a line of the contract's form (its own workload, named as such; small RVE here)"""
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--order", "2", "--bbar", "--n", "8", "--steps", "3", "--warmup", "1", "--pcg-iters", "10"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["config"]["qpts"] == 27 * 8 ** 3 and "NOT the headline" in d["config"]["workload"]
+    assert d["value"] > 0 and d["nonconverged_points"] == 0 and d["pcg_iters"] == 10 and d["local_solver_evals"]["mean"] > 4
+    assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline_pcg_apply"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
