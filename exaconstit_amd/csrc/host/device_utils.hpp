@@ -51,7 +51,7 @@ void vk_cg_init(double* S, double rel, double abs_, hipStream_t s);
 void vk_cg_den(double* S, hipStream_t s);
 void vk_cg_beta(double* S, int max_iter, hipStream_t s);
 void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, bool ident,
-                 bool fuse_beta, int max_iter, hipStream_t s);
+                 bool fuse_beta, int max_iter, hipStream_t s, const double* partialD = nullptr);   // partialD: consumer-side reduction of the denominator (vec_kernels.hip)
 void vk_cg_step2(int64_t n, const double* S, const double* z, double* d, hipStream_t s);
 // single-reduction PCG (more than one rank): see vec_kernels.hip
 void vk_cg2_init(double* S, double rel, double abs_, hipStream_t s);
@@ -59,7 +59,8 @@ void vk_cg2_scalars(double* S, int max_iter, hipStream_t s);
 void vk_cg2_update(int64_t n, const double* S, const double* dinv, double* x, double* r, double* u, double* p, double* sv, double* q, bool ident, hipStream_t s);
 void vk_cg2_dots(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* r, const double* u, double* sv, const double* flag, double* partial, double* out2,
                  bool ident, hipStream_t s);
-void vk_cg_step2z(int64_t n, const double* S, double* z, const double* r, double* d, bool ident, hipStream_t s);   // ... and z = 0 for the accumulating operator action
+void vk_cg_step2z(int64_t n, double* S, double* z, const double* r, double* d, bool ident, hipStream_t s, const double* partialN = nullptr, int max_iter = 0);   // ... and z = 0 for the accumulating operator action; partialN: consumer-side reduction of (r, z)
+void vk_dot_partial(int64_t n, int64_t nn, const double* w, const double* a, const double* b, const double* flag, double* partial, hipStream_t s);   // partial sums only (their consumer reduces them)
 void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* a, double* b, const double* flag, double* partial, double* out, hipStream_t s,
                  double* fuse_den_S = nullptr);
 void vk_min3(int64_t nn, const double* x, double* partial /*>= DOT_BLOCKS*/, double* out3, hipStream_t s);

@@ -516,7 +516,7 @@ NonlinearMechOperator::NonlinearMechOperator(const ExaOptions& opt, const Partit
    if (!records_setup_) { matGrad.alloc(qf(36)); matGrad.zero(); }   // (allocated on demand if the records route is left, see SetPrecond)
    stress0.zero(); stress1.zero(); matVars1.zero();
    diag.alloc(nd_); dinv.alloc(nd_); tmp_l_.alloc(nd_); tmp_r_.alloc(nd_); el_x2_.alloc(3 * (size_t)npe_ * E_); ess_mask.alloc(nd_); ess_mask.zero();
-   partial.alloc(DOT_BLOCKS * 4); scal.alloc(16); scal.zero();
+   partial.alloc(DOT_BLOCKS * 4); scal.alloc(32); scal.zero();
    { DevBuf<double> q; q.upload(quats_per_elem); abi_check(ctx_, exa_init_state(ctx_, matVars0.p, q.p, stream_), "exa_init_state"); EXA_HC(hipStreamSynchronize(stream_)); }
    model_.reset(new ExaCMechModel(ctx_, &stress0, &stress1, &matGrad, &matVars0, &matVars1));
    comm_.setup_halo(part);
@@ -997,6 +997,9 @@ void SystemDriver::drop_cg_graph() {
 
 // device PCG (MFEM CGSolver::Mult with iterative_mode = false); all scalars stay on the device, the host only polls the
 // done-flag every cg_check_every iterations.
+#ifndef EXA_PCG_CONSUMER_REDUCE_MAX_DOFS
+#define EXA_PCG_CONSUMER_REDUCE_MAX_DOFS INT64_MAX   // consumer-side reductions of the PCG scalars up to this many local dofs (EXA_PCG_REDUCE_LAUNCH=1: never, =<n>: up to n)
+#endif
 int SystemDriver::CGSolve(const double* b, double* x) {
    if ((comm.nranks > 1 || comm.forced()) && std::getenv("EXA_PCG_TWO_REDUCTIONS") == nullptr) return CGSolveSingleReduction(b, x);
    NonlinearMechOperator& op = *oper_;
@@ -1013,12 +1016,21 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    vk_dot(nd, nn, op.weight.p, cg_d_.p, cg_r_.p, nullptr, op.partial.p, S + 8, s);
    comm.allreduce_sum(S + 8, 1, s);
    vk_cg_init(S, opt_.krylov_rel, opt_.krylov_abs, s);
-   op.GradMult(cg_d_.p, cg_z_.p, true, S + 6);
-   vk_dot(nd, nn, op.weight.p, cg_z_.p, cg_d_.p, S + 6, op.partial.p, S + 8, s);
-   comm.allreduce_sum(S + 8, 1, s);
-   vk_cg_den(S, s);
-   double hS[12]; int launched = 0; bool done = false;
    const bool fused = std::getenv("EXA_PCG_UNFUSED") == nullptr;   // A/B switch for measurements
+   // Consumer-side reductions (vec_kernels.hip): one rank, fused loop.  An iteration is then four launches instead of six - update / direction / action / masked dot - and
+   // the blocks of the update and direction kernels sum the <= 1024 partial sums themselves.  Same bits as the one-block reduction launches (EXA_PCG_REDUCE_LAUNCH=1).
+   const char* red_env = std::getenv("EXA_PCG_REDUCE_LAUNCH");      // (read per solve: the tests switch it between drivers of one process)
+   const int64_t red_max_dofs = red_env ? (std::atoll(red_env) == 1 ? (int64_t)0 : (int64_t)std::atoll(red_env)) : (int64_t)EXA_PCG_CONSUMER_REDUCE_MAX_DOFS;
+   const bool red = fused && comm.nranks == 1 && !comm.forced() && nd <= red_max_dofs;
+   double* partD = op.partial.p + 2 * DOT_BLOCKS;      // partial sums of the denominator (the (r, z) ones use the front of the buffer)
+   op.GradMult(cg_d_.p, cg_z_.p, true, S + 6);
+   if (red) vk_dot_partial(nd, nn, op.weight.p, cg_z_.p, cg_d_.p, S + 6, partD, s);      // the first update kernel turns them into alpha
+   else {
+      vk_dot(nd, nn, op.weight.p, cg_z_.p, cg_d_.p, S + 6, op.partial.p, S + 8, s);
+      comm.allreduce_sum(S + 8, 1, s);
+      vk_cg_den(S, s);
+   }
+   double hS[18]; int launched = 0; bool done = false;
    // One rank: the scalar updates ride in the reductions (no all-reduce in between).  (Summing the denominator d.(K d) element-wise
    // inside the action, with its scatter skipping the essential rows, was measured too: the pass it saves costs what it adds to the
    // action kernel, +0.8 %.)
@@ -1026,6 +1038,13 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    auto iteration = [&]() {
       // identity preconditioner + fused loop: z == r is never materialised (the un-fused path reads z in k_cg_step2)
       const bool ident = fused && op.precond == Precond::IDENTITY;
+      if (red) {
+         vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, ident, false, opt_.krylov_iter, s, partD);      // alpha from partD; (r, z) partial sums
+         vk_cg_step2z(nd, S, cg_z_.p, cg_r_.p, cg_d_.p, ident, s, op.partial.p, opt_.krylov_iter);      // beta from them; d = z + beta d; z = 0
+         op.GradMult(cg_d_.p, cg_z_.p, true, S + 6, true, true);
+         vk_mask_dot(nd, nn, op.weight.p, op.ess_mask.p, cg_d_.p, cg_z_.p, S + 6, partD, nullptr, s, nullptr);
+         return;
+      }
       vk_cg_step1(nd, nn, S, op.weight.p, op.dinv.p, cg_d_.p, x, cg_r_.p, cg_z_.p, op.partial.p, ident, fused && one, opt_.krylov_iter, s);
       if (!(fused && one)) { comm.allreduce_sum(S + 8, 1, s); vk_cg_beta(S, opt_.krylov_iter, s); }
       if (fused) {
@@ -1047,7 +1066,7 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    // collective inside the capture); above graph_max_dofs the kernels are long enough to hide their launches (measured).
    // The capture bakes in every kernel argument: the solution pointer, the preconditioner variant, the iteration cap (an argument of
    // k_cg_step1 / the reductions) and the chunk length - all of them are part of the key.
-   const int64_t graph_key = ((int64_t)op.precond << 48) ^ ((int64_t)cg_check_every << 32) ^ (int64_t)opt_.krylov_iter;
+   const int64_t graph_key = ((int64_t)op.precond << 48) ^ ((int64_t)red << 47) ^ ((int64_t)cg_check_every << 32) ^ (int64_t)opt_.krylov_iter;
    bool use_graph = one && fused && !comm.forced() && nd <= cg_graph_max_dofs && cg_check_every > 1;
    if (use_graph && (!cg_graph_ || cg_graph_x_ != x || cg_graph_key_ != graph_key)) {
       drop_cg_graph();
@@ -1068,7 +1087,8 @@ int SystemDriver::CGSolve(const double* b, double* x) {
    while (!done) {
       if (use_graph) { EXA_HC(hipGraphLaunch((hipGraphExec_t)cg_graph_, s)); launched += cg_check_every; }
       else for (int k = 0; k < cg_check_every && launched < opt_.krylov_iter; k++, launched++) iteration();
-      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 12, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+      EXA_HC(hipMemcpyAsync(hS, S, sizeof(double) * 18, hipMemcpyDeviceToHost, s)); EXA_HC(hipStreamSynchronize(s));
+      if (red) hS[7] = hS[17];      // the iteration count travels in S[17] between the direction and the update kernel
       done = (hS[6] != 0.0) || launched >= opt_.krylov_iter;
    }
    EXA_HC(hipEventRecord(e1, s)); EXA_HC(hipEventSynchronize(e1));

@@ -75,10 +75,11 @@ __global__ void k_reduce(int nb, const double* __restrict__ partial, const doubl
 }
 
 // PCG scalars: S[0]=nom S[1]=den S[2]=betanom S[3]=r0 S[4]=alpha S[5]=beta S[6]=done flag (0 run, 1 converged, -1 breakdown) S[7]=iterations
-// S[8]=scratch for reductions  S[9]=scratch of the operator's dot  S[10]=number of iterations with (Ad, d) < 0
+// S[8]=scratch for reductions  S[9]=scratch of the operator's dot  S[10]=number of iterations with (Ad, d) < 0  S[16], S[17]=nom / iterations in flight (consumer-side reductions)
 __global__ void k_cg_init(double* S, double rel, double abs_) {       // after nom was reduced into S[8]
    const double nom = S[8];
    S[0] = nom; S[3] = fmax(nom * rel * rel, abs_ * abs_); S[7] = 0.0; S[2] = nom; S[11] = nom;   // S[11]: (r0, z0), S[2]: latest (r, z) - the achieved reduction is reported
+   S[16] = nom; S[17] = 0.0;   // (nom, iterations) as the consumer-side reductions hand them from k_cg_step2z to k_cg_step1 (below)
    S[6] = (nom < 0.0) ? -1.0 : ((nom <= S[3]) ? 1.0 : 0.0);
 }
 __device__ __forceinline__ void cg_den_update(double* S) {            // den reduced into S[8]
@@ -116,12 +117,58 @@ __global__ void k_reduce_cg(int nb, const double* __restrict__ partial, double* 
 #ifndef EXA_CG_X_NT
 #define EXA_CG_X_NT 1
 #endif
-template <bool IDENT, bool XNT = (EXA_CG_X_NT != 0)>
-__global__ void k_cg_step1(int64_t n, int64_t nn, const double* __restrict__ S, const double* __restrict__ w, const double* __restrict__ dinv,
-                           const double* __restrict__ d, double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial) {
+// Consumer-side reductions (one rank, fused loop, small systems): the two one-block launches that turned partial sums into alpha / beta (k_reduce_cg) are gone;
+// every block of the NEXT kernel sums the partial sums itself - same order as k_reduce_cg, so the same bits in every block and as before - and block 0 keeps the
+// scalar record.  What all blocks read in a kernel is never written in that kernel: k_cg_step2z reads (nom, iterations) from S[0], S[7] and leaves the new pair in
+// S[16], S[17]; k_cg_step1 reads S[16] and commits both.  The done flag S[6] may be set by block 0 while other blocks start: a block takes it through one thread
+// (no divergence across a barrier), and a block that still reads 0 reaches the same decision from the sum it computes.
+// block_sum's tree with fewer barriers: the steps 128 and 64 through LDS, the steps 32 ... 1 inside the first wave (the same pairs are added: the same bits)
+__device__ __forceinline__ double block_sum_w(double v, double* sm) {
+   static_assert(RBLK == 256, "two LDS steps, then one wave");
+   sm[threadIdx.x] = v; __syncthreads();
+   if (threadIdx.x < 128) sm[threadIdx.x] += sm[threadIdx.x + 128];
+   __syncthreads();
+   if (threadIdx.x < 64) {
+      double x = sm[threadIdx.x] + sm[threadIdx.x + 64];
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) x += __shfl_down(x, s);      // lane t < s adds lane t + s, as sm[t] += sm[t + s] does; the other lanes' sums are not used
+      if (threadIdx.x == 0) sm[0] = x;
+   }
+   __syncthreads();
+   const double r = sm[0]; __syncthreads();
+   return r;
+}
+// sum of the partial sums and the done flag in one go: the flag is taken by one thread (no divergence across the barriers) and published by the tree's first barrier,
+// so its round trip to L2 runs beside the loads of the partial sums
+__device__ __forceinline__ double sum_partials(int nb, const double* __restrict__ partial, const double* S, double* sm, double* sflag, bool& done) {
+   double acc = 0;
+   for (int i = threadIdx.x; i < nb; i += RBLK) acc += partial[i];
+   if (threadIdx.x == 0) *sflag = S[6];
+   const double r = block_sum_w(acc, sm);
+   done = *sflag != 0.0;
+   return r;
+}
+// RED: alpha from the partial sums of the denominator (k_mask_dot_partial / k_dot_partial wrote partialD[0 .. nbD))
+template <bool IDENT, bool XNT = (EXA_CG_X_NT != 0), bool RED = false>
+__global__ void k_cg_step1(int64_t n, int64_t nn, double* S, const double* __restrict__ w, const double* __restrict__ dinv,
+                           const double* __restrict__ d, double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial,
+                           int nbD, const double* __restrict__ partialD) {
    __shared__ double sm[RBLK];
-   if (S[6] != 0.0) return;
-   const double alpha = S[4];
+   double alpha;
+   if constexpr (RED) {
+      __shared__ double sflag;
+      const double nom = S[16], its = S[17];      // (requested before the reduction: nothing below waits for them alone)
+      bool done;
+      const double den = sum_partials(nbD, partialD, S, sm, &sflag, done);      // cg_den_update, in every block
+      if (done) return;
+      const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+      if (den == 0.0) { if (lead) { S[8] = den; S[1] = den; S[6] = -1.0; } return; }
+      alpha = nom / den;
+      if (lead) { S[8] = den; S[1] = den; if (den < 0.0) S[10] += 1.0; S[4] = alpha; S[0] = nom; S[7] = its; }
+   } else {
+      if (S[6] != 0.0) return;
+      alpha = S[4];
+   }
    double acc = 0;
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
       if constexpr (XNT) __builtin_nontemporal_store(__builtin_nontemporal_load(&x[i]) + alpha * d[i], &x[i]);      // x is touched once per iteration: it need not displace d, r, z from the caches
@@ -144,10 +191,28 @@ __global__ void k_cg_step2(int64_t n, const double* __restrict__ S, const double
 }
 
 // d = z + beta d, then z = 0: the operator action that follows accumulates into z with atomics, so the separate fill pass is folded in
-template <bool IDENT>
-__global__ void k_cg_step2z(int64_t n, const double* __restrict__ S, double* __restrict__ z, const double* __restrict__ r, double* __restrict__ d) {
-   if (S[6] != 0.0) return;
-   const double beta = S[5];
+// RED: beta from the partial sums of (r, z) (k_cg_step1 wrote partialN[0 .. nbN)); cg_beta_update in every block
+template <bool IDENT, bool RED = false>
+__global__ void k_cg_step2z(int64_t n, double* S, double* __restrict__ z, const double* __restrict__ r, double* __restrict__ d,
+                            int nbN, const double* __restrict__ partialN, double max_iter) {
+   double beta;
+   if constexpr (RED) {
+      __shared__ double sm[RBLK]; __shared__ double sflag;
+      const double nom = S[0], thr = S[3], it = S[7] + 1.0;
+      bool done;
+      const double bn = sum_partials(nbN, partialN, S, sm, &sflag, done);
+      if (done) return;
+      const bool conv = bn <= thr, capped = !conv && it >= max_iter;
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+         S[8] = bn; S[2] = bn; S[17] = it;
+         if (conv) S[6] = 1.0; else if (capped) S[6] = 2.0; else { S[5] = bn / nom; S[16] = bn; }
+      }
+      if (conv || capped) return;
+      beta = bn / nom;
+   } else {
+      if (S[6] != 0.0) return;
+      beta = S[5];
+   }
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { d[i] = (IDENT ? r[i] : z[i]) + beta * d[i]; z[i] = 0.0; }
 }
 
@@ -361,16 +426,32 @@ void vk_vgrad_velocity(int64_t nn, const uint8_t* m, const double* x, const doub
    double9 L; for (int i = 0; i < 9; i++) L.a[i] = L9[i];
    hipLaunchKernelGGL(k_vgrad_velocity, dim3(nblk(nn)), dim3(256), 0, s, nn, m, x, org, L, v);
 }
-void vk_cg_step2z(int64_t n, const double* S, double* z, const double* r, double* d, bool ident, hipStream_t s) {
-   if (ident) hipLaunchKernelGGL(k_cg_step2z<true>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, r, d);
-   else hipLaunchKernelGGL(k_cg_step2z<false>, dim3(gblk(n) * 4), dim3(RBLK), 0, s, n, S, z, r, d);
+#ifndef EXA_CG_RED_GRID
+#define EXA_CG_RED_GRID 1
+#endif
+// partialN != nullptr: consumer-side reduction of the (r, z) partial sums k_cg_step1 left there (one rank; S[6] / S[5] / S[16..17] updated by the launch itself)
+void vk_cg_step2z(int64_t n, double* S, double* z, const double* r, double* d, bool ident, hipStream_t s, const double* partialN, int max_iter) {
+   const unsigned nb = gblk(n);
+   if (partialN) {
+      const unsigned g = nb * EXA_CG_RED_GRID;      // (every block pays the prologue: fewer, longer blocks than the plain kernel's 4 nb)
+      if (ident) hipLaunchKernelGGL((k_cg_step2z<true, true>), dim3(g), dim3(RBLK), 0, s, n, S, z, r, d, (int)nb, partialN, (double)max_iter);
+      else hipLaunchKernelGGL((k_cg_step2z<false, true>), dim3(g), dim3(RBLK), 0, s, n, S, z, r, d, (int)nb, partialN, (double)max_iter);
+   } else {
+      if (ident) hipLaunchKernelGGL((k_cg_step2z<true, false>), dim3(nb * 4), dim3(RBLK), 0, s, n, S, z, r, d, 0, (const double*)nullptr, 0.0);
+      else hipLaunchKernelGGL((k_cg_step2z<false, false>), dim3(nb * 4), dim3(RBLK), 0, s, n, S, z, r, d, 0, (const double*)nullptr, 0.0);
+   }
 }
+// out == nullptr and fuse_den_S == nullptr: the partial sums stay in `partial` for the consumer-side reduction of k_cg_step1<.., RED>
 void vk_mask_dot(int64_t n, int64_t nn, const double* w, const uint8_t* m, const double* a, double* b, const double* flag, double* partial, double* out, hipStream_t s, double* fuse_den_S) {
    check_3nn(n, nn);
    const unsigned nb = gblk(n);
    hipLaunchKernelGGL(k_mask_dot_partial, dim3(nb), dim3(RBLK), 0, s, n, nn, w, m, a, b, flag, partial);
    if (fuse_den_S) hipLaunchKernelGGL(k_reduce_cg<2>, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, fuse_den_S, 0.0);
-   else hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out);
+   else if (out) hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, flag, out);
+}
+void vk_dot_partial(int64_t n, int64_t nn, const double* w, const double* a, const double* b, const double* flag, double* partial, hipStream_t s) {
+   check_3nn(n, nn);
+   hipLaunchKernelGGL(k_dot_partial, dim3(gblk(n)), dim3(RBLK), 0, s, n, nn, w, a, b, flag, partial);
 }
 // failed local solves of the constitutive launch behind a residual: the count goes to count_out (as a double, next to the norm in the read-back)
 // and a non-zero count makes the local sum +inf, so that Newton sees a non-finite residual on every rank after the all-reduce
@@ -384,13 +465,16 @@ void vk_cg_init(double* S, double rel, double abs_, hipStream_t s) { hipLaunchKe
 void vk_cg_den(double* S, hipStream_t s) { hipLaunchKernelGGL(k_cg_den, dim3(1), dim3(1), 0, s, S); }
 void vk_cg_beta(double* S, int max_iter, hipStream_t s) { hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1), 0, s, S, (double)max_iter); }
 // fuse_beta: one rank, the reduction also performs the beta update (no vk_cg_beta launch afterwards)
+// partialD != nullptr: consumer-side reductions - alpha from the denominator's partial sums in partialD, and the (r, z) partial sums are left in `partial` for vk_cg_step2z
 void vk_cg_step1(int64_t n, int64_t nn, double* S, const double* w, const double* dinv, const double* d, double* x, double* r, double* z, double* partial, bool ident,
-                 bool fuse_beta, int max_iter, hipStream_t s) {
+                 bool fuse_beta, int max_iter, hipStream_t s, const double* partialD) {
    check_3nn(n, nn);
    const unsigned nb = gblk(n);
    const bool xnt = vk_x_nt(n);
-   if (ident) { if (xnt) hipLaunchKernelGGL((k_cg_step1<true, true>), dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial); else hipLaunchKernelGGL((k_cg_step1<true, false>), dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial); }
-   else { if (xnt) hipLaunchKernelGGL((k_cg_step1<false, true>), dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial); else hipLaunchKernelGGL((k_cg_step1<false, false>), dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial); }
+#define STEP1(I, X, R) hipLaunchKernelGGL((k_cg_step1<I, X, R>), dim3(nb), dim3(RBLK), 0, s, n, nn, S, w, dinv, d, x, r, z, partial, (int)nb, partialD)
+   if (partialD) { if (ident) { if (xnt) STEP1(true, true, true); else STEP1(true, false, true); } else { if (xnt) STEP1(false, true, true); else STEP1(false, false, true); } return; }
+   if (ident) { if (xnt) STEP1(true, true, false); else STEP1(true, false, false); } else { if (xnt) STEP1(false, true, false); else STEP1(false, false, false); }
+#undef STEP1
    if (fuse_beta) hipLaunchKernelGGL(k_reduce_cg<1>, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S, (double)max_iter);
    else hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RBLK), 0, s, (int)nb, partial, S + 6, S + 8);
 }

@@ -337,3 +337,25 @@ def test_pcg_graph_replay_is_bitwise_neutral(oracle, tmp_path, monkeypatch):
         d.close()
     assert np.array_equal(res[0][0], res[1][0])
     assert all(list(a) == list(b) for a, b in zip(res[0][1], res[1][1]))
+
+
+@pytest.mark.parametrize("case", ["voce_pa", "voce_ea", "mtsdd_bcc"])
+def test_pcg_consumer_side_reductions_are_bitwise_neutral(oracle, tmp_path, monkeypatch, case):
+    """One rank, fused loop: the blocks of the update / direction kernels sum the partial sums themselves (four launches per iteration) instead of two one-block
+    reduction launches in between (EXA_PCG_REDUCE_LAUNCH=1, six launches): same summation order, so with the ordered E->L sum the averages and the Newton / Krylov
+    counts are bit-identical - with stream launches and with graph replay."""
+    monkeypatch.setenv("EXA_DETERMINISTIC", "1")
+    res = []
+    for red, g in (("1", "0"), ("", "0"), ("", "all")):
+        if red:
+            monkeypatch.setenv("EXA_PCG_REDUCE_LAUNCH", red)
+        else:
+            monkeypatch.delenv("EXA_PCG_REDUCE_LAUNCH", raising=False)
+        monkeypatch.setenv("EXA_PCG_GRAPH", g)
+        d = _run(case, 4, tmp_path / (red + g))
+        res.append((d.avgs(0, 6), d.stats()))
+        d.close()
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0])
+        assert all(list(a) == list(b) for a, b in zip(res[0][1], other[1]))
+    assert sum(res[0][1][1]) > 0      # Krylov iterations were run
