@@ -344,6 +344,8 @@ def test_pcg_consumer_side_reductions_are_bitwise_neutral(oracle, tmp_path, monk
     """One rank, fused loop: the blocks of the update / direction kernels sum the partial sums themselves (four launches per iteration) instead of two one-block
     reduction launches in between (EXA_PCG_REDUCE_LAUNCH=1, six launches): same summation order, so with the ordered E->L sum the averages and the Newton / Krylov
     counts are bit-identical - with stream launches and with graph replay."""
+    if case != "voce_pa" and os.environ.get("EXA_EA_ASSEMBLED") == "1":      # (voce_ea and mtsdd_bcc assemble element matrices)
+        pytest.skip("the streamed 24 x 24 matrices scatter with atomics: deterministic mode refuses that action by design (exa_grad_apply_lvec)")
     monkeypatch.setenv("EXA_DETERMINISTIC", "1")
     res = []
     for red, g in (("1", "0"), ("", "0"), ("", "all")):
