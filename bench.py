@@ -643,6 +643,17 @@ def main():
                                                                 + [k for k in out["roofline"] if k not in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic") and not k.startswith("in_solve_frac_")])}
             out["roofline"]["in_solve"] = in_solve
         if adapter is not None:
+            # L2-boundary traffic of the adapter route's launches from the counter passes of this kernel build (Voce instantiations; per launch, like roofline.traffic)
+            try:
+                ab = (tj or {}).get("adapter_route_bytes_per_qpt") if args.model == "fcc_voce" else None
+                if ab and "model_setup" in adapter:
+                    adapter["model_setup"]["traffic"] = ab["k_model_setup_staged_aos_evec"] * P_local
+                    adapter["grad_apply"]["traffic"] = ab["k_grad_apply_p1_evec_compact_geo"] * P_local
+                    adapter["lvec_pair"]["model_setup"]["traffic"] = ab["k_model_setup_staged_aos_lvec"] * P_local
+                    adapter["lvec_pair"]["fused_records"]["traffic"] = ab["k_model_setup_staged_aos_lvec_records"] * P_local
+                    adapter["traffic_source"] = tsrc
+            except Exception:
+                pass
             out["adapter_route"] = adapter
         if world == 1 and not args.no_cpu_baseline:
             try:
