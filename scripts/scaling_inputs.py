@@ -1,6 +1,6 @@
 """Inputs of the 1/2/4/8-GPU prediction in DESIGN.md section 7, measured on ONE MI355X: per-rank kernel times of the strong-scaling
 decomposition of the 128^3 problem (128^3, 2 x 64 x 128 x 128 ... approximated by cubes of the same element count per rank) and the
-latency floor of the two RCCL calls of a PCG iteration.  Run on the GPU box: python scripts/scaling_inputs.py > gpurun_out/.../scaling_inputs.json"""
+latency floor of the two RCCL calls of a PCG iteration.  Run on the GPU box: python scripts/scaling_inputs.py gpurun_out/r06_scaling_inputs.json"""
 import ctypes as C
 import json
 import os
@@ -34,4 +34,7 @@ for N in (128, 101, 80, 64):                           # elements per edge with 
     j = bench(N, EXA_FORCE_RCCL="1", EXA_HALO_SELFTEST="1")
     out["n%d" % N]["pcg_ms_per_iter_multirank_loop_self_exchange"] = j["pcg_ms_per_iter"]
 out["library"] = {"kernel_build_id": L.exa_kernel_build_id().decode()}
-print(json.dumps(out, indent=1))
+if len(sys.argv) > 1:      # (RCCL prints its version banner to stdout when the process ends: a file keeps the JSON clean)
+    json.dump(out, open(sys.argv[1], "w"), indent=1)
+else:
+    print(json.dumps(out, indent=1))
